@@ -1,0 +1,111 @@
+/*
+ * pave_hip.h -- C ABI of libpave_hip.so: the MI355X (gfx950) device side of the
+ * PAVE-Net forward hot path.
+ *
+ * Every entry point takes plain device pointers + sizes + a hipStream_t passed
+ * as void* (no torch / ATen types), returns 0 on success and a negative
+ * PAVE_E_* code on failure (pave_last_error() has the message), launches on the
+ * given stream and never synchronises or allocates.
+ *
+ * Reference interfaces these replace (paths relative to zgspose/PAVENet):
+ *   [R1] third_party/mmcv/mmcv/ops/csrc/pytorch/pybind.cpp:160-173,737-748
+ *        Tensor ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+ *                                      sampling_loc, attn_weight, im2col_step)
+ *        -> third_party/mmcv/mmcv/ops/csrc/pytorch/cuda/ms_deform_attn_cuda.cu:209-277
+ *        -> kernel third_party/mmcv/mmcv/ops/csrc/common/cuda/ms_deform_attn_cuda_kernel.cuh:200-254
+ *   [R2] third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:305-412
+ *        MultiScaleDeformableAttention.forward: softmax over L*P, loc = ref + off/(W,H),
+ *        then [R1]  (encoder self-attention, hot loop #1)
+ *   [R3] opera/models/utils/transformer.py:1644-1863 (T=3) / 2738-3117 (T=5)
+ *        MulFramesMultiScaleDeformablePoseAttentionNumFrames{3,5}.forward: per-frame
+ *        softmax + Z_t re-weighting (== joint softmax over T*L*K), pose-box scaled
+ *        offsets, T x [R1]  (pose decoder, hot loop #2)
+ *   [R4] third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:1388-1587 (T=3) / 1590-1981 (T=5)
+ *        MulFramesMultiScaleDeformableAttentionNumFrames{3,5}.forward: same fusion with
+ *        grid offsets, T x [R1]  (joint decoder, hot loop #3)
+ */
+#ifndef PAVE_HIP_H_
+#define PAVE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAVE_OK 0
+#define PAVE_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define PAVE_E_LAUNCH (-2)  /* hipLaunchKernel reported an error */
+#define PAVE_E_STEP (-3)    /* batch %% im2col_step != 0, as the reference asserts */
+
+/* ABI version; bumped on any signature change. */
+int pave_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* pave_last_error(void);
+
+/*
+ * [R1] Multi-scale deformable attention, forward, fp32 / fp64.
+ *   value          [bs, S, M, D]
+ *   spatial_shapes [L, 2] int64 (h, w), DEVICE memory   (as the reference tensor)
+ *   level_start    [L]    int64,        DEVICE memory
+ *   sampling_loc   [bs, Lq, M, L, P, 2] (x, y) normalised to [0,1]
+ *   attn_weight    [bs, Lq, M, L, P]
+ *   out            [bs, Lq, M*D]  (fully overwritten; need not be zeroed)
+ * im2col_step only reproduces the reference's divisibility check
+ * (ms_deform_attn_cuda.cu:242-245): min(bs, step) must divide bs.
+ */
+int pave_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* sampling_loc,
+                                    const float* attn_weight, float* out, int bs, int S, int M,
+                                    int D, int L, int Lq, int P, int im2col_step, void* stream);
+int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const double* sampling_loc,
+                                    const double* attn_weight, double* out, int bs, int S, int M,
+                                    int D, int L, int Lq, int P, int im2col_step, void* stream);
+
+/*
+ * Fused T-frame deformable attention (M = 8 heads x D = 32 channels).
+ *
+ * One launch replaces, for all T frames: softmax / Z_t arithmetic, sampling
+ * location arithmetic, T calls of [R1] and the cross-frame fusion.  The softmax
+ * is the numerically stabilised joint softmax over all T*L*P logits of a
+ * (unit, head), which is algebraically what [R3]/[R4] compute with an
+ * un-stabilised exp.
+ *
+ * "unit" = one query row: encoder token (b, q) / pose query (b, q) / joint query (n, k).
+ *
+ *   value      [n_clips*T, S, 8, 32]  projected (and padding-masked) memory; frame t of
+ *                                     clip c is slab c*T + t
+ *   proj       [n_units, proj_stride] raw outputs of the offset / logit Linears for one unit:
+ *                offsets at [t][m][l][p][2] starting at column 0,
+ *                logits  at [t][m][l][p]    starting at column T*8*L*P*2
+ *   unit_clip  [n_units] int32 clip index of each unit, or NULL => unit / units_per_clip
+ *   order      [n_units] int32 permutation giving the processing order of units (XCD/L2
+ *              locality), or NULL => identity
+ *   out        [n_units, 256]
+ *   stat_max, stat_sum  [n_units, 8] or NULL: per-head max logit and sum(exp(logit-max)) over the
+ *              frames this call saw (for merging frame-sharded partial results)
+ *
+ * GRID form ([R2] with T = 1, [R4]): L = 4 levels x P = 4 points;
+ *   ref [T, n_units, L, 2] (already multiplied by valid ratios);  loc = ref + off / (W_l, H_l)
+ * POSE form ([R3]): L levels x P = K keypoints (K <= 24);
+ *   ref [n_clips, T, Q, L, 2K] with n_units = n_clips*Q;  wh = clamp(max-min over K, 1e-4);
+ *   loc = ref_k + off * wh * 0.5
+ */
+int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* proj,
+                                    const float* ref, const int32_t* unit_clip,
+                                    const int32_t* order, float* out, float* stat_max,
+                                    float* stat_sum, int n_units, int units_per_clip, int n_clips,
+                                    int T, int S, int L, int P, int proj_stride, void* stream);
+
+int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* proj,
+                                    const float* ref, float* out, float* stat_max,
+                                    float* stat_sum, int n_clips, int Q, int T, int S, int L,
+                                    int K, int proj_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAVE_HIP_H_ */

@@ -1,0 +1,641 @@
+// pave_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the PAVE-Net
+// forward hot path + their C ABI (include/pave_hip.h).
+//
+// Written for MI355X only: 64-lane wavefronts, 8 lanes x float4 = one 128-byte
+// value row per attention head, LDS-staged sampling descriptors, XCD-aware
+// block -> unit mapping.  No CUDA compatibility layer.
+//
+// Semantics restated from (zgspose/PAVENet):
+//   third_party/mmcv/mmcv/ops/csrc/common/cuda/ms_deform_attn_cuda_kernel.cuh:17-64,200-254
+//   third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:305-412, 1388-1587
+//   opera/models/utils/transformer.py:1644-1863
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pave_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kHeads = 8;      // fused kernels: M
+constexpr int kDim = 32;       // fused kernels: D
+constexpr int kRowFloats = kHeads * kDim;  // 256 floats = 1 KiB per token
+constexpr int kMaxLevels = 8;
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// [R1] generic forward: arbitrary M, D, L, P; scalar_t = float | double.
+// One thread per output scalar (b, q, m, c), exactly the reference's work
+// decomposition, used for shapes the vector kernel does not cover (D % 4 != 0,
+// fp64).  Arithmetic order follows ms_deform_attn_cuda_kernel.cuh:200-254.
+// ---------------------------------------------------------------------------
+template <typename scalar_t>
+__global__ __launch_bounds__(256) void msda_fwd_scalar_kernel(
+    const long long n, const scalar_t* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const scalar_t* __restrict__ loc,
+    const scalar_t* __restrict__ attw, const int S, const int M, const int D, const int L,
+    const int Lq, const int P, scalar_t* __restrict__ out) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < n;
+       index += (long long)gridDim.x * blockDim.x) {
+    long long tmp = index;
+    const int c = (int)(tmp % D);
+    tmp /= D;
+    const long long sampling_index = tmp;  // (b*Lq + q)*M + m
+    const int m = (int)(tmp % M);
+    tmp /= M;
+    tmp /= Lq;
+    const long long b = tmp;
+    long long wptr = sampling_index * L * P;
+    long long lptr = wptr << 1;
+    const long long row = (long long)M * D;
+    const scalar_t* vb = value + b * S * row;
+    scalar_t col = 0;
+    for (int l = 0; l < L; ++l) {
+      const long long start = lsi[l];
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const scalar_t* vl = vb + start * row;
+      for (int p = 0; p < P; ++p) {
+        const scalar_t loc_w = loc[lptr], loc_h = loc[lptr + 1];
+        const scalar_t weight = attw[wptr];
+        const scalar_t h_im = loc_h * H - (scalar_t)0.5;
+        const scalar_t w_im = loc_w * W - (scalar_t)0.5;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const scalar_t lh = h_im - h_low, lw = w_im - w_low;
+          const scalar_t hh = 1 - lh, hw = 1 - lw;
+          scalar_t v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+          const long long base = (long long)m * D + c;
+          if (h_low >= 0 && w_low >= 0) v1 = vl[((long long)h_low * W + w_low) * row + base];
+          if (h_low >= 0 && w_high <= W - 1) v2 = vl[((long long)h_low * W + w_high) * row + base];
+          if (h_high <= H - 1 && w_low >= 0) v3 = vl[((long long)h_high * W + w_low) * row + base];
+          if (h_high <= H - 1 && w_high <= W - 1)
+            v4 = vl[((long long)h_high * W + w_high) * row + base];
+          const scalar_t w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          col += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * weight;
+        }
+        wptr += 1;
+        lptr += 2;
+      }
+    }
+    out[index] = col;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Bilinear corner descriptor shared by the vector kernels: 4 weights (already
+// multiplied by the attention weight, 0 for a corner outside the map) and 4
+// byte offsets of the corner's 128-byte head row relative to the frame slab.
+// ---------------------------------------------------------------------------
+struct Corners {
+  float w[4];
+  int o[4];
+};
+
+// px, py: pixel-space sample position (loc * size - 0.5).  `rowbytes` = M*D*4.
+__device__ __forceinline__ Corners make_corners(float px, float py, int H, int W, int start,
+                                                int head_byte, int rowbytes, float aw) {
+  Corners c;
+  const bool inside = (py > -1.f) && (px > -1.f) && (py < (float)H) && (px < (float)W);
+  const float fy = floorf(py), fx = floorf(px);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + 1, x1 = x0 + 1;
+  const float ly = py - fy, lx = px - fx;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const bool y0ok = inside && (y0 >= 0), y1ok = inside && (y1 <= H - 1);
+  const bool x0ok = (x0 >= 0), x1ok = (x1 <= W - 1);
+  c.w[0] = (y0ok && x0ok) ? hy * hx * aw : 0.f;
+  c.w[1] = (y0ok && x1ok) ? hy * lx * aw : 0.f;
+  c.w[2] = (y1ok && x0ok) ? ly * hx * aw : 0.f;
+  c.w[3] = (y1ok && x1ok) ? ly * lx * aw : 0.f;
+  // clamp so that a masked corner still reads a nearby, valid (cached) row
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  c.o[0] = (start + cy0 * W + cx0) * rowbytes + head_byte;
+  c.o[1] = (start + cy0 * W + cx1) * rowbytes + head_byte;
+  c.o[2] = (start + cy1 * W + cx0) * rowbytes + head_byte;
+  c.o[3] = (start + cy1 * W + cx1) * rowbytes + head_byte;
+  return c;
+}
+
+__device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
+  return *reinterpret_cast<const float4*>(base + off);
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
+  acc.x = fmaf(w, v.x, acc.x);
+  acc.y = fmaf(w, v.y, acc.y);
+  acc.z = fmaf(w, v.z, acc.z);
+  acc.w = fmaf(w, v.w, acc.w);
+}
+
+// ---------------------------------------------------------------------------
+// [R1] vector forward, fp32, D % 4 == 0, G = D/4 lanes per (b, q, m) group, G a
+// power of two <= 64.  Each lane owns 4 channels and walks the L*P points of its
+// group; loc / weight reads are same-address broadcasts inside the group.
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void msda_fwd_vec_kernel(
+    const long long ngroups, const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+    const float* __restrict__ attw, const int S, const int M, const int D, const int L,
+    const int Lq, const int P, float* __restrict__ out) {
+  int Hs[kMaxLevels], Ws[kMaxLevels], St[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    if (l < L) {
+      Hs[l] = (int)shapes[2 * l];
+      Ws[l] = (int)shapes[2 * l + 1];
+      St[l] = (int)lsi[l];
+    } else {
+      Hs[l] = Ws[l] = 1;
+      St[l] = 0;
+    }
+  }
+  const int rowbytes = M * D * 4;
+  const long long slab = (long long)S * rowbytes;
+  constexpr int kGroupsPerBlock = 256 / G;
+  const int sub = threadIdx.x % G;
+  for (long long g = (long long)blockIdx.x * kGroupsPerBlock + threadIdx.x / G; g < ngroups;
+       g += (long long)gridDim.x * kGroupsPerBlock) {
+    const int m = (int)(g % M);
+    const long long b = g / ((long long)M * Lq);
+    const char* vb = reinterpret_cast<const char*>(value) + b * slab + sub * 16;
+    const float* lp = loc + g * L * P * 2;
+    const float* wp = attw + g * L * P;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) {
+      if (l < L) {
+        const int H = Hs[l], W = Ws[l];
+        for (int p = 0; p < P; ++p) {
+          const float2 xy = *reinterpret_cast<const float2*>(lp);
+          const float aw = *wp;
+          lp += 2;
+          wp += 1;
+          const Corners c =
+              make_corners(xy.x * W - 0.5f, xy.y * H - 0.5f, H, W, St[l], m * D * 4, rowbytes, aw);
+          const float4 v0 = ld16(vb, c.o[0]), v1 = ld16(vb, c.o[1]);
+          const float4 v2 = ld16(vb, c.o[2]), v3 = ld16(vb, c.o[3]);
+          fma4(acc, c.w[0], v0);
+          fma4(acc, c.w[1], v1);
+          fma4(acc, c.w[2], v2);
+          fma4(acc, c.w[3], v3);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + g * D + sub * 4) = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused T-frame deformable attention, M = 8 x D = 32.
+//
+// Wave layout: lane = (head h = lane>>3, sub j = lane&7).  The 8 lanes of a head
+// own the head's 32 channels as float4 each, so one corner fetch is one 128-byte
+// row per head and a wave instruction gathers 8 rows.
+//
+// Work is cut into ITEMS of <= 8*PPL sampling points per head:
+//   GRID: item = frame t, 16 points = 4 levels x 4 points (slot i -> l = i>>2)
+//   POSE: item = (frame t, level l), K keypoints
+// Lane j of a head prepares the corner descriptors of points j*PPL .. j*PPL+PPL-1
+// of the item (location arithmetic + softmax weight), stages them in LDS, and
+// all 8 lanes of the head then walk the item's points reading the descriptors as
+// LDS broadcasts.
+//
+// Softmax: every wave first makes one online (max, sum-exp) pass over ALL
+// T*L*P logits of its unit (8 lanes/head + 3 xor-shuffles), so its items carry
+// final normalised weights; waves of one unit just add their partial rows
+// through LDS at the end.
+// ---------------------------------------------------------------------------
+enum { kGrid = 0, kPose = 1 };
+
+struct FusedParams {
+  const float* value;
+  const int64_t* shapes;
+  const int64_t* lsi;
+  const float* proj;
+  const float* ref;
+  const int32_t* unit_clip;
+  const int32_t* order;
+  float* out;
+  float* stat_max;
+  float* stat_sum;
+  int n_units;
+  int units_per_clip;
+  int T;
+  int S;
+  int L;
+  int P;  // points per level (GRID: 4; POSE: K)
+  int proj_stride;
+  int n_blocks_logical;
+};
+
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  return v;
+}
+__device__ __forceinline__ float group8_min(float v) {
+  v = fminf(v, __shfl_xor(v, 1));
+  v = fminf(v, __shfl_xor(v, 2));
+  v = fminf(v, __shfl_xor(v, 4));
+  return v;
+}
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+
+// XCD-aware bijective remap: hardware deals blocks round-robin over the 8 XCDs
+// (block b -> XCD b % 8); give each XCD one contiguous run of logical blocks so
+// that the units it processes (ordered by image band on the host) share its L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int per = nb >> 3, rem = nb & 7;
+  const int x = b & 7, idx = b >> 3;
+  return x * per + min(x, rem) + idx;
+}
+
+template <int MODE, int PPL, int WQ>
+__global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParams p) {
+  constexpr int kWavesPerBlock = 4;
+  constexpr int kUnitsPerBlock = kWavesPerBlock / WQ;
+  constexpr int kSlots = 8 * PPL;
+  constexpr int kHeadStride = kSlots * 8 + 8;  // floats; +8 pad => heads on distinct banks
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kHeads * kHeadStride];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int h = lane >> 3, j = lane & 7;
+  const int wq = wave % WQ;  // which of the unit's WQ waves
+  const int logical_block = xcd_remap(blockIdx.x, p.n_blocks_logical);
+  const int slot_unit = logical_block * kUnitsPerBlock + wave / WQ;
+  const bool active = slot_unit < p.n_units;
+  const int unit = active ? (p.order ? p.order[slot_unit] : slot_unit) : 0;
+
+  const int L = p.L, P = p.P, T = p.T;
+  const int LP = L * P;
+  const int rowbytes = kRowFloats * 4;
+  float* my_lds = lds + (wave * kHeads + h) * kHeadStride;
+
+  // level table (uniform -> SGPRs)
+  int Hs[4], Ws[4], St[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int ll = l < L ? l : 0;
+    Hs[l] = (int)p.shapes[2 * ll];
+    Ws[l] = (int)p.shapes[2 * ll + 1];
+    St[l] = (int)p.lsi[ll];
+  }
+
+  const float* row = p.proj + (long long)unit * p.proj_stride;
+  const float* off_row = row;                            // [T][8][LP][2]
+  const float* logit_row = row + (long long)T * kHeads * LP * 2;  // [T][8][LP]
+  const int n_items = (MODE == kGrid) ? T : T * L;
+  const int n_items_run = active ? n_items : 0;  // idle waves still join the barriers
+  const int pts = (MODE == kGrid) ? 16 : P;  // valid slots per item
+
+  // ---- pass 1: online softmax statistics over all T*LP logits of (unit, head)
+  float mx = -INFINITY, sm = 0.f;
+  for (int it = 0; it < n_items; ++it) {
+    const int t = (MODE == kGrid) ? it : it / L;
+    const int lp0 = (MODE == kGrid) ? 0 : (it % L) * P;
+    const float* lg = logit_row + (t * kHeads + h) * LP + lp0;
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+      const int i = j * PPL + s;
+      if (i < pts) {
+        const float x = lg[i];
+        const float nm = fmaxf(mx, x);
+        sm = sm * expf(mx - nm) + expf(x - nm);
+        mx = nm;
+      }
+    }
+  }
+  {
+    const float gm = group8_max(mx);
+    sm = (mx == -INFINITY) ? 0.f : sm * expf(mx - gm);
+    sm = group8_sum(sm);
+    mx = gm;
+  }
+  const float inv_sum = 1.f / sm;
+
+  const int clip = p.unit_clip ? p.unit_clip[unit] : unit / p.units_per_clip;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- pass 2: this wave's items
+  for (int it = wq; it < n_items_run; it += WQ) {
+    const int t = (MODE == kGrid) ? it : it / L;
+    const int lvl = (MODE == kGrid) ? 0 : it % L;
+    const int lp0 = (MODE == kGrid) ? 0 : lvl * P;
+    const float* lg = logit_row + (t * kHeads + h) * LP + lp0;
+    const float* of = off_row + ((long long)(t * kHeads + h) * LP + lp0) * 2;
+    const char* frame = reinterpret_cast<const char*>(p.value) +
+                        (long long)(clip * T + t) * p.S * rowbytes + j * 16;
+
+    float rx[PPL], ry[PPL];
+    float whx = 0.f, why = 0.f;
+    if (MODE == kPose) {
+      // ref [n_clips, T, Q, L, 2K]; unit = clip*Q + q
+      const int q = unit - clip * p.units_per_clip;
+      const float* rp =
+          p.ref + ((((long long)clip * T + t) * p.units_per_clip + q) * L + lvl) * (2 * P);
+      float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+#pragma unroll
+      for (int s = 0; s < PPL; ++s) {
+        const int i = j * PPL + s;
+        if (i < pts) {
+          const float2 r = *reinterpret_cast<const float2*>(rp + 2 * i);
+          rx[s] = r.x;
+          ry[s] = r.y;
+          xmin = fminf(xmin, r.x);
+          xmax = fmaxf(xmax, r.x);
+          ymin = fminf(ymin, r.y);
+          ymax = fmaxf(ymax, r.y);
+        } else {
+          rx[s] = ry[s] = 0.f;
+        }
+      }
+      xmin = group8_min(xmin);
+      xmax = group8_max(xmax);
+      ymin = group8_min(ymin);
+      ymax = group8_max(ymax);
+      whx = fmaxf(xmax - xmin, 1e-4f);
+      why = fmaxf(ymax - ymin, 1e-4f);
+    }
+
+    // descriptors of my PPL points -> LDS
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+      const int i = j * PPL + s;
+      Corners c;
+      if (i < pts) {
+        const int l = (MODE == kGrid) ? (i >> 2) : lvl;
+        // select level constants without dynamic register indexing
+        const int H = l == 0 ? Hs[0] : l == 1 ? Hs[1] : l == 2 ? Hs[2] : Hs[3];
+        const int W = l == 0 ? Ws[0] : l == 1 ? Ws[1] : l == 2 ? Ws[2] : Ws[3];
+        const int st = l == 0 ? St[0] : l == 1 ? St[1] : l == 2 ? St[2] : St[3];
+        const float2 o = *reinterpret_cast<const float2*>(of + 2 * i);
+        const float aw = expf(lg[i] - mx) * inv_sum;
+        float lx, ly;
+        if (MODE == kGrid) {
+          // ref [T, n_units, L, 2]
+          const float2 r = *reinterpret_cast<const float2*>(
+              p.ref + (((long long)t * p.n_units + unit) * L + l) * 2);
+          lx = r.x + o.x / (float)W;
+          ly = r.y + o.y / (float)H;
+        } else {
+          lx = rx[s] + o.x * whx * 0.5f;
+          ly = ry[s] + o.y * why * 0.5f;
+        }
+        c = make_corners(lx * (float)W - 0.5f, ly * (float)H - 0.5f, H, W, st, h * kDim * 4,
+                         rowbytes, aw);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c.w[k] = 0.f;
+          c.o[k] = h * kDim * 4;
+        }
+      }
+      float4* dst = reinterpret_cast<float4*>(my_lds + i * 8);
+      dst[0] = make_float4(c.w[0], c.w[1], c.w[2], c.w[3]);
+      dst[1] = make_float4(__int_as_float(c.o[0]), __int_as_float(c.o[1]),
+                           __int_as_float(c.o[2]), __int_as_float(c.o[3]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // gather: all 8 lanes of the head walk the item's points
+#pragma unroll 4
+    for (int i = 0; i < pts; ++i) {
+      const float4* src = reinterpret_cast<const float4*>(my_lds + i * 8);
+      const float4 w = src[0];
+      const float4 o = src[1];
+      const float4 v0 = ld16(frame, (unsigned)__float_as_int(o.x));
+      const float4 v1 = ld16(frame, (unsigned)__float_as_int(o.y));
+      const float4 v2 = ld16(frame, (unsigned)__float_as_int(o.z));
+      const float4 v3 = ld16(frame, (unsigned)__float_as_int(o.w));
+      fma4(acc, w.x, v0);
+      fma4(acc, w.y, v1);
+      fma4(acc, w.z, v2);
+      fma4(acc, w.w, v3);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- combine the WQ partial rows of a unit
+  if (WQ > 1) {
+    __syncthreads();  // every wave is done with its descriptor region
+    float4* red = reinterpret_cast<float4*>(lds);  // [wave][64] float4 = 4 KiB
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wq == 0) {
+#pragma unroll
+      for (int k = 1; k < WQ; ++k) {
+        const float4 o = red[(wave + k) * 64 + lane];
+        acc.x += o.x;
+        acc.y += o.y;
+        acc.z += o.z;
+        acc.w += o.w;
+      }
+    }
+  }
+  if (active && wq == 0) {
+    *reinterpret_cast<float4*>(p.out + (long long)unit * kRowFloats + lane * 4) = acc;
+    if (p.stat_max && j == 0) {
+      p.stat_max[(long long)unit * kHeads + h] = mx;
+      p.stat_sum[(long long)unit * kHeads + h] = sm;
+    }
+  }
+}
+
+template <int MODE, int PPL, int WQ>
+int launch_fused(const FusedParams& p0, hipStream_t stream) {
+  FusedParams p = p0;
+  constexpr int kUnitsPerBlock = 4 / WQ;
+  const int nb = (p.n_units + kUnitsPerBlock - 1) / kUnitsPerBlock;
+  p.n_blocks_logical = nb;
+  hipLaunchKernelGGL((fused_deform_attn_kernel<MODE, PPL, WQ>), dim3(nb), dim3(256), 0, stream, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+template <typename scalar_t>
+int msda_forward_impl(const scalar_t* value, const int64_t* shapes, const int64_t* lsi,
+                      const scalar_t* loc, const scalar_t* attw, scalar_t* out, int bs, int S,
+                      int M, int D, int L, int Lq, int P, int im2col_step, void* stream) {
+  if (!value || !shapes || !lsi || !loc || !attw || !out)
+    return fail(PAVE_E_ARG, "ms_deform_attn_forward: null pointer");
+  if (bs <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0 || im2col_step <= 0)
+    return fail(PAVE_E_ARG, "ms_deform_attn_forward: sizes must be positive");
+  if (L > kMaxLevels) return fail(PAVE_E_ARG, "ms_deform_attn_forward: more than 8 levels");
+  const int step = bs < im2col_step ? bs : im2col_step;
+  if (bs % step != 0)
+    return fail(PAVE_E_STEP, "ms_deform_attn_forward: batch must be divisible by im2col_step");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long n = (long long)bs * Lq * M * D;
+  if ((long long)S * M * D * (long long)sizeof(scalar_t) >= (1ll << 31))
+    return fail(PAVE_E_ARG, "ms_deform_attn_forward: one value slab must be < 2 GiB");
+  bool launched = false;
+  if constexpr (sizeof(scalar_t) == 4) {
+    const int G = D / 4;
+    const long long ngroups = (long long)bs * Lq * M;
+    if (D % 4 == 0 && (G & (G - 1)) == 0 && G <= 64) {
+      const float* v = reinterpret_cast<const float*>(value);
+      const float* lc = reinterpret_cast<const float*>(loc);
+      const float* aw = reinterpret_cast<const float*>(attw);
+      float* o = reinterpret_cast<float*>(out);
+#define PAVE_LAUNCH_VEC(GG)                                                                     \
+  {                                                                                             \
+    const long long per = 256 / GG;                                                             \
+    long long nb = (ngroups + per - 1) / per;                                                   \
+    if (nb > 65536 * 4) nb = 65536 * 4;                                                         \
+    hipLaunchKernelGGL((msda_fwd_vec_kernel<GG>), dim3((unsigned)nb), dim3(256), 0, st, ngroups, \
+                       v, shapes, lsi, lc, aw, S, M, D, L, Lq, P, o);                           \
+    launched = true;                                                                            \
+  }
+      switch (G) {
+        case 1: PAVE_LAUNCH_VEC(1) break;
+        case 2: PAVE_LAUNCH_VEC(2) break;
+        case 4: PAVE_LAUNCH_VEC(4) break;
+        case 8: PAVE_LAUNCH_VEC(8) break;
+        case 16: PAVE_LAUNCH_VEC(16) break;
+        case 32: PAVE_LAUNCH_VEC(32) break;
+        case 64: PAVE_LAUNCH_VEC(64) break;
+      }
+#undef PAVE_LAUNCH_VEC
+    }
+  }
+  if (!launched) {
+    long long nb = (n + 255) / 256;
+    if (nb > 65536 * 4) nb = 65536 * 4;
+    hipLaunchKernelGGL((msda_fwd_scalar_kernel<scalar_t>), dim3((unsigned)nb), dim3(256), 0, st, n,
+                       value, shapes, lsi, loc, attw, S, M, D, L, Lq, P, out);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pave_abi_version(void) { return 1; }
+const char* pave_last_error(void) { return g_err; }
+
+int pave_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* sampling_loc,
+                                    const float* attn_weight, float* out, int bs, int S, int M,
+                                    int D, int L, int Lq, int P, int im2col_step, void* stream) {
+  return msda_forward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                                  out, bs, S, M, D, L, Lq, P, im2col_step, stream);
+}
+
+int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const double* sampling_loc,
+                                    const double* attn_weight, double* out, int bs, int S, int M,
+                                    int D, int L, int Lq, int P, int im2col_step, void* stream) {
+  return msda_forward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                                   out, bs, S, M, D, L, Lq, P, im2col_step, stream);
+}
+
+int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* proj,
+                                    const float* ref, const int32_t* unit_clip,
+                                    const int32_t* order, float* out, float* stat_max,
+                                    float* stat_sum, int n_units, int units_per_clip, int n_clips,
+                                    int T, int S, int L, int P, int proj_stride, void* stream) {
+  if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: null pointer");
+  if (n_units <= 0 || T <= 0 || S <= 0 || n_clips <= 0 || units_per_clip <= 0)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: sizes must be positive");
+  if (L != 4 || P != 4)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: only L = 4, P = 4 is built");
+  if ((stat_max == nullptr) != (stat_sum == nullptr))
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: stat_max / stat_sum must both be given");
+  if (proj_stride < T * kHeads * L * P * 3)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: proj_stride too small");
+  if ((long long)S * kRowFloats * 4 >= (1ll << 31))
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: one value slab must be < 2 GiB");
+  if (!unit_clip && (long long)n_clips * units_per_clip < n_units)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: n_units exceeds n_clips * units_per_clip");
+  FusedParams p{};
+  p.value = value;
+  p.shapes = spatial_shapes;
+  p.lsi = level_start;
+  p.proj = proj;
+  p.ref = ref;
+  p.unit_clip = unit_clip;
+  p.order = order;
+  p.out = out;
+  p.stat_max = stat_max;
+  p.stat_sum = stat_sum;
+  p.n_units = n_units;
+  p.units_per_clip = units_per_clip;
+  p.T = T;
+  p.S = S;
+  p.L = L;
+  p.P = P;
+  p.proj_stride = proj_stride;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (T == 1) return launch_fused<kGrid, 2, 1>(p, st);
+  if (T == 2) return launch_fused<kGrid, 2, 2>(p, st);
+  return launch_fused<kGrid, 2, 4>(p, st);
+}
+
+int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* proj,
+                                    const float* ref, float* out, float* stat_max,
+                                    float* stat_sum, int n_clips, int Q, int T, int S, int L,
+                                    int K, int proj_stride, void* stream) {
+  if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: null pointer");
+  if (n_clips <= 0 || Q <= 0 || T <= 0 || S <= 0 || K <= 0)
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: sizes must be positive");
+  if (L < 1 || L > 4) return fail(PAVE_E_ARG, "deform_attn_pose_fused: 1 <= L <= 4 levels");
+  if (K > 24) return fail(PAVE_E_ARG, "deform_attn_pose_fused: at most 24 keypoints");
+  if ((stat_max == nullptr) != (stat_sum == nullptr))
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: stat_max / stat_sum must both be given");
+  if (proj_stride < T * kHeads * L * K * 3)
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: proj_stride too small");
+  if ((long long)S * kRowFloats * 4 >= (1ll << 31))
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: one value slab must be < 2 GiB");
+  FusedParams p{};
+  p.value = value;
+  p.shapes = spatial_shapes;
+  p.lsi = level_start;
+  p.proj = proj;
+  p.ref = ref;
+  p.unit_clip = nullptr;
+  p.order = nullptr;
+  p.out = out;
+  p.stat_max = stat_max;
+  p.stat_sum = stat_sum;
+  p.n_units = n_clips * Q;
+  p.units_per_clip = Q;
+  p.T = T;
+  p.S = S;
+  p.L = L;
+  p.P = K;
+  p.proj_stride = proj_stride;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (K <= 16) return launch_fused<kPose, 2, 4>(p, st);
+  return launch_fused<kPose, 3, 4>(p, st);
+}
+
+}  // extern "C"

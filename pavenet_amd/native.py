@@ -1,0 +1,59 @@
+"""ctypes binding of libpave_hip.so (C ABI declared in include/pave_hip.h).
+
+The library is built in-tree by ``pavenet_amd.build_native`` (hipcc,
+--offload-arch=gfx950).  There is NO fallback: if the shared object is missing
+or a symbol is absent, importing the product ops raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpave_hip.so')
+
+_c_int = ctypes.c_int
+_vp = ctypes.c_void_p
+
+# name -> argtypes; every entry point returns int (0 = PAVE_OK)
+SIGNATURES = {
+    'pave_ms_deform_attn_forward_f32': [_vp] * 6 + [_c_int] * 8 + [_vp],
+    'pave_ms_deform_attn_forward_f64': [_vp] * 6 + [_c_int] * 8 + [_vp],
+    'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp],
+    'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp],
+}
+# every symbol include/pave_hip.h declares
+EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpave_hip.so (once) and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; '
+            f'g.build()"` (hipcc --offload-arch=gfx950). pavenet_amd has no '
+            f'CPU or eager fallback for its HIP kernels.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    lib.pave_abi_version.restype = _c_int
+    lib.pave_abi_version.argtypes = []
+    lib.pave_last_error.restype = ctypes.c_char_p
+    lib.pave_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pave_last_error().decode()
+        raise RuntimeError(f'{what} failed with status {status}: {msg}')

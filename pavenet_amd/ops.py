@@ -1,0 +1,185 @@
+"""Torch-facing wrappers of the HIP kernels (device tensors in, device tensors out).
+
+Mirrors the reference operator surface for this path:
+
+* ``ms_deform_attn_forward`` -- same name and keyword names as the pybind export
+  ``mmcv._ext.ms_deform_attn_forward``
+  (third_party/mmcv/mmcv/ops/csrc/pytorch/pybind.cpp:737-741);
+* ``MultiScaleDeformableAttnFunction`` -- same ``apply`` signature as
+  third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:20-57;
+* ``deform_attn_grid_fused`` / ``deform_attn_pose_fused`` -- the fused T-frame
+  launches that replace the per-frame softmax / location / sampling / fusion
+  chain of MO:1388-1587 and OT:1644-1863.
+
+PyTorch is used here only for device memory and the current HIP stream.  There
+is no CPU path: a non-device tensor raises, exactly as the reference's
+``AT_ASSERTM(value.is_cuda())`` does (ms_deform_attn_cuda.cu:221-230).
+"""
+import torch
+
+from . import native
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev(t, name, dtype=None):
+    _require(isinstance(t, torch.Tensor), f'{name} must be a tensor')
+    _require(t.is_cuda, f'{name} must be a HIP device tensor (pavenet_amd has no CPU path)')
+    _require(t.is_contiguous(), f'{name} tensor has to be contiguous')
+    if dtype is not None:
+        _require(t.dtype == dtype, f'{name} must be {dtype}, got {t.dtype}')
+    return t
+
+
+def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                           sampling_locations, attention_weights, im2col_step=64):
+    """[R1] value [bs,S,M,D], shapes [L,2] i64, lsi [L] i64, loc [bs,Lq,M,L,P,2],
+    weights [bs,Lq,M,L,P] -> [bs, Lq, M*D]."""
+    lib = native.load()
+    _require(value.dtype in (torch.float32, torch.float64),
+             'ms_deform_attn_forward: value must be float32 or float64')
+    dt = value.dtype
+    _dev(value, 'value', dt)
+    _dev(value_spatial_shapes, 'spatial_shapes', torch.int64)
+    _dev(value_level_start_index, 'level_start_index', torch.int64)
+    _dev(sampling_locations, 'sampling_loc', dt)
+    _dev(attention_weights, 'attn_weight', dt)
+    _require(value.dim() == 4 and sampling_locations.dim() == 6 and attention_weights.dim() == 5,
+             'ms_deform_attn_forward: bad tensor ranks')
+    bs, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_locations.shape
+    _require(M2 == M and two == 2 and sampling_locations.shape[0] == bs,
+             'ms_deform_attn_forward: sampling_loc shape mismatch')
+    _require(tuple(attention_weights.shape) == (bs, Lq, M, L, P),
+             'ms_deform_attn_forward: attn_weight shape mismatch')
+    _require(tuple(value_spatial_shapes.shape) == (L, 2) and
+             tuple(value_level_start_index.shape) == (L,),
+             'ms_deform_attn_forward: spatial_shapes / level_start_index shape mismatch')
+    out = torch.empty((bs, Lq, M * D), dtype=dt, device=value.device)
+    fn = (lib.pave_ms_deform_attn_forward_f32 if dt == torch.float32
+          else lib.pave_ms_deform_attn_forward_f64)
+    with torch.cuda.device(value.device):
+        st = fn(value.data_ptr(), value_spatial_shapes.data_ptr(),
+                value_level_start_index.data_ptr(), sampling_locations.data_ptr(),
+                attention_weights.data_ptr(), out.data_ptr(), bs, S, M, D, L, Lq, P,
+                int(im2col_step), _stream_ptr())
+    native.check(st, 'ms_deform_attn_forward')
+    return out
+
+
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """Same ``apply(value, shapes, lsi, loc, weights, im2col_step)`` as MO:20-57.
+
+    Forward only this round (backward is "next").
+    """
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index,
+                sampling_locations, attention_weights, im2col_step):
+        return ms_deform_attn_forward(
+            value, value_spatial_shapes, value_level_start_index,
+            sampling_locations, attention_weights, im2col_step=im2col_step)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError(
+            'pavenet_amd: ms_deform_attn_backward is not built yet (forward-only path)')
+
+
+def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,
+                           n_clips, units_per_clip, unit_clip=None, order=None,
+                           return_stats=False):
+    """Fused grid-offset deformable attention over T frames ([R2] with T=1, [R4]).
+
+    value [n_clips*T, S, 8, 32]; proj [n_units, >= T*8*16*3]; ref [T, n_units, 4, 2]
+    -> out [n_units, 256] (+ (max, sum) [n_units, 8] if return_stats).
+    """
+    lib = native.load()
+    f32 = torch.float32
+    _dev(value, 'value', f32)
+    _dev(spatial_shapes, 'spatial_shapes', torch.int64)
+    _dev(level_start_index, 'level_start_index', torch.int64)
+    _dev(proj, 'proj', f32)
+    _dev(ref, 'ref', f32)
+    _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
+             'deform_attn_grid_fused: value must be [frames, S, 8, 32]')
+    _require(value.shape[0] == n_clips * T, 'deform_attn_grid_fused: value frames != n_clips*T')
+    S = value.shape[1]
+    L = spatial_shapes.shape[0]
+    _require(proj.dim() == 2, 'deform_attn_grid_fused: proj must be 2-D')
+    n_units = proj.shape[0]
+    _require(tuple(ref.shape) == (T, n_units, L, 2),
+             f'deform_attn_grid_fused: ref must be [T, n_units, L, 2], got {tuple(ref.shape)}')
+    if unit_clip is not None:
+        _dev(unit_clip, 'unit_clip', torch.int32)
+        _require(unit_clip.numel() == n_units, 'deform_attn_grid_fused: unit_clip length')
+    if order is not None:
+        _dev(order, 'order', torch.int32)
+        _require(order.numel() == n_units, 'deform_attn_grid_fused: order length')
+    out = torch.empty((n_units, 256), dtype=f32, device=value.device)
+    smax = ssum = None
+    if return_stats:
+        smax = torch.empty((n_units, 8), dtype=f32, device=value.device)
+        ssum = torch.empty((n_units, 8), dtype=f32, device=value.device)
+    with torch.cuda.device(value.device):
+        st = lib.pave_deform_attn_grid_fused_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            proj.data_ptr(), ref.data_ptr(),
+            unit_clip.data_ptr() if unit_clip is not None else None,
+            order.data_ptr() if order is not None else None, out.data_ptr(),
+            smax.data_ptr() if return_stats else None,
+            ssum.data_ptr() if return_stats else None, n_units, int(units_per_clip),
+            int(n_clips), int(T), S, L, 4, proj.stride(0), _stream_ptr())
+    native.check(st, 'deform_attn_grid_fused')
+    if return_stats:
+        return out, smax, ssum
+    return out
+
+
+def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,
+                           n_clips, num_query, num_keypoints, return_stats=False):
+    """Fused pose-aware deformable attention over T frames ([R3]).
+
+    value [n_clips*T, S, 8, 32]; proj [n_clips*Q, >= T*8*L*K*3];
+    ref [n_clips, T*Q, L, 2K] -> out [n_clips*Q, 256].
+    """
+    lib = native.load()
+    f32 = torch.float32
+    _dev(value, 'value', f32)
+    _dev(spatial_shapes, 'spatial_shapes', torch.int64)
+    _dev(level_start_index, 'level_start_index', torch.int64)
+    _dev(proj, 'proj', f32)
+    _dev(ref, 'ref', f32)
+    _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
+             'deform_attn_pose_fused: value must be [frames, S, 8, 32]')
+    _require(value.shape[0] == n_clips * T, 'deform_attn_pose_fused: value frames != n_clips*T')
+    S = value.shape[1]
+    L = spatial_shapes.shape[0]
+    Q, K = int(num_query), int(num_keypoints)
+    _require(proj.dim() == 2 and proj.shape[0] == n_clips * Q,
+             'deform_attn_pose_fused: proj must be [n_clips*Q, cols]')
+    _require(ref.numel() == n_clips * T * Q * L * 2 * K,
+             'deform_attn_pose_fused: ref must be [n_clips, T*Q, L, 2K]')
+    out = torch.empty((n_clips * Q, 256), dtype=f32, device=value.device)
+    smax = ssum = None
+    if return_stats:
+        smax = torch.empty((n_clips * Q, 8), dtype=f32, device=value.device)
+        ssum = torch.empty((n_clips * Q, 8), dtype=f32, device=value.device)
+    with torch.cuda.device(value.device):
+        st = lib.pave_deform_attn_pose_fused_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
+            smax.data_ptr() if return_stats else None,
+            ssum.data_ptr() if return_stats else None, int(n_clips), Q, int(T), S, L, K,
+            proj.stride(0), _stream_ptr())
+    native.check(st, 'deform_attn_pose_fused')
+    if return_stats:
+        return out, smax, ssum
+    return out

@@ -1,0 +1,133 @@
+"""The oracle (oracle/pavenet_ref.py + oracle/msda_ref.c) against golden vectors produced
+by the real reference (oracle/gen_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pavenet_ref as R
+from oracle.seeded import seeded_state_dict
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'), allow_pickle=False)
+
+
+def _sd(g, prefix=''):
+    shapes = json.loads(str(g['keys']))
+    sd = seeded_state_dict(shapes)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _lsi(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+
+
+def test_mmcv_seed3_known_answer(golden_dir):
+    """mmcv's own pin for this op: tests/test_ops/test_ms_deformable_attn.py:73-135
+    (double: abs<1e-18, rel<1e-15; float: abs<1e-9, rel<1e-6)."""
+    g = _load(golden_dir, 'op_msda')
+    shapes = g['s3_shapes']
+    lsi = np.concatenate([[0], np.cumsum(shapes.prod(1))[:-1]])
+    # the inputs are the deterministic torch.manual_seed(3) draws of the mmcv test
+    torch.manual_seed(3)
+    value = torch.rand(1, 30, 2, 2) * 0.01
+    assert torch.equal(value, _t(g['s3_value']))
+    out64 = R.msda_forward_c(g['s3_value'].astype(np.float64), shapes, lsi,
+                             g['s3_loc'].astype(np.float64), g['s3_aw'].astype(np.float64))
+    ref64 = g['s3_out_f64']
+    assert np.abs(out64 - ref64).max() < 1e-18
+    assert (np.abs(out64 - ref64) / np.abs(ref64)).max() < 1e-15
+    out32 = R.msda_forward_c(g['s3_value'], shapes, lsi, g['s3_loc'], g['s3_aw'])
+    ref32 = g['s3_out_f32']
+    assert np.abs(out32 - ref32).max() < 1e-9
+    assert (np.abs(out32 - ref32) / np.abs(ref32)).max() < 1e-6
+
+
+@pytest.mark.parametrize('case', ['enc', 'pose', 'joint', 'odd', 'd71'])
+def test_sampler_cases(golden_dir, case):
+    g = _load(golden_dir, 'op_msda')
+    shapes = g['levels']
+    lsi = np.concatenate([[0], np.cumsum(shapes.prod(1))[:-1]])
+    out = R.msda_forward_c(g[f'{case}_value'], shapes, lsi, g[f'{case}_loc'], g[f'{case}_aw'])
+    ref = g[f'{case}_out']
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=2e-6)
+    # the torch restatement agrees too
+    out_t = R.msda_forward_torch(_t(g[f'{case}_value']), _t(shapes), _t(g[f'{case}_loc']),
+                                 _t(g[f'{case}_aw'])).numpy()
+    np.testing.assert_allclose(out_t, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_encoder_msda_module(golden_dir):
+    g = _load(golden_dir, 'mod_enc_msda')
+    sd = _sd(g, 'm.')
+    shapes = _t(g['levels'])
+    out = R.msda_module(sd, 'm', _t(g['query']), _t(g['pos']), _t(g['mask']), _t(g['ref']),
+                        shapes, _lsi(shapes))
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-4, atol=2e-5)
+
+
+def test_pose_single_module(golden_dir):
+    g = _load(golden_dir, 'mod_pose_single')
+    sd = _sd(g, 'm.')
+    shapes = _t(g['levels'])
+    out = R.pose_attn_single(sd, 'm', _t(g['query']), _t(g['value']), _t(g['pos']),
+                             _t(g['mask']), _t(g['ref']), shapes, _lsi(shapes), K=17)
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('T', [3, 5])
+def test_pose_mulframes_module(golden_dir, T):
+    g = _load(golden_dir, f'mod_pose_t{T}')
+    sd = _sd(g, 'm.')
+    shapes = _t(g['levels'])
+    out = R.pose_attn_mulframes(sd, 'm', T, _t(g['query']), _t(g['value']), _t(g['pos']),
+                                _t(g['mask']), _t(g['ref']), shapes, _lsi(shapes), K=15)
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('T', [3, 5])
+def test_joint_mulframes_module(golden_dir, T):
+    g = _load(golden_dir, f'mod_joint_t{T}')
+    sd = _sd(g, 'm.')
+    shapes = _t(g['levels'])
+    N = g['query'].shape[1]
+    mem = _t(g['memory'])
+    value = mem[:, [0] * N]
+    mask = _t(g['mask'])[None].expand(N, -1, -1)
+    out = R.joint_attn_mulframes(sd, 'm', T, _t(g['query']), value, _t(g['pos']), mask,
+                                 _t(g['ref']), shapes, _lsi(shapes))
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('T', [3, 5])
+def test_end_to_end(golden_dir, T):
+    """Whole simple_test at 128x160 with name-seeded weights vs the reference's outputs.
+    Top-k selections are compared as index sets first (SURVEY 8c top-k sensitivity)."""
+    g = _load(golden_dir, f'e2e_videopose_r50_t{T}')
+    sd = _sd(g)
+    N = int(g['score_topk'].shape[0])
+    cfg = dict(num_frames=T, num_keypoints=15, num_query=300, max_per_img=N)
+    taps = {}
+    with torch.no_grad():
+        bboxes, labels, kpts = R.videopose_simple_test(
+            sd, cfg, _t(g['img']), img_shape=tuple(int(v) for v in g['img_shape']), taps=taps)
+    if 'memory' in g.files:
+        np.testing.assert_allclose(taps['memory'].numpy(), g['memory'], rtol=1e-3, atol=2e-4)
+    else:
+        np.testing.assert_allclose(taps['memory'][T // 2::T].numpy(), g['memory_center'],
+                                   rtol=1e-3, atol=2e-4)
+    assert set(taps['topk_idx'].flatten().tolist()) == set(g['enc_topk'].flatten().tolist())
+    np.testing.assert_allclose(taps['hs'].numpy(), g['hs'], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(taps['inter_references'].numpy(), g['inter_references'],
+                               rtol=1e-3, atol=1e-4)
+    assert taps['score_topk_idx'].tolist() == g['score_topk'].tolist()
+    assert kpts.shape == g['det_kpts'].shape
+    np.testing.assert_allclose(kpts.numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)  # pixels
+    np.testing.assert_allclose(bboxes.numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
