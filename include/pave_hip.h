@@ -105,6 +105,17 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
                                     int K, int proj_stride, void* stream);
 
+/*
+ * Greedy OKS-NMS, one launch for n_clips clips (replaces oks_nms / oks_iou,
+ * opera/models/dense_heads/videopose_head_mul_frames.py:1624-1665, a NumPy loop behind a
+ * device->host sync in the reference).
+ *   kpts   [n_clips, N, K, 3] (x, y, score) pixels;  scores [n_clips, N];  sigmas [K] double, DEVICE
+ *   keep   [n_clips, N] int32: 1 = kept;  order [n_clips, N] int32: indices by descending score
+ * A pose is suppressed when its OKS with an earlier kept pose is > thresh.
+ */
+int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigmas, double thresh,
+                     int32_t* keep, int32_t* order, int n_clips, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

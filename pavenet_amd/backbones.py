@@ -1,0 +1,181 @@
+"""``mmdet.ResNet`` incl. the fork's ``input_type='mul_frames'`` (a14), restated from
+third_party/mmdetection/mmdet/models/backbones/resnet.py (Bottleneck :99-305, ResNet :308-672,
+forward :632-654).  Same ctor kwargs (the ones the PAVE-Net configs use) and state-dict keys.
+
+Dense convolutions are true contractions and go to MIOpen (MFMA) through PyTorch-ROCm.
+Inference-time: frozen BatchNorm is folded into the preceding convolution (cached; the
+reference offers the same transformation as ``--fuse-conv-bn``, tools/test.py:227-228), and
+the whole trunk runs channels-last.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .bricks import BaseModule, build_norm_layer
+from .registry import MMDET_MODELS
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, planes)[1]
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = build_norm_layer(norm_cfg, planes)[1]
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.pairs = (('conv1', 'bn1', True), ('conv2', 'bn2', False))
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        super().__init__()
+        assert style in ['pytorch', 'caffe']
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, s1, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, planes)[1]
+        self.conv2 = nn.Conv2d(planes, planes, 3, s2, dilation, dilation, bias=False)
+        self.bn2 = build_norm_layer(norm_cfg, planes)[1]
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = build_norm_layer(norm_cfg, planes * 4)[1]
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.pairs = (('conv1', 'bn1', True), ('conv2', 'bn2', True), ('conv3', 'bn3', False))
+
+
+def _fold(conv, bn):
+    """conv (no bias) followed by eval-mode BN -> (weight, bias) of one convolution."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = conv.weight * scale.view(-1, 1, 1, 1)
+    b = bn.bias - bn.running_mean * scale
+    if conv.bias is not None:
+        b = b + conv.bias * scale
+    return w, b
+
+
+@MMDET_MODELS.register_module()
+class ResNet(BaseModule):
+    arch_settings = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)),
+                     50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)),
+                     152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3),
+                 style='pytorch', deep_stem=False, avg_down=False, frozen_stages=-1,
+                 conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+                 dcn=None, stage_with_dcn=(False, False, False, False), plugins=None,
+                 with_cp=False, zero_init_residual=True, pretrained=None, init_cfg=None,
+                 input_type='single_frame'):
+        super().__init__(init_cfg)
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        assert not deep_stem and not avg_down and dcn is None and plugins is None, \
+            'pavenet_amd.ResNet builds the plain stem / no DCN / no plugins used by PAVE-Net'
+        self.depth = depth
+        self.input_type = input_type
+        stem_channels = stem_channels or base_channels
+        self.num_stages = num_stages
+        self.out_indices = out_indices
+        self.frozen_stages = frozen_stages
+        self.norm_eval = norm_eval
+        self.style = style
+        block, stage_blocks = self.arch_settings[depth]
+        stage_blocks = stage_blocks[:num_stages]
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, 2, 3, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, stem_channels)[1]
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.res_layers = []
+        inplanes = stem_channels
+        for i, nb in enumerate(stage_blocks):
+            planes = base_channels * 2**i
+            layers = []
+            for b in range(nb):
+                stride = strides[i] if b == 0 else 1
+                downsample = None
+                if b == 0 and (stride != 1 or inplanes != planes * block.expansion):
+                    downsample = nn.Sequential(
+                        nn.Conv2d(inplanes, planes * block.expansion, 1, stride, bias=False),
+                        build_norm_layer(norm_cfg, planes * block.expansion)[1])
+                layers.append(block(inplanes, planes, stride, dilations[i], downsample, style,
+                                    norm_cfg))
+                inplanes = planes * block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        self._folded = None
+        self.channels_last = True
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                nn.init.constant_(m.bn3.weight, 0)
+            elif isinstance(m, BasicBlock):
+                nn.init.constant_(m.bn2.weight, 0)
+        self._is_init = True
+
+    # -- folded inference path ----------------------------------------------
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+
+    def _build_folded(self):
+        key = self._params_key()
+        if self._folded is not None and self._folded[0] == key:
+            return self._folded[1]
+        mf = torch.channels_last if self.channels_last else torch.contiguous_format
+        with torch.no_grad():
+            f = {'stem': tuple(t.contiguous(memory_format=mf) if t.dim() == 4 else t
+                               for t in _fold(self.conv1, self.bn1))}
+            for name in self.res_layers:
+                for bi, blk in enumerate(getattr(self, name)):
+                    for cn, bn, _ in blk.pairs:
+                        w, b = _fold(getattr(blk, cn), getattr(blk, bn))
+                        f[(name, bi, cn)] = (w.contiguous(memory_format=mf), b)
+                    if blk.downsample is not None:
+                        w, b = _fold(blk.downsample[0], blk.downsample[1])
+                        f[(name, bi, 'ds')] = (w.contiguous(memory_format=mf), b)
+        self._folded = (key, f)
+        return f
+
+    def forward(self, x):
+        if self.input_type == 'mul_frames':
+            x = x.flatten(0, 1)  # [B, T, C, H, W] -> [B*T, C, H, W]  (resnet.py:634-639)
+        assert not self.training, 'pavenet_amd.ResNet is an inference (frozen BN) backbone'
+        f = self._build_folded()
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        w, b = f['stem']
+        x = F.relu_(F.conv2d(x, w, b, 2, 3))
+        x = self.maxpool(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for bi, blk in enumerate(getattr(self, name)):
+                identity = x
+                y = x
+                for cn, _, act in blk.pairs:
+                    conv = getattr(blk, cn)
+                    w, b = f[(name, bi, cn)]
+                    y = F.conv2d(y, w, b, conv.stride, conv.padding, conv.dilation)
+                    if act:
+                        y = F.relu_(y)
+                if blk.downsample is not None:
+                    w, b = f[(name, bi, 'ds')]
+                    identity = F.conv2d(x, w, b, blk.downsample[0].stride)
+                x = F.relu_(y.add_(identity))
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)

@@ -1,0 +1,425 @@
+"""Transformer building blocks with the reference's names, ctor kwargs, forward kwargs and
+state-dict keys (restated from third_party/mmcv/mmcv/cnn/bricks/transformer.py and
+third_party/mmdetection/mmdet/models/utils/{transformer,positional_encoding}.py).
+
+Dense ops (Linear / LayerNorm / nn.MultiheadAttention) run through PyTorch-ROCm (rocBLAS /
+hipBLASLt MFMA GEMMs); everything is inference-mode: dropout layers exist only as
+identities so that configs with ``dropout=0.1`` build unchanged.
+
+Layout note: sequence-first tensors ``[n, bs, C]`` handed between modules are kept as
+*views* of batch-first contiguous storage wherever possible (``seq_first_view``), so the
+``permute(1, 0, 2)`` the reference performs in every attention module is free and the
+token-major ``[bs*n, C]`` matrices feed the GEMMs and HIP kernels without copies.
+"""
+import copy
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import (MMCV_ATTENTION, MMCV_FEEDFORWARD_NETWORK, MMCV_POSITIONAL_ENCODING,
+                       MMCV_TRANSFORMER_LAYER, MMCV_TRANSFORMER_LAYER_SEQUENCE, build_attention,
+                       build_feedforward_network, build_transformer_layer)
+
+
+class BaseModule(nn.Module):
+    """mmcv.runner.BaseModule subset: carries init_cfg, provides init_weights()."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self._is_init = False
+        self.init_cfg = copy.deepcopy(init_cfg)
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+        self._is_init = True
+
+
+Linear = nn.Linear
+
+
+def build_norm_layer(cfg, num_features):
+    """mmcv/cnn/bricks/norm.py: returns (name, layer) for LN / BN / GN."""
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    requires_grad = cfg.pop('requires_grad', True)
+    cfg.setdefault('eps', 1e-5)
+    if t == 'LN':
+        name, layer = 'ln', nn.LayerNorm(num_features, **cfg)
+    elif t in ('BN', 'BN2d', 'SyncBN'):
+        name, layer = 'bn', nn.BatchNorm2d(num_features, **cfg)
+    elif t == 'GN':
+        name, layer = 'gn', nn.GroupNorm(num_channels=num_features, **cfg)
+    else:
+        raise KeyError(f'Unrecognized norm type {t}')
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name, layer
+
+
+def build_activation_layer(cfg):
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    table = dict(ReLU=nn.ReLU, GELU=nn.GELU, LeakyReLU=nn.LeakyReLU, Sigmoid=nn.Sigmoid,
+                 Tanh=nn.Tanh, PReLU=nn.PReLU, ELU=nn.ELU, ReLU6=nn.ReLU6)
+    if t not in table:
+        raise KeyError(f'Unrecognized activation type {t}')
+    if t == 'GELU':
+        cfg.pop('inplace', None)
+    return table[t](**cfg)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """mmdet/models/utils/transformer.py:390-406."""
+    x = x.clamp(min=0, max=1)
+    x1 = x.clamp(min=eps)
+    x2 = (1 - x).clamp(min=eps)
+    return torch.log(x1 / x2)
+
+
+def seq_first_view(x_batch_first):
+    """[bs, n, C] contiguous -> [n, bs, C] view (no copy)."""
+    return x_batch_first.transpose(0, 1)
+
+
+def batch_first(x_seq_first):
+    """[n, bs, C] -> [bs, n, C], contiguous; free when x is a seq_first_view."""
+    y = x_seq_first.transpose(0, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def layer_norm_any_layout(norm, x):
+    """LayerNorm over the last dim without forcing a layout change of dims 0/1."""
+    if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+        return norm(x.transpose(0, 1)).transpose(0, 1)
+    return norm(x)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> act with mmcv's attribute names (``conv``, ``gn`` / ``bn``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias='auto', conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        assert conv_cfg is None or conv_cfg.get('type', 'Conv2d') in ('Conv2d', 'Conv')
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation,
+                              groups, bias)
+        self.norm_name = None
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            act_cfg = dict(act_cfg)
+            if act_cfg['type'] not in ('Tanh', 'PReLU', 'Sigmoid', 'GELU'):
+                act_cfg.setdefault('inplace', inplace)
+            self.activate = build_activation_layer(act_cfg)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = getattr(self, self.norm_name)(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+@MMCV_FEEDFORWARD_NETWORK.register_module()
+class FFN(BaseModule):
+    """mmcv/cnn/bricks/transformer.py:1046-1120 (keys ``layers.0.0``, ``layers.1``)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert num_fcs >= 2
+        self.embed_dims = embed_dims
+        self.feedforward_channels = feedforward_channels
+        self.num_fcs = num_fcs
+        self.act_cfg = act_cfg
+        self.activate = build_activation_layer(act_cfg)
+        layers = []
+        in_channels = embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(Linear(in_channels, feedforward_channels), self.activate,
+                                        nn.Dropout(ffn_drop)))
+            in_channels = feedforward_channels
+        layers.append(Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            out = self.layers(x.transpose(0, 1)).transpose(0, 1)  # keep the token-major storage
+        else:
+            out = self.layers(x)
+        if not self.add_identity:
+            return out
+        if identity is None:
+            identity = x
+        return identity + out
+
+
+@MMCV_ATTENTION.register_module()
+class MultiheadAttention(BaseModule):
+    """Wrapper of nn.MultiheadAttention, mmcv/cnn/bricks/transformer.py:406-551."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0.,
+                 dropout_layer=dict(type='Dropout', drop_prob=0.), init_cfg=None,
+                 batch_first=False, **kwargs):
+        super().__init__(init_cfg)
+        if 'dropout' in kwargs:
+            attn_drop = kwargs.pop('dropout')
+        self.embed_dims = embed_dims
+        self.num_heads = num_heads
+        self.batch_first = batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+        self.proj_drop = nn.Identity()
+        self.dropout_layer = nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
+                attn_mask=None, key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None:
+            if query_pos is not None:
+                if query_pos.shape == key.shape:
+                    key_pos = query_pos
+                else:
+                    warnings.warn(f'position encoding of key is missing in '
+                                  f'{self.__class__.__name__}.')
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        if self.batch_first:
+            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask,
+                        key_padding_mask=key_padding_mask, need_weights=False)[0]
+        if self.batch_first:
+            out = out.transpose(0, 1)
+        return identity + out
+
+
+@MMCV_TRANSFORMER_LAYER.register_module()
+class BaseTransformerLayer(BaseModule):
+    """mmcv/cnn/bricks/transformer.py:1123-1353 incl. the fork's ``query_time_pos`` kwarg."""
+
+    def __init__(self, attn_cfgs=None,
+                 ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                               ffn_drop=0., act_cfg=dict(type='ReLU', inplace=True)),
+                 operation_order=None, norm_cfg=dict(type='LN'), init_cfg=None,
+                 batch_first=False, **kwargs):
+        ffn_cfgs = copy.deepcopy(ffn_cfgs)
+        deprecated_args = dict(feedforward_channels='feedforward_channels', ffn_dropout='ffn_drop',
+                               ffn_num_fcs='num_fcs')
+        for ori_name, new_name in deprecated_args.items():
+            if ori_name in kwargs:
+                ffn_cfgs[new_name] = kwargs[ori_name]
+        super().__init__(init_cfg)
+        self.batch_first = batch_first
+        assert set(operation_order) & {'self_attn', 'norm', 'ffn', 'cross_attn'} == \
+            set(operation_order)
+        num_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        else:
+            attn_cfgs = [copy.deepcopy(dict(c)) for c in attn_cfgs]
+            assert num_attn == len(attn_cfgs)
+        self.num_attn = num_attn
+        self.operation_order = tuple(operation_order)
+        self.norm_cfg = norm_cfg
+        self.pre_norm = operation_order[0] == 'norm'
+        self.attentions = nn.ModuleList()
+        index = 0
+        for operation_name in operation_order:
+            if operation_name in ['self_attn', 'cross_attn']:
+                if 'batch_first' in attn_cfgs[index]:
+                    assert self.batch_first == attn_cfgs[index]['batch_first']
+                else:
+                    attn_cfgs[index]['batch_first'] = self.batch_first
+                attention = build_attention(attn_cfgs[index])
+                attention.operation_name = operation_name
+                self.attentions.append(attention)
+                index += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList()
+        num_ffns = operation_order.count('ffn')
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(dict(ffn_cfgs)) for _ in range(num_ffns)]
+        assert len(ffn_cfgs) == num_ffns
+        for ffn_index in range(num_ffns):
+            if 'embed_dims' not in ffn_cfgs[ffn_index]:
+                ffn_cfgs[ffn_index]['embed_dims'] = self.embed_dims
+            else:
+                assert ffn_cfgs[ffn_index]['embed_dims'] == self.embed_dims
+            self.ffns.append(build_feedforward_network(ffn_cfgs[ffn_index], dict(type='FFN')))
+        self.norms = nn.ModuleList()
+        for _ in range(operation_order.count('norm')):
+            self.norms.append(build_norm_layer(norm_cfg, self.embed_dims)[1])
+
+    def forward(self, query, key=None, value=None, query_pos=None, query_time_pos=None,
+                key_pos=None, attn_masks=None, query_key_padding_mask=None,
+                key_padding_mask=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+        else:
+            assert len(attn_masks) == self.num_attn
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                temp_key = temp_value = query
+                query = self.attentions[attn_index](
+                    query, temp_key, temp_value, identity if self.pre_norm else None,
+                    query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = layer_norm_any_layout(self.norms[norm_index], query)
+                norm_index += 1
+            elif layer == 'cross_attn':
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    query_time_pos=query_time_pos, key_pos=key_pos,
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+@MMCV_TRANSFORMER_LAYER.register_module()
+class DetrTransformerDecoderLayer(BaseTransformerLayer):
+    """mmdet/models/utils/transformer.py:409-453."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'),
+                 ffn_num_fcs=2, **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                         ffn_dropout=ffn_dropout, operation_order=operation_order,
+                         act_cfg=act_cfg, norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+
+
+@MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module()
+class TransformerLayerSequence(BaseModule):
+    """mmcv/cnn/bricks/transformer.py:1606-1687."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList()
+        for i in range(num_layers):
+            self.layers.append(build_transformer_layer(transformerlayers[i]))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        for layer in self.layers:
+            query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos,
+                          attn_masks=attn_masks, query_key_padding_mask=query_key_padding_mask,
+                          key_padding_mask=key_padding_mask, **kwargs)
+        return query
+
+
+@MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DetrTransformerEncoder(TransformerLayerSequence):
+    """mmdet/models/utils/transformer.py:501-531."""
+
+    def __init__(self, *args, post_norm_cfg=dict(type='LN'), **kwargs):
+        super().__init__(*args, **kwargs)
+        if post_norm_cfg is not None:
+            self.post_norm = build_norm_layer(post_norm_cfg, self.embed_dims)[1] \
+                if self.pre_norm else None
+        else:
+            assert not self.pre_norm
+            self.post_norm = None
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        if self.post_norm is not None:
+            x = layer_norm_any_layout(self.post_norm, x)
+        return x
+
+
+@MMCV_POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding(BaseModule):
+    """mmdet/models/utils/positional_encoding.py:11-93."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi,
+                 eps=1e-6, offset=0., init_cfg=None):
+        super().__init__(init_cfg)
+        if normalize:
+            assert isinstance(scale, (float, int))
+        self.num_feats = num_feats
+        self.temperature = temperature
+        self.normalize = normalize
+        self.scale = scale
+        self.eps = eps
+        self.offset = offset
+
+    def forward(self, mask):
+        mask = mask.to(torch.int)
+        not_mask = 1 - mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        # dim_t on the host: fully-padded columns give arguments of ~1e6 rad (offset / eps),
+        # where a 1-ulp difference in a device powf changes sin / cos completely
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32)
+        dim_t = (self.temperature**(2 * (dim_t // 2) / self.num_feats)).to(mask.device)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        B, H, W = mask.size()
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()),
+                            dim=4).view(B, H, W, -1)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()),
+                            dim=4).view(B, H, W, -1)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    if hasattr(module, 'weight') and module.weight is not None:
+        if distribution == 'uniform':
+            nn.init.xavier_uniform_(module.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(module.weight, gain=gain)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if hasattr(module, 'weight') and module.weight is not None:
+        nn.init.constant_(module.weight, val)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-math.log((1 - prior_prob) / prior_prob))

@@ -462,6 +462,74 @@ __global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParam
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Greedy OKS-NMS on the device (replaces the NumPy loop + host sync of
+// opera/models/dense_heads/videopose_head_mul_frames.py:1624-1665).
+// One workgroup per clip.  Precisions follow the NumPy code: squared distances
+// and areas in float32, the division chain / exp / mean in float64.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ kpts,
+                                                      const float* __restrict__ scores,
+                                                      const double* __restrict__ sigmas,
+                                                      const double thresh, int* __restrict__ keep,
+                                                      int* __restrict__ order_out, const int N,
+                                                      const int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* order = reinterpret_cast<int*>(smem);           // [N]
+  int* dead = order + N;                               // [N]
+  float* area = reinterpret_cast<float*>(dead + N);    // [N]
+  const int b = blockIdx.x;
+  const float* kp = kpts + (long long)b * N * K * 3;
+  const float* sc = scores + (long long)b * N;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const float x = kp[(j * K + k) * 3], y = kp[(j * K + k) * 3 + 1];
+      xmin = fminf(xmin, x);
+      xmax = fmaxf(xmax, x);
+      ymin = fminf(ymin, y);
+      ymax = fmaxf(ymax, y);
+    }
+    area[j] = (xmax - xmin) * (ymax - ymin);
+    // descending score; ties: larger index first (reverse of a stable ascending sort)
+    const float s = sc[j];
+    int rank = 0;
+    for (int i = 0; i < N; ++i) {
+      const float t = sc[i];
+      rank += (t > s) || (t == s && i > j);
+    }
+    order[rank] = j;
+    dead[j] = 0;
+  }
+  __syncthreads();
+  for (int ii = 0; ii < N; ++ii) {
+    const int i = order[ii];
+    if (!dead[i]) {  // uniform: read from LDS after the barrier
+      for (int jj = ii + 1 + threadIdx.x; jj < N; jj += blockDim.x) {
+        const int j = order[jj];
+        if (dead[j]) continue;
+        const double denom = (double)((area[i] + area[j]) / 2.f) + 2.220446049250313e-16;
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) {
+          const float dx = kp[(j * K + k) * 3] - kp[(i * K + k) * 3];
+          const float dy = kp[(j * K + k) * 3 + 1] - kp[(i * K + k) * 3 + 1];
+          const float d2 = dx * dx + dy * dy;
+          const double var = (sigmas[k] * 2.0) * (sigmas[k] * 2.0);
+          const double e = (double)d2 / var / denom / 2.0;
+          acc += exp(-e);
+        }
+        if (acc / (double)K > thresh) dead[j] = 1;
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    keep[(long long)b * N + j] = dead[j] ? 0 : 1;
+    order_out[(long long)b * N + j] = order[j];
+  }
+}
+
 template <int MODE, int PPL, int WQ>
 int launch_fused(const FusedParams& p0, hipStream_t stream) {
   FusedParams p = p0;
@@ -636,6 +704,21 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (K <= 16) return launch_fused<kPose, 2, 4>(p, st);
   return launch_fused<kPose, 3, 4>(p, st);
+}
+
+int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigmas, double thresh,
+                     int32_t* keep, int32_t* order, int n_clips, int N, int K, void* stream) {
+  if (!kpts || !scores || !sigmas || !keep || !order)
+    return fail(PAVE_E_ARG, "oks_nms: null pointer");
+  if (n_clips <= 0 || N <= 0 || K <= 0) return fail(PAVE_E_ARG, "oks_nms: sizes must be positive");
+  if (N > 4096) return fail(PAVE_E_ARG, "oks_nms: at most 4096 poses per clip");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t shmem = (size_t)N * (2 * sizeof(int) + sizeof(float));
+  hipLaunchKernelGGL(oks_nms_kernel, dim3(n_clips), dim3(256), shmem, st, kpts, scores, sigmas,
+                     thresh, keep, order, N, K);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
 }
 
 }  // extern "C"

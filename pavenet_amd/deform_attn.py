@@ -1,0 +1,504 @@
+"""Deformable-attention modules of the PAVE-Net forward path, on the fused HIP kernels.
+
+Same registry names, ctor kwargs, forward kwargs and state-dict keys as the reference:
+
+* ``mmcv.MultiScaleDeformableAttention``                      MO:207-412   (encoder, a2)
+* ``opera.MultiScaleDeformablePoseAttention``                 OT:251-427   (PETR decoder, a15)
+* ``opera.MulFramesMultiScaleDeformablePoseAttentionNumFrames3/5``  OT:1543-1863 / 2738-3117 (a5)
+* ``mmcv.MulFramesMultiScaleDeformableAttentionNumFrames3/5``       MO:1268-1587 / 1590-1981 (a7)
+
+plus ``...MulFrames...Attention`` generalisations to any odd ``num_frames`` (the reference
+hard-codes T = 3 / 5 with one named Linear pair per frame; frame offset k from the centre
+gets the prefix 'pre_' * (-k) / '' / 'next_' * k, which reproduces the reference's names).
+
+What changes relative to the reference is *how* the forward runs on the device:
+one concatenated GEMM produces the offsets and logits of all frames, and ONE HIP launch
+(pavenet_amd/csrc/pave_kernels.hip) does the joint softmax over T*L*P logits, the sampling
+location arithmetic, the bilinear gathers of all frames and the cross-frame fusion
+(the reference: 2T Linears, T softmaxes, T exp-sums, T sampler launches, 3T elementwise ops).
+The joint softmax is stabilised; it equals the reference's Z_t re-weighting whenever that
+does not overflow (|logit| < ~88), see DESIGN.md "Intentional divergences".
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .bricks import BaseModule, batch_first, constant_init, seq_first_view, xavier_init
+from .registry import ATTENTION, MMCV_ATTENTION
+
+
+def frame_prefixes(num_frames):
+    assert num_frames % 2 == 1, 'num_frames must be odd (centre frame + symmetric neighbours)'
+    c = num_frames // 2
+    return ['pre_' * (c - t) if t < c else 'next_' * (t - c) for t in range(num_frames)]
+
+
+def _check_heads(embed_dims, num_heads):
+    if embed_dims % num_heads != 0:
+        raise ValueError(f'embed_dims must be divisible by num_heads, '
+                         f'but got {embed_dims} and {num_heads}')
+    d = embed_dims // num_heads
+    if not (isinstance(d, int) and d > 0 and (d & (d - 1)) == 0):
+        warnings.warn("You'd better set embed_dims in MultiScaleDeformAttention to make the "
+                      'dimension of each attention head a power of 2 which is more efficient '
+                      'in our implementation.')
+
+
+class _CatProj:
+    """Caches the row-concatenation [offsets of all frames ; logits of all frames] of the
+    per-frame ``sampling_offsets`` / ``attention_weights`` Linears, so one GEMM feeds the
+    fused kernel.  Rebuilt whenever a source parameter changes (version / storage)."""
+
+    def _cat_sources(self):
+        raise NotImplementedError
+
+    def _cat_proj(self):
+        offs, logits = self._cat_sources()
+        srcs = [m.weight for m in offs + logits] + [m.bias for m in offs + logits]
+        key = tuple((p.data_ptr(), p._version) for p in srcs)
+        if getattr(self, '_cat_key', None) != key:
+            with torch.no_grad():
+                self._cat_w = torch.cat([m.weight for m in offs + logits], 0).contiguous()
+                self._cat_b = torch.cat([m.bias for m in offs + logits], 0).contiguous()
+            self._cat_key = key
+        return self._cat_w, self._cat_b
+
+
+def _fused_ok(mod, *tensors):
+    """The fused kernels are built for 8 heads x 32 channels, fp32, on the device."""
+    return (mod.embed_dims == 256 and mod.num_heads == 8
+            and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
+
+
+def _host_levels(spatial_shapes, kwargs):
+    """Level sizes as host ints without a device sync when the caller provides them."""
+    hs = kwargs.get('spatial_shapes_host')
+    if hs is not None:
+        return [(int(h), int(w)) for h, w in hs]
+    return [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
+
+
+# ---------------------------------------------------------------------------
+@MMCV_ATTENTION.register_module()
+class MultiScaleDeformableAttention(BaseModule, _CatProj):
+    """Encoder self-attention (MO:207-412)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        _check_heads(embed_dims, num_heads)
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Identity()  # inference path
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        constant_init(self.sampling_offsets, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid_init.view(-1))
+        constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    def _cat_sources(self):
+        return [self.sampling_offsets], [self.attention_weights]
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            q, v = batch_first(query), batch_first(value)
+        else:
+            q, v = query, value
+        bs, num_query, _ = q.shape
+        num_value = v.shape[1]
+        v = self.value_proj(v)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        v = v.view(bs, num_value, self.num_heads, -1)
+        fused = (_fused_ok(self, q, v) and self.num_levels == 4 and self.num_points == 4
+                 and reference_points.shape[-1] == 2)
+        if fused:
+            w, b = self._cat_proj()
+            proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+            ref = reference_points.reshape(1, bs * num_query, self.num_levels, 2)
+            if not ref.is_contiguous():
+                ref = ref.contiguous()
+            out = ops.deform_attn_grid_fused(
+                v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=bs,
+                units_per_clip=num_query, order=kwargs.get('unit_order'))
+            out = out.view(bs, num_query, self.embed_dims)
+        else:
+            off = self.sampling_offsets(q).view(bs, num_query, self.num_heads, self.num_levels,
+                                                self.num_points, 2)
+            aw = self.attention_weights(q).view(bs, num_query, self.num_heads,
+                                                self.num_levels * self.num_points).softmax(-1)
+            aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+            if reference_points.shape[-1] == 2:
+                norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+                loc = reference_points[:, :, None, :, None, :] + \
+                    off / norm[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                loc = reference_points[:, :, None, :, None, :2] + \
+                    off / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+            else:
+                raise ValueError(f'Last dim of reference_points must be 2 or 4, but get '
+                                 f'{reference_points.shape[-1]} instead.')
+            out = ops.MultiScaleDeformableAttnFunction.apply(
+                v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
+                aw.contiguous(), self.im2col_step)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = seq_first_view(out)
+        return out + identity
+
+
+# ---------------------------------------------------------------------------
+class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
+    """Pose-aware T-frame cross-attention, any odd T (generalises OT:1543-1863, 2738-3117).
+
+    forward: query [Q, B, C]; value [S, B*T, C] frame-interleaved (clip b, frame t at b*T+t);
+    key_padding_mask [B*T, S] applied BEFORE value_proj (OT:1706-1711);
+    reference_points [B, T*Q, L, 2K] frame-major along dim 1.
+    """
+
+    def __init__(self, num_frames=3, embed_dims=256, num_heads=8, num_levels=4, num_points=17,
+                 im2col_step=64, dropout=0.1, norm_cfg=None, init_cfg=None, batch_first=False):
+        super().__init__(init_cfg)
+        _check_heads(embed_dims, num_heads)
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Identity()
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.num_frames = num_frames
+        self.frame_prefixes = frame_prefixes(num_frames)
+        for fp in self.frame_prefixes:
+            setattr(self, fp + 'sampling_offsets',
+                    nn.Linear(embed_dims, num_heads * num_levels * num_points * 2))
+            setattr(self, fp + 'attention_weights',
+                    nn.Linear(embed_dims, num_heads * num_levels * num_points))
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        for fp in self.frame_prefixes:
+            constant_init(getattr(self, fp + 'sampling_offsets'), 0.)
+            constant_init(getattr(self, fp + 'attention_weights'), val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+
+    def _cat_sources(self):
+        return ([getattr(self, fp + 'sampling_offsets') for fp in self.frame_prefixes],
+                [getattr(self, fp + 'attention_weights') for fp in self.frame_prefixes])
+
+    def project_value(self, value_bf, key_padding_mask=None):
+        """value_bf [B*T, S, C] -> [B*T, S, 8, 32]: padding mask, then value_proj."""
+        if key_padding_mask is not None:
+            value_bf = value_bf.masked_fill(key_padding_mask[..., None], 0.0)
+        v = self.value_proj(value_bf)
+        return v.view(v.shape[0], v.shape[1], self.num_heads, -1)
+
+    def forward(self, query, key=None, value=None, residual=None, query_pos=None,
+                query_time_pos=None, key_padding_mask=None, reference_points=None,
+                spatial_shapes=None, level_start_index=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        inp_residual = query if residual is None else residual
+        if query_pos is not None:
+            query = query + query_pos
+        T, M, L, K = self.num_frames, self.num_heads, self.num_levels, self.num_points
+        q = batch_first(query) if not self.batch_first else query
+        bs, num_query, _ = q.shape
+        if reference_points.shape[-1] != K * 2:
+            raise ValueError(f'Last dim of reference_points must be 2K, but get '
+                             f'{reference_points.shape[-1]} instead.')
+        projected = kwargs.get('value_projected')
+        if projected is not None:
+            v = projected  # [B*T, S, 8, 32], hoisted by the transformer
+        else:
+            vb = batch_first(value) if not self.batch_first else value
+            v = self.project_value(vb, key_padding_mask)
+        assert v.shape[0] == bs * T, 'value must hold num_frames slabs per clip'
+        w, b = self._cat_proj()
+        proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+        if _fused_ok(self, q, v) and L <= 4 and K <= 24:
+            ref = reference_points if reference_points.is_contiguous() \
+                else reference_points.contiguous()
+            stats = kwargs.get('return_softmax_stats', False)
+            res = ops.deform_attn_pose_fused(
+                v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
+                proj, ref, T=T, n_clips=bs, num_query=num_query, num_keypoints=K,
+                return_stats=stats)
+            if stats:  # frame-sharded multi-GPU: caller merges partial rows, then projects
+                return res
+            out = res.view(bs, num_query, self.embed_dims)
+        else:
+            out = self._unfused(v, proj, reference_points, spatial_shapes, level_start_index, bs,
+                                num_query)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = seq_first_view(out)
+        return out + inp_residual
+
+    def _unfused(self, v, proj, reference_points, spatial_shapes, level_start_index, bs, nq):
+        """Shapes the fused kernel does not cover: per-frame launches of the generic sampler
+        with the stabilised joint softmax computed in torch."""
+        T, M, L, K = self.num_frames, self.num_heads, self.num_levels, self.num_points
+        n_off = T * M * L * K * 2
+        off = proj[:, :n_off].view(bs, nq, T, M, L, K, 2)
+        lg = proj[:, n_off:].view(bs, nq, T, M, L * K)
+        aw = lg.permute(0, 1, 3, 2, 4).reshape(bs, nq, M, T * L * K).softmax(-1)
+        aw = aw.view(bs, nq, M, T, L, K)
+        out = 0
+        for t in range(T):
+            rp_t = reference_points[:, t * nq:(t + 1) * nq]
+            rp = rp_t.reshape(bs, nq, L, -1, 2).unsqueeze(2)
+            x1 = rp_t[..., 0::2].min(-1, keepdim=True)[0]
+            y1 = rp_t[..., 1::2].min(-1, keepdim=True)[0]
+            x2 = rp_t[..., 0::2].max(-1, keepdim=True)[0]
+            y2 = rp_t[..., 1::2].max(-1, keepdim=True)[0]
+            wh = torch.cat([torch.clamp(x2 - x1, min=1e-4), torch.clamp(y2 - y1, min=1e-4)],
+                           -1)[:, :, None, :, None, :]
+            loc = rp + off[:, :, t] * wh * 0.5
+            out = out + ops.MultiScaleDeformableAttnFunction.apply(
+                v[t::T].contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
+                aw[:, :, :, t].contiguous(), self.im2col_step)
+        return out
+
+
+@ATTENTION.register_module()
+class MulFramesMultiScaleDeformablePoseAttentionNumFrames3(MulFramesMultiScaleDeformablePoseAttention):
+    """OT:1543-1863."""
+
+    def __init__(self, num_frames=3, **kwargs):
+        assert num_frames == 3
+        super().__init__(num_frames=3, **kwargs)
+
+
+@ATTENTION.register_module()
+class MulFramesMultiScaleDeformablePoseAttentionNumFrames5(MulFramesMultiScaleDeformablePoseAttention):
+    """OT:2738-3117 (its ctor has no num_frames argument)."""
+
+    def __init__(self, **kwargs):
+        kwargs.pop('num_frames', None)
+        super().__init__(num_frames=5, **kwargs)
+
+
+ATTENTION.register_module(name='MulFramesMultiScaleDeformablePoseAttention',
+                          module=MulFramesMultiScaleDeformablePoseAttention)
+
+
+@ATTENTION.register_module()
+class MultiScaleDeformablePoseAttention(MulFramesMultiScaleDeformablePoseAttention):
+    """Single-frame pose attention of PETR (OT:251-427): the T = 1 case, except that the
+    padding mask is applied AFTER value_proj (OT:386-388)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=17, im2col_step=64,
+                 dropout=0.1, norm_cfg=None, init_cfg=None, batch_first=False):
+        super().__init__(num_frames=1, embed_dims=embed_dims, num_heads=num_heads,
+                         num_levels=num_levels, num_points=num_points, im2col_step=im2col_step,
+                         dropout=dropout, norm_cfg=norm_cfg, init_cfg=init_cfg,
+                         batch_first=batch_first)
+
+    def project_value(self, value_bf, key_padding_mask=None):
+        v = self.value_proj(value_bf)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        return v.view(v.shape[0], v.shape[1], self.num_heads, -1)
+
+
+# ---------------------------------------------------------------------------
+class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
+    """Joint-decoder T-frame cross-attention, any odd T (generalises MO:1268-1587, 1590-1981).
+
+    Reference calling convention: query [K, N, C]; value [S, N, T, C] with the clip memory
+    replicated once per pose (OT:21498) and re-projected N times; key_padding_mask [N, T, S]
+    applied BEFORE value_proj (MO:1454-1458); reference_points [T*N, K, L, 2] frame-major.
+
+    Native convention (no replication): pass the clip memory once as value [S, B, T, C] (B clips)
+    plus ``memory_clip_index`` int tensor [N] (clip of each pose) and key_padding_mask [B, T, S];
+    or pass ``value_projected`` [B*T, S, 8, 32].  A replicated value whose pose dimension is a
+    stride-0 expand is de-duplicated automatically.
+    """
+
+    def __init__(self, num_frames=3, embed_dims=256, num_heads=8, num_levels=4, num_points=4,
+                 im2col_step=64, dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        _check_heads(embed_dims, num_heads)
+        self.norm_cfg = norm_cfg
+        self.dropout = nn.Identity()
+        self.batch_first = batch_first
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.num_frames = num_frames
+        self.frame_prefixes = frame_prefixes(num_frames)
+        for fp in self.frame_prefixes:
+            setattr(self, fp + 'sampling_offsets',
+                    nn.Linear(embed_dims, num_heads * num_levels * num_points * 2))
+            setattr(self, fp + 'attention_weights',
+                    nn.Linear(embed_dims, num_heads * num_levels * num_points))
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        for fp in self.frame_prefixes:
+            constant_init(getattr(self, fp + 'sampling_offsets'), 0.)
+            with torch.no_grad():  # own storage per frame (the reference aliases one tensor)
+                getattr(self, fp + 'sampling_offsets').bias.copy_(grid_init.view(-1))
+            constant_init(getattr(self, fp + 'attention_weights'), val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    def _cat_sources(self):
+        return ([getattr(self, fp + 'sampling_offsets') for fp in self.frame_prefixes],
+                [getattr(self, fp + 'attention_weights') for fp in self.frame_prefixes])
+
+    def project_value(self, memory_bt, key_padding_mask=None):
+        """memory_bt [B, T, S, C] (+ mask [B, T, S]) -> [B*T, S, 8, 32]."""
+        if key_padding_mask is not None:
+            memory_bt = memory_bt.masked_fill(key_padding_mask[..., None], 0.0)
+        v = self.value_proj(memory_bt)
+        B, T, S, _ = v.shape
+        return v.view(B * T, S, self.num_heads, -1)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                query_time_pos=None, key_padding_mask=None, reference_points=None,
+                spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        T, M, L, P = self.num_frames, self.num_heads, self.num_levels, self.num_points
+        q = batch_first(query) if not self.batch_first else query
+        N, num_query, _ = q.shape
+        clip_index = kwargs.get('memory_clip_index')
+        projected = kwargs.get('value_projected')
+        if projected is not None:
+            v = projected
+            n_clips = v.shape[0] // T
+            if clip_index is None:
+                assert n_clips == 1 or n_clips == N
+                clip_index = torch.arange(N, device=q.device) if n_clips == N and N > 1 else \
+                    torch.zeros(N, dtype=torch.long, device=q.device)
+        else:
+            # value arrives [S, n, T, C] (seq-first) or [n, S, T, C] (batch_first)
+            vb = value.permute(1, 2, 0, 3) if not self.batch_first else value.permute(0, 2, 1, 3)
+            n = vb.shape[0]                                     # vb: [n, T, S, C]
+            mask = key_padding_mask
+            if clip_index is None and n == N and N > 1 and vb.stride(0) == 0:
+                vb = vb[:1]                                     # stride-0 replica -> one clip
+                mask = mask[:1] if mask is not None else None
+                n = 1
+            if clip_index is None:
+                assert n in (1, N), 'value must carry one slab set per pose or per clip'
+                clip_index = torch.arange(N, device=q.device) if (n == N and N > 1) else \
+                    torch.zeros(N, dtype=torch.long, device=q.device)
+            assert vb.shape[1] == T
+            v = self.project_value(vb, mask)
+            n_clips = n
+        if reference_points.shape[-1] != 2:
+            raise ValueError('MulFrames joint attention is built for 2-d reference points '
+                             f'(got last dim {reference_points.shape[-1]})')
+        w, b = self._cat_proj()
+        proj = F.linear(q.reshape(N * num_query, self.embed_dims), w, b)
+        ref = reference_points.reshape(T, N * num_query, L, 2)
+        if _fused_ok(self, q, v) and L == 4 and P == 4:
+            unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
+            out = ops.deform_attn_grid_fused(
+                v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
+                proj, ref if ref.is_contiguous() else ref.contiguous(), T=T, n_clips=n_clips,
+                units_per_clip=num_query, unit_clip=unit_clip)
+            out = out.view(N, num_query, self.embed_dims)
+        else:
+            out = self._unfused(v, proj, ref, clip_index, spatial_shapes, level_start_index, N,
+                                num_query)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = seq_first_view(out)
+        return out + identity
+
+    def _unfused(self, v, proj, ref, clip_index, spatial_shapes, level_start_index, N, nq):
+        T, M, L, P = self.num_frames, self.num_heads, self.num_levels, self.num_points
+        n_off = T * M * L * P * 2
+        off = proj[:, :n_off].view(N, nq, T, M, L, P, 2)
+        lg = proj[:, n_off:].view(N, nq, T, M, L * P)
+        aw = lg.permute(0, 1, 3, 2, 4).reshape(N, nq, M, T * L * P).softmax(-1)
+        aw = aw.view(N, nq, M, T, L, P)
+        norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        out = 0
+        for t in range(T):
+            rp = ref[t].view(N, nq, L, 2)
+            loc = rp[:, :, None, :, None, :] + off[:, :, t] / norm[None, None, None, :, None, :]
+            vt = v[clip_index * T + t]
+            out = out + ops.MultiScaleDeformableAttnFunction.apply(
+                vt.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
+                aw[:, :, :, t].contiguous(), self.im2col_step)
+        return out
+
+
+@MMCV_ATTENTION.register_module()
+class MulFramesMultiScaleDeformableAttentionNumFrames3(MulFramesMultiScaleDeformableAttention):
+    """MO:1268-1587."""
+
+    def __init__(self, num_frames=3, **kwargs):
+        assert num_frames == 3
+        super().__init__(num_frames=3, **kwargs)
+
+
+@MMCV_ATTENTION.register_module()
+class MulFramesMultiScaleDeformableAttentionNumFrames5(MulFramesMultiScaleDeformableAttention):
+    """MO:1590-1981 (its ctor has no num_frames argument)."""
+
+    def __init__(self, **kwargs):
+        kwargs.pop('num_frames', None)
+        super().__init__(num_frames=5, **kwargs)
+
+
+MMCV_ATTENTION.register_module(name='MulFramesMultiScaleDeformableAttention',
+                               module=MulFramesMultiScaleDeformableAttention)

@@ -1,0 +1,77 @@
+"""``opera.VideoPoseV1`` (L6): backbone -> neck -> head, ``simple_test`` restated from
+opera/models/detectors/videoposev1.py:18-190 and mmdet SingleStageDetector.extract_feat
+(third_party/mmdetection/mmdet/models/detectors/single_stage.py:47).
+
+Native additions: ``forward_device`` keeps the whole clip batch on the device and returns
+fixed-shape result tensors (no host sync); B >= 1 clips per call (the reference asserts B = 1,
+videoposev1.py:175-177).
+"""
+import numpy as np
+import torch
+
+from .bricks import BaseModule
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+def bbox_kpt2result(bboxes, labels, kpts, num_classes):
+    """opera/core/keypoint/transforms.py:132-154."""
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)], \
+            [np.zeros((0, kpts.size(1), 3), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+        labels = labels.detach().cpu().numpy()
+        kpts = kpts.detach().cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes)], \
+        [kpts[labels == i, :, :] for i in range(num_classes)]
+
+
+@DETECTORS.register_module()
+class VideoPoseV1(BaseModule):
+
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        backbone = dict(backbone)
+        if pretrained:
+            backbone['pretrained'] = pretrained
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg)
+        bbox_head.update(test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    @torch.no_grad()
+    def forward_device(self, img, img_metas, rescale=False, **head_kwargs):
+        """img [B, T, 3, H, W] on the device; img_metas: one dict per clip.  Returns the
+        head's fixed-shape device result dict (see VideoPoseHeadMulFrames.get_bboxes)."""
+        feat = self.extract_feat(img)
+        outs = self.bbox_head(feat, img_metas, **head_kwargs)
+        return self.bbox_head.get_bboxes(outs, img_metas, rescale=rescale)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, rescale=False):
+        """videoposev1.py:159-190 -> per clip (bbox_results, kpt_results) lists of numpy arrays."""
+        res = self.forward_device(img, img_metas, rescale=rescale)
+        results_list = self.bbox_head.results_to_list(res)
+        return [bbox_kpt2result(b, l, k, self.bbox_head.num_classes) for b, l, k in results_list]
+
+    def forward(self, img, img_metas, return_loss=False, rescale=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError('pavenet_amd is a forward (inference) path')
+        if isinstance(img, (list, tuple)):  # mmdet forward_test nests one level per augmentation
+            img, img_metas = img[0], img_metas[0]
+        return self.simple_test(img, img_metas, rescale=rescale)

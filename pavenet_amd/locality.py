@@ -1,0 +1,44 @@
+"""XCD / L2-aware processing order of encoder tokens (host logic, cached per shape).
+
+MI355X deals workgroups round-robin over its 8 XCDs, each with a private 4 MiB L2, and one
+frame's projected value maps are 22.9 MB at 800x1344 -- far more than one L2.  The fused
+kernel (pave_kernels.hip: xcd_remap) hands every XCD one contiguous run of logical blocks;
+this module orders the units so that such a run is one horizontal image band across all
+levels (a query samples around its own position on every level, so a band of queries reads
+a band of every value map: ~1/8 of 22.9 MB, which fits the XCD's L2), and so that all XCDs
+work on the same frame at the same time.
+"""
+import numpy as np
+import torch
+
+N_XCD = 8
+
+
+def encoder_unit_order(levels, n_frames, mode='band'):
+    """Permutation [n_frames * S] int32: position -> unit (= frame * S + token).
+
+    levels: [(H, W), ...] in flattening order.  mode 'band': tokens of a frame sorted by
+    normalised row centre (ties: level, column), cut into 8 equal bands; units laid out
+    band-major, then frame, then in-band order.  mode 'none': identity.
+    """
+    S = sum(int(h) * int(w) for h, w in levels)
+    if mode == 'none':
+        return torch.arange(n_frames * S, dtype=torch.int32)
+    ys, lv, xs = [], [], []
+    for l, (h, w) in enumerate(levels):
+        h, w = int(h), int(w)
+        r = np.repeat(np.arange(h), w)
+        ys.append((r + 0.5) / h)
+        xs.append(np.tile(np.arange(w), h))
+        lv.append(np.full(h * w, l))
+    ys, lv, xs = np.concatenate(ys), np.concatenate(lv), np.concatenate(xs)
+    tok = np.lexsort((xs, lv, ys))  # primary key: y centre
+    bounds = [(S * i) // N_XCD for i in range(N_XCD + 1)]
+    out = []
+    for b in range(N_XCD):
+        band = tok[bounds[b]:bounds[b + 1]]
+        for f in range(n_frames):
+            out.append(f * S + band)
+    order = np.concatenate(out).astype(np.int32)
+    assert order.shape[0] == n_frames * S
+    return torch.from_numpy(order)

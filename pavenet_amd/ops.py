@@ -183,3 +183,24 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     if return_stats:
         return out, smax, ssum
     return out
+
+
+def oks_nms(kpts, scores, sigmas, thresh):
+    """Device OKS-NMS (HEAD:1624-1665).  kpts [n_clips, N, K, 3], scores [n_clips, N],
+    sigmas [K] float64 -> (keep [n_clips, N] int32, order [n_clips, N] int32)."""
+    lib = native.load()
+    _dev(kpts, 'kpts', torch.float32)
+    _dev(scores, 'scores', torch.float32)
+    _dev(sigmas, 'sigmas', torch.float64)
+    _require(kpts.dim() == 4 and kpts.shape[-1] == 3, 'oks_nms: kpts must be [n_clips, N, K, 3]')
+    n_clips, N, K, _ = kpts.shape
+    _require(tuple(scores.shape) == (n_clips, N) and sigmas.numel() == K,
+             'oks_nms: scores / sigmas shape mismatch')
+    keep = torch.empty((n_clips, N), dtype=torch.int32, device=kpts.device)
+    order = torch.empty((n_clips, N), dtype=torch.int32, device=kpts.device)
+    with torch.cuda.device(kpts.device):
+        st = lib.pave_oks_nms_f32(kpts.data_ptr(), scores.data_ptr(), sigmas.data_ptr(),
+                                  float(thresh), keep.data_ptr(), order.data_ptr(), n_clips, N,
+                                  K, _stream_ptr())
+    native.check(st, 'oks_nms')
+    return keep, order

@@ -1,0 +1,511 @@
+"""Decoders and transformers of the PAVE-Net forward path (same registry names / kwargs /
+state-dict keys as the reference).
+
+* ``opera.VideoPoseTransformerDecoderV2`` / ``V2_1``           OT:6661-6753 / 6757-6852   (a6)
+* ``mmcv.DeformableDetrTransformerDecoderV1`` / ``V1_2``       MT:794-886 / 889-986       (a8)
+* ``opera.VideoPoseTransformerMulFrames``                     OT:20986-21536             (a4, a9)
+* ``opera.PetrTransformerDecoder``, ``mmcv.DeformableDetrTransformerDecoder``  (a15)
+
+MT = third_party/mmdetection/mmdet/models/utils/transformer.py, OT = opera/models/utils/transformer.py.
+
+Device-side differences from the reference (results identical): tensors are kept batch-first
+contiguous under sequence-first views; constant-per-shape tensors (reference grids, level
+start indices, XCD unit order) are cached; the clip memory is never replicated per pose; the
+value projections of all decoder layers are hoisted out of the layer loop when asked.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .bricks import (BaseModule, TransformerLayerSequence, batch_first, inverse_sigmoid,
+                     layer_norm_any_layout, seq_first_view, xavier_init)
+from .deform_attn import (MulFramesMultiScaleDeformableAttention,
+                          MulFramesMultiScaleDeformablePoseAttention,
+                          MultiScaleDeformableAttention, frame_prefixes)
+from .locality import encoder_unit_order
+from .registry import (MMCV_TRANSFORMER, MMCV_TRANSFORMER_LAYER_SEQUENCE, TRANSFORMER,
+                       TRANSFORMER_LAYER_SEQUENCE, build_transformer_layer_sequence)
+
+_REF_BRANCH_KW = ('pre_pre_', 'pre_', '', 'next_', 'next_next_')
+
+
+def _collect_frame_branches(T, kwargs, suffix):
+    """Per-frame branch lists from the reference's kwarg names (pre_pre_X, pre_X, X, next_X,
+    next_next_X) or from the generic ``frame_<suffix>`` list (any T)."""
+    generic = kwargs.pop('frame_' + suffix, None)
+    named = {p: kwargs.pop(p + suffix, None) for p in _REF_BRANCH_KW}
+    if generic is not None:
+        assert len(generic) == T
+        return list(generic)
+    if named[''] is None:
+        return None
+    out = [named.get(p) for p in frame_prefixes(T)]
+    if any(b is None for b in out):
+        return None
+    return out
+
+
+# ---------------------------------------------------------------------------
+class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
+    """Pose decoder, any odd T (generalises OT:6661-6753 and 6757-6852)."""
+
+    def __init__(self, *args, return_intermediate=False, num_keypoints=17, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.num_keypoints = num_keypoints
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, **kwargs):
+        K = self.num_keypoints
+        T = getattr(self.layers[0].attentions[-1], 'num_frames', 1)
+        branches = _collect_frame_branches(T, kwargs, 'kpt_branches')
+        projected = kwargs.pop('values_projected', None)  # optional: one per layer
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == K * 2:
+                reference_points_input = reference_points[:, :, None] * \
+                    valid_ratios.repeat(1, 1, K)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            if projected is not None:
+                kwargs['value_projected'] = projected[lid]
+            output = layer(output, *args, reference_points=reference_points_input, **kwargs)
+            output = output.permute(1, 0, 2)
+            if branches is not None:
+                tmps = torch.cat([b[lid](output) for b in branches], dim=1)  # OT:6728-6732
+                if reference_points.shape[-1] == K * 2:
+                    reference_points = (tmps + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    raise NotImplementedError
+            output = output.permute(1, 0, 2)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+TRANSFORMER_LAYER_SEQUENCE.register_module(name='VideoPoseTransformerDecoderV2',
+                                           module=VideoPoseTransformerDecoderMulFrames)
+TRANSFORMER_LAYER_SEQUENCE.register_module(name='VideoPoseTransformerDecoderV2_1',
+                                           module=VideoPoseTransformerDecoderMulFrames, force=True)
+TRANSFORMER_LAYER_SEQUENCE.register_module(name='VideoPoseTransformerDecoderMulFrames',
+                                           module=VideoPoseTransformerDecoderMulFrames, force=True)
+
+
+class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
+    """Joint decoder, any odd T (generalises MT:794-886 and 889-986).
+
+    reference_points [T*N, K, 2] frame-major on dim 0; valid_ratios [N*T, L, 2]."""
+
+    def __init__(self, *args, return_intermediate=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, **kwargs):
+        T = getattr(self.layers[0].attentions[-1], 'num_frames', 1)
+        branches = _collect_frame_branches(T, kwargs, 'reg_branches')
+        projected = kwargs.pop('values_projected', None)
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                reference_points_input = reference_points[:, :, None] * \
+                    torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            if projected is not None:
+                kwargs['value_projected'] = projected[lid]
+            output = layer(output, *args, reference_points=reference_points_input, **kwargs)
+            output = output.permute(1, 0, 2)
+            if branches is not None:
+                tmps = torch.cat([b[lid](output) for b in branches], dim=0)  # MT:861-864
+                assert reference_points.shape[-1] == 2
+                reference_points = (tmps + inverse_sigmoid(reference_points)).sigmoid()
+            output = output.permute(1, 0, 2)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module(
+    name='DeformableDetrTransformerDecoderV1', module=DeformableDetrTransformerDecoderMulFrames)
+MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module(
+    name='DeformableDetrTransformerDecoderV1_2', module=DeformableDetrTransformerDecoderMulFrames,
+    force=True)
+MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module(
+    name='DeformableDetrTransformerDecoderMulFrames',
+    module=DeformableDetrTransformerDecoderMulFrames, force=True)
+
+
+@MMCV_TRANSFORMER_LAYER_SEQUENCE.register_module()
+class DeformableDetrTransformerDecoder(TransformerLayerSequence):
+    """Stock single-frame refine decoder (MT:705-791); reference points are detached there,
+    which is a no-op at inference."""
+
+    def __init__(self, *args, return_intermediate=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, reg_branches=None,
+                **kwargs):
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                reference_points_input = reference_points[:, :, None] * \
+                    torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            output = layer(output, *args, reference_points=reference_points_input, **kwargs)
+            output = output.permute(1, 0, 2)
+            if reg_branches is not None:
+                tmp = reg_branches[lid](output)
+                if reference_points.shape[-1] == 4:
+                    new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    new_reference_points = tmp.clone()
+                    new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
+                    new_reference_points = new_reference_points.sigmoid()
+                reference_points = new_reference_points.detach()
+            output = output.permute(1, 0, 2)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class PetrTransformerDecoder(TransformerLayerSequence):
+    """PETR pose decoder (OT:4148-4231): single frame, references detached."""
+
+    def __init__(self, *args, return_intermediate=False, num_keypoints=17, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.num_keypoints = num_keypoints
+
+    def forward(self, query, *args, reference_points=None, valid_ratios=None, kpt_branches=None,
+                **kwargs):
+        K = self.num_keypoints
+        output = query
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == K * 2:
+                reference_points_input = reference_points[:, :, None] * \
+                    valid_ratios.repeat(1, 1, K)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+            output = layer(output, *args, reference_points=reference_points_input, **kwargs)
+            output = output.permute(1, 0, 2)
+            if kpt_branches is not None:
+                tmp = kpt_branches[lid](output)
+                if reference_points.shape[-1] == K * 2:
+                    reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid().detach()
+                else:
+                    raise NotImplementedError
+            output = output.permute(1, 0, 2)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+# ---------------------------------------------------------------------------
+@MMCV_TRANSFORMER.register_module()
+class Transformer(BaseModule):
+    """mmdet Transformer base (MT:533-576): builds ``encoder`` and ``decoder``."""
+
+    def __init__(self, encoder=None, decoder=None, init_cfg=None):
+        super().__init__(init_cfg=init_cfg)
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.decoder = build_transformer_layer_sequence(decoder)
+        self.embed_dims = self.encoder.embed_dims
+
+    def init_weights(self):
+        for m in self.modules():
+            if hasattr(m, 'weight') and m.weight is not None and m.weight.dim() > 1:
+                xavier_init(m, distribution='uniform')
+        self._is_init = True
+
+
+class _LevelGeometry:
+    """Host-side description of the flattened multi-level token sequence (cached per shape)."""
+
+    def __init__(self, hw_list, device):
+        self.hw = [(int(h), int(w)) for h, w in hw_list]
+        self.spatial_shapes = torch.as_tensor(self.hw, dtype=torch.long, device=device)
+        starts = [0]
+        for h, w in self.hw[:-1]:
+            starts.append(starts[-1] + h * w)
+        self.starts = starts
+        self.level_start_index = torch.as_tensor(starts, dtype=torch.long, device=device)
+        self.S = sum(h * w for h, w in self.hw)
+        self._order = {}
+
+    def unit_order(self, n_frames, device):
+        if n_frames not in self._order:
+            self._order[n_frames] = encoder_unit_order(self.hw, n_frames).to(device)
+        return self._order[n_frames]
+
+
+@TRANSFORMER.register_module()
+class VideoPoseTransformerMulFrames(Transformer):
+    """OT:20986-21536."""
+
+    def __init__(self, hm_encoder=None, refine_decoder=None, as_two_stage=True,
+                 num_feature_levels=4, two_stage_num_proposals=300, num_keypoints=17,
+                 num_frames=3, **kwargs):
+        super().__init__(**kwargs)
+        self.as_two_stage = as_two_stage
+        self.num_feature_levels = num_feature_levels
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.embed_dims = self.encoder.embed_dims
+        self.num_keypoints = num_keypoints
+        self.num_frames = num_frames
+        # hm_encoder is accepted and ignored, as in the reference (OT:21041 commented out)
+        self.refine_decoder = build_transformer_layer_sequence(refine_decoder)
+        self.init_layers()
+        self._geom = {}
+        self.hoist_value_proj = True
+        self.xcd_unit_order = True
+
+    def init_layers(self):
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
+        if self.as_two_stage:
+            self.enc_output = nn.Linear(self.embed_dims, self.embed_dims)
+            self.enc_output_norm = nn.LayerNorm(self.embed_dims)
+            self.refine_query_embedding = nn.Embedding(self.num_keypoints, self.embed_dims * 2)
+        else:
+            self.reference_points = nn.Linear(self.embed_dims, 2 * self.num_keypoints)
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MultiScaleDeformableAttention):  # OT:21084-21089
+                m.init_weights()
+        if not self.as_two_stage:
+            xavier_init(self.reference_points, distribution='uniform', bias=0.)
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.refine_query_embedding.weight)
+        self._is_init = True
+
+    # -- helpers (OT:21095-21216) -------------------------------------------
+    def geometry(self, hw_list, device):
+        key = (tuple((int(h), int(w)) for h, w in hw_list), str(device))
+        if key not in self._geom:
+            self._geom[key] = _LevelGeometry(hw_list, device)
+        return self._geom[key]
+
+    def gen_encoder_output_proposals(self, memory, memory_padding_mask, geom):
+        N, S, C = memory.shape
+        dev = memory.device
+        proposals = []
+        _cur = 0
+        for lvl, (H, W) in enumerate(geom.hw):
+            if memory_padding_mask is not None:
+                m = memory_padding_mask[:, _cur:(_cur + H * W)].view(N, H, W, 1)
+                valid_H = torch.sum(~m[:, :, 0, 0], 1)
+                valid_W = torch.sum(~m[:, 0, :, 0], 1)
+            else:
+                valid_H = torch.full((N,), H, device=dev)
+                valid_W = torch.full((N,), W, device=dev)
+            grid_y, grid_x = torch.meshgrid(
+                torch.linspace(0, H - 1, H, dtype=torch.float32, device=dev),
+                torch.linspace(0, W - 1, W, dtype=torch.float32, device=dev), indexing='ij')
+            grid = torch.cat([grid_x.unsqueeze(-1), grid_y.unsqueeze(-1)], -1)
+            scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N, 1, 1, 2)
+            grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+            proposals.append(grid.view(N, -1, 2))
+            _cur += H * W
+        output_proposals = torch.cat(proposals, 1)
+        valid = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
+        output_proposals = torch.log(output_proposals / (1 - output_proposals))
+        if memory_padding_mask is not None:
+            output_proposals = output_proposals.masked_fill(
+                memory_padding_mask.unsqueeze(-1), float('inf'))
+        output_proposals = output_proposals.masked_fill(~valid, float('inf'))
+        output_memory = memory
+        if memory_padding_mask is not None:
+            output_memory = output_memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
+        output_memory = output_memory.masked_fill(~valid, float(0))
+        output_memory = self.enc_output_norm(self.enc_output(output_memory))
+        return output_memory, output_proposals
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        reference_points_list = []
+        for lvl, (H, W) in enumerate(spatial_shapes):
+            H, W = int(H), int(W)
+            ref_y, ref_x = torch.meshgrid(
+                torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device),
+                torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device),
+                indexing='ij')
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+            reference_points_list.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(reference_points_list, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+    def _frame_branch_lists(self, kwargs, suffix):
+        """Reference kwarg names -> per-frame list (or generic frame_<suffix>)."""
+        return _collect_frame_branches(self.num_frames, kwargs, suffix)
+
+    # -- a4: forward (OT:21218-21456) ----------------------------------------
+    def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, cls_branches=None,
+                sigma_branches=None, has_padding=True, **kwargs):
+        assert self.as_two_stage or query_embed is not None
+        T = self.num_frames
+        branches = self._frame_branch_lists(kwargs, 'kpt_branches')
+        kpt_branches = branches[T // 2] if branches is not None else None
+        dev = mlvl_feats[0].device
+        geom = self.geometry([f.shape[-2:] for f in mlvl_feats], dev)
+        feat_flatten, mask_flatten, lvl_pos_embed_flatten = [], [], []
+        for lvl, (feat, mask, pos_embed) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
+            feat_flatten.append(feat.flatten(2).transpose(1, 2))
+            mask_flatten.append(mask.flatten(1))
+            pos_embed = pos_embed.flatten(2).transpose(1, 2)
+            lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
+        feat_flatten = torch.cat(feat_flatten, 1)                      # [B*T, S, C] contiguous
+        mask_flatten = torch.cat(mask_flatten, 1)
+        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        if lvl_pos_embed_flatten.shape[0] != feat_flatten.shape[0]:    # shared across frames
+            lvl_pos_embed_flatten = lvl_pos_embed_flatten.expand(feat_flatten.shape[0], -1, -1)
+        spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+        if valid_ratios.shape[0] != feat_flatten.shape[0]:
+            valid_ratios = valid_ratios.expand(feat_flatten.shape[0], -1, -1)
+        reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
+        attn_mask = mask_flatten if has_padding else None
+        if attn_mask is not None and attn_mask.shape[0] != feat_flatten.shape[0]:
+            attn_mask = attn_mask.expand(feat_flatten.shape[0], -1)
+        bs = feat_flatten.shape[0]
+        extra = {}
+        if self.xcd_unit_order and feat_flatten.is_cuda:
+            extra['unit_order'] = geom.unit_order(bs, dev)
+        memory = self.encoder(
+            query=seq_first_view(feat_flatten), key=None, value=None,
+            query_pos=seq_first_view(lvl_pos_embed_flatten), query_key_padding_mask=attn_mask,
+            spatial_shapes=spatial_shapes, reference_points=reference_points,
+            level_start_index=level_start_index, valid_ratios=valid_ratios, **extra)
+        memory = batch_first(memory)                                   # [B*T, S, C]
+        c = memory.shape[-1]
+        ctr = slice(T // 2, None, T)
+        now_frame_memory = memory[ctr]
+        now_frame_mask_flatten = mask_flatten[ctr] if mask_flatten.shape[0] == bs else mask_flatten
+        now_frame_valid_ratios = valid_ratios[ctr]
+        if self.as_two_stage:
+            output_memory, output_proposals = self.gen_encoder_output_proposals(
+                now_frame_memory, now_frame_mask_flatten if has_padding else None, geom)
+            enc_outputs_class = cls_branches[self.decoder.num_layers](output_memory)
+            enc_outputs_kpt_unact = kpt_branches[self.decoder.num_layers](output_memory)
+            enc_outputs_kpt_unact[..., 0::2] += output_proposals[..., 0:1]
+            enc_outputs_kpt_unact[..., 1::2] += output_proposals[..., 1:2]
+            enc_outputs_sigma_unact = sigma_branches[self.decoder.num_layers](output_memory)
+            topk = self.two_stage_num_proposals
+            topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
+            forced = kwargs.pop('force_topk_proposals', None)
+            if forced is not None:  # parity harness: follow the reference's selection
+                topk_proposals = forced
+            self.last_topk_proposals = topk_proposals
+            topk_kpts_unact = torch.gather(
+                enc_outputs_kpt_unact, 1,
+                topk_proposals.unsqueeze(-1).repeat(1, 1, enc_outputs_kpt_unact.size(-1)))
+            tgt = torch.gather(output_memory, 1,
+                               topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
+            reference_points = topk_kpts_unact.sigmoid().repeat(1, T, 1)
+            init_reference_out = reference_points
+            query_pos, query = torch.split(query_embed, c, dim=1)
+            query_pos = query_pos.unsqueeze(0).expand(bs // T, -1, -1)
+            query = query.unsqueeze(0).expand(bs // T, -1, -1)
+            query = tgt + query
+        else:
+            query_pos, query = torch.split(query_embed, c, dim=1)
+            query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+            query = query.unsqueeze(0).expand(bs, -1, -1)
+            reference_points = self.reference_points(query_pos).sigmoid()
+            init_reference_out = reference_points
+            enc_outputs_class = enc_outputs_kpt_unact = enc_outputs_sigma_unact = None
+        dec_kwargs = {}
+        if branches is not None:
+            dec_kwargs['frame_kpt_branches'] = branches
+        if self.hoist_value_proj and all(
+                isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
+                for l in self.decoder.layers):
+            dec_kwargs['values_projected'] = [
+                l.attentions[-1].project_value(memory, attn_mask) for l in self.decoder.layers]
+        inter_states, inter_references = self.decoder(
+            query=seq_first_view(query.contiguous()), key=None, value=seq_first_view(memory),
+            query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
+            reference_points=reference_points, spatial_shapes=spatial_shapes,
+            level_start_index=level_start_index, valid_ratios=now_frame_valid_ratios,
+            **dec_kwargs)
+        memory_out = seq_first_view(memory)
+        if self.as_two_stage:
+            return inter_states, init_reference_out, inter_references, enc_outputs_class, \
+                enc_outputs_kpt_unact, enc_outputs_sigma_unact, None, memory_out
+        return inter_states, init_reference_out, inter_references, None, None, None, None, None, None
+
+    # -- a9: forward_refine (OT:21458-21536) ---------------------------------
+    def forward_refine(self, mlvl_masks, memory, reference_points_pose, img_inds,
+                       has_padding=True, **kwargs):
+        """memory [S, B, T, C] (view of [B, T, S, C]); reference_points_pose [T*N, 2K]
+        frame-major; img_inds [N] clip index of each pose."""
+        T = self.num_frames
+        branches = self._frame_branch_lists(kwargs, 'kpt_branches')
+        dev = memory.device
+        geom = self.geometry([m.shape[-2:] for m in mlvl_masks], dev)
+        mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
+        spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+        B = memory.shape[1]
+        if valid_ratios.shape[0] != B * T:
+            valid_ratios = valid_ratios.expand(B * T, -1, -1)
+            mask_flatten = mask_flatten.expand(B * T, -1)
+        rq = self.refine_query_embedding.weight
+        query_pos, query = torch.split(rq, rq.size(1) // 2, dim=1)
+        pos_num = reference_points_pose.size(0) // T
+        query_pos = query_pos.unsqueeze(0).expand(pos_num, -1, -1)
+        query = query.unsqueeze(0).expand(pos_num, -1, -1)
+        reference_points = reference_points_pose.reshape(-1, reference_points_pose.size(1) // 2, 2)
+        mask_bt = mask_flatten.reshape(-1, T, mask_flatten.size(-1))          # [B, T, S]
+        vr = valid_ratios.reshape(-1, T, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
+        dec_kwargs = {}
+        if branches is not None:
+            dec_kwargs['frame_reg_branches'] = branches
+        mem_bt = memory.permute(1, 2, 0, 3)                                   # [B, T, S, C]
+        attn_mask = mask_bt if has_padding else None
+        if self.hoist_value_proj and all(
+                isinstance(l.attentions[-1], MulFramesMultiScaleDeformableAttention)
+                for l in self.refine_decoder.layers):
+            dec_kwargs['values_projected'] = [
+                l.attentions[-1].project_value(mem_bt, attn_mask)
+                for l in self.refine_decoder.layers]
+        inter_states, inter_references = self.refine_decoder(
+            query=seq_first_view(query.contiguous()), key=None, value=memory,
+            query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
+            reference_points=reference_points, spatial_shapes=spatial_shapes,
+            level_start_index=level_start_index, valid_ratios=vr.flatten(0, 1),
+            memory_clip_index=img_inds, **dec_kwargs)
+        return inter_states, reference_points, inter_references

@@ -1,0 +1,91 @@
+"""Micro-benchmark of the HIP sampling kernels at BASELINE sizes (800x1344 -> S = 22 323).
+Prints one line per kernel: us per launch and algorithmic GB/s (SURVEY 8d byte counts)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pavenet_amd import ops  # noqa: E402
+
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
+
+
+def timeit(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters
+
+
+def grid_refs(frames, dev):
+    ys = torch.cat([((torch.arange(h * w) // w).float() + 0.5) / h for h, w in LEVELS])
+    xs = torch.cat([((torch.arange(h * w) % w).float() + 0.5) / w for h, w in LEVELS])
+    r = torch.stack([xs, ys], -1)[None, :, None, :].expand(frames, -1, 4, 2)
+    return r.reshape(1, -1, 4, 2).contiguous().to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=3)
+    ap.add_argument('--sigma', type=float, default=3.0, help='offset std-dev in pixels')
+    ap.add_argument('--order', default='none')
+    args = ap.parse_args()
+    dev = 'cuda'
+    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    F = args.frames
+    g = torch.Generator(device=dev).manual_seed(0)
+    value = torch.randn(F, S, 8, 32, device=dev, generator=g)
+    U = F * S
+    proj = torch.randn(U, 384, device=dev, generator=g)
+    proj[:, :256] *= args.sigma
+    ref = grid_refs(F, dev)
+    order = None
+    if args.order != 'none':
+        from pavenet_amd.locality import encoder_unit_order
+        order = encoder_unit_order(LEVELS, F, mode=args.order).to(dev)
+    us = timeit(lambda: ops.deform_attn_grid_fused(value, shapes, lsi, proj, ref, T=1, n_clips=F,
+                                                   units_per_clip=S, order=order))
+    alg = 4 * (F * S * 256 + U * 384 + U * 256)
+    print(f'enc_fused   frames={F} order={args.order}: {us:9.1f} us  {us / F:8.1f} us/frame  '
+          f'alg {alg / us / 1e3:7.1f} GB/s')
+    # the un-fused reference-shaped op on the same work
+    off = proj[:, :256].view(F, S, 8, 4, 4, 2)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    loc = (ref.view(F, S, 1, 4, 1, 2) + off / norm[None, None, None, :, None, :]).contiguous()
+    aw = proj[:, 256:].view(F, S, 8, 16).softmax(-1).view(F, S, 8, 4, 4).contiguous()
+    us = timeit(lambda: ops.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64))
+    alg2 = 4 * (F * S * 256 + U * 8 * 16 * 3 + U * 256)
+    print(f'msda_generic frames={F}: {us:9.1f} us  {us / F:8.1f} us/frame  alg {alg2 / us / 1e3:7.1f} GB/s')
+    # pose decoder shape: Q=300, K=15, T frames of one clip
+    for T in (3, 7):
+        if T > F:
+            continue
+        Q, K = 300, 15
+        pp = torch.randn(Q, T * 8 * 4 * K * 3, device=dev, generator=g)
+        rp = torch.rand(1, T * Q, 4, 2 * K, device=dev, generator=g) * 0.5 + 0.25
+        us = timeit(lambda: ops.deform_attn_pose_fused(value[:T], shapes, lsi, pp, rp, T=T,
+                                                       n_clips=1, num_query=Q, num_keypoints=K))
+        print(f'pose_fused  T={T} Q=300: {us:9.1f} us')
+        N = 20
+        jp = torch.randn(N * K, T * 8 * 16 * 3, device=dev, generator=g)
+        jp[:, :T * 256] *= args.sigma
+        jr = torch.rand(T, N * K, 4, 2, device=dev, generator=g) * 0.8 + 0.1
+        uc = torch.zeros(N * K, dtype=torch.int32, device=dev)
+        us = timeit(lambda: ops.deform_attn_grid_fused(value[:T], shapes, lsi, jp, jr, T=T,
+                                                       n_clips=1, units_per_clip=N * K,
+                                                       unit_clip=uc))
+        print(f'joint_fused T={T} N=20: {us:9.1f} us')
+
+
+if __name__ == '__main__':
+    main()
