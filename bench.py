@@ -1,0 +1,170 @@
+"""bench.py -- PAVE-Net forward throughput on MI355X (clips/s), the BASELINE.json metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): PAVE-Net
+R-50, T = 7 frames, batch = 4 clips of synthetic 800x1344 video per GPU, 300 pose queries,
+K = 15 keypoints, max_per_img = 20, random weights, fp32 -- the whole ``simple_test`` path:
+backbone -> neck -> 6-layer deformable encoder -> proposals/top-k -> 3-layer pose-aware T-frame
+decoder -> 2-layer joint decoder -> OKS-NMS, results copied to the host.  One "step" = one such
+batch.  Multi-GPU is clip-parallel (independent clips per rank, weak scaling) with one RCCL
+all-gather of the fixed-shape results per step.
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant hand-written kernel, the
+fused encoder deformable-attention launch, timed with HIP events on its own stream inside the
+timed region; ``cpu_baseline`` is the CPU oracle (a port of the reference's CPU path) timed on
+rank 0 at N = 1 on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
+S_TOKENS = sum(h * w for h, w in LEVELS)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=7)
+    ap.add_argument('--clips', type=int, default=4, help='clips per GPU per step')
+    ap.add_argument('--height', type=int, default=800)
+    ap.add_argument('--width', type=int, default=1344)
+    ap.add_argument('--max-per-img', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-frames', type=int, default=None)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_encoder_launch(n_frames):
+    """4 B x [value S*256 + offsets/logits S*8*16*3 + out S*256] per frame-layer
+    = 80.0 MB at S = 22 323; one launch covers all frames of the batch."""
+    return 4 * n_frames * S_TOKENS * (256 + 8 * 16 * 3 + 256)
+
+
+def cpu_baseline(model, args, frames):
+    """The oracle (CPU restatement of the reference's path, torch-CPU sampler as the
+    reference's own CPU fallback uses) on ONE clip of the same shape."""
+    from oracle import pavenet_ref as R
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(num_frames=frames, num_keypoints=15, num_query=300, max_per_img=args.max_per_img)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, frames, 3, args.height, args.width, generator=g)
+    threads = torch.get_num_threads()
+    R.SAMPLER = 'torch'
+    t0 = time.time()
+    with torch.no_grad():
+        R.videopose_simple_test(sd, cfg, img)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit='clips/s', cores=threads, kind='port',
+                sample=f'1 clip, T={frames}, {args.height}x{args.width}, max_per_img='
+                       f'{args.max_per_img}, oracle/pavenet_ref.py with torch-CPU grid_sample '
+                       f'sampler, {threads} threads, {dt:.1f} s')
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pavenet_amd import ops
+    from pavenet_amd.models import build_model, videopose_r50_cfg
+    from pavenet_amd.weights import init_random_weights
+
+    T, B = args.frames, args.clips
+    model = build_model(videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img))
+    init_random_weights(model, seed=0)
+    model = model.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
+    metas = [dict(batch_input_shape=(args.height, args.width),
+                  img_shape=(args.height, args.width, 3), scale_factor=(1., 1., 1., 1.))
+             for _ in range(B)]
+    N, K = args.max_per_img, 15
+
+    def step():
+        res = model.forward_device(img, metas)
+        packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1),
+                            res['keep'].float()], dim=1)  # [B, N*5 + N*K*3 + N]
+        if dist is not None:
+            out = torch.empty((world,) + tuple(packed.shape), device=dev)
+            dist.all_gather_into_tensor(out, packed)
+            packed = out
+        return packed.cpu()  # results on the host, as simple_test returns them
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ops.KERNEL_EVENTS = []  # encoder launches record (start, end) HIP events on their stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    events = ops.KERNEL_EVENTS
+    ops.KERNEL_EVENTS = None
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    enc = [s.elapsed_time(e) * 1e-3 for tag, s, e in events if tag == 'enc_grid_T1']
+    n_frames = B * T
+    roofline = None
+    if enc:
+        avg = sum(enc) / len(enc)
+        achieved = algorithmic_bytes_encoder_launch(n_frames) / avg / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, 'profiles', 'enc_kernel_traffic.json')
+        if os.path.exists(tj):
+            traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
+        roofline = dict(bound='hbm', kernel='fused_deform_attn_kernel<GRID,T=1> (encoder MSDA)',
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        launches=len(enc), avg_us=round(avg * 1e6, 1),
+                        algorithmic_bytes_per_launch=algorithmic_bytes_encoder_launch(n_frames))
+    if rank == 0:
+        clips = B * world * args.steps
+        line = dict(metric='clips/sec (T=7, 800x1344) fwd', value=round(clips / dt, 4),
+                    unit='clips/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload=f'PAVE-Net R-50 T={T} frames, batch={B} clips/GPU, '
+                                         f'{args.height}x{args.width}, Q=300, K=15, '
+                                         f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
+                                parallelism=f'clip-parallel x{world}',
+                                detections_last_step=int(last[..., -N:].sum().item())),
+                    roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(model, args, args.cpu_baseline_frames or T)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

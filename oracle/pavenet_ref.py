@@ -97,8 +97,14 @@ def msda_forward_torch(value, shapes, loc, attw):
     return out.transpose(1, 2).contiguous()
 
 
+SAMPLER = 'c'  # 'torch' = the reference's own CPU formulation (multi-threaded grid_sample)
+
+
 def msda(value, shapes, lsi, loc, attw):
-    """Sampler used inside the restated modules: the C restatement."""
+    """Sampler used inside the restated modules: the C restatement (or, for timing the CPU
+    baseline, the reference's grid_sample formulation MO:92-149)."""
+    if SAMPLER == 'torch':
+        return msda_forward_torch(value, shapes, loc, attw)
     out = msda_forward_c(value.detach().cpu().numpy(), shapes.cpu().numpy(),
                          lsi.cpu().numpy(), loc.detach().cpu().numpy(),
                          attw.detach().cpu().numpy())

@@ -20,8 +20,29 @@ import torch
 from . import native
 
 
+# When set to a list, the fused launches append (tag, start_event, end_event) recorded on the
+# stream they launch on (bench.py uses this to time the dominant kernel inside its timed region).
+KERNEL_EVENTS = None
+
+
 def _stream_ptr():
     return torch.cuda.current_stream().cuda_stream
+
+
+class _Timed:
+    def __init__(self, tag):
+        self.tag = tag if KERNEL_EVENTS is not None else None
+
+    def __enter__(self):
+        if self.tag is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.tag is not None:
+            self.e.record()
+            KERNEL_EVENTS.append((self.tag, self.s, self.e))
 
 
 def _require(cond, msg):
@@ -128,7 +149,8 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     if return_stats:
         smax = torch.empty((n_units, 8), dtype=f32, device=value.device)
         ssum = torch.empty((n_units, 8), dtype=f32, device=value.device)
-    with torch.cuda.device(value.device):
+    tag = 'enc_grid_T1' if (T == 1 and unit_clip is None) else f'grid_T{T}'
+    with torch.cuda.device(value.device), _Timed(tag):
         st = lib.pave_deform_attn_grid_fused_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             proj.data_ptr(), ref.data_ptr(),
@@ -172,7 +194,7 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     if return_stats:
         smax = torch.empty((n_clips * Q, 8), dtype=f32, device=value.device)
         ssum = torch.empty((n_clips * Q, 8), dtype=f32, device=value.device)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _Timed(f'pose_T{T}'):
         st = lib.pave_deform_attn_pose_fused_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             proj.data_ptr(), ref.data_ptr(), out.data_ptr(),

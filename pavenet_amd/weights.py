@@ -1,0 +1,33 @@
+"""Random-weight initialisation for benchmarks and demos (no checkpoints are published for
+PAVE-Net, README.md:14-15 of the reference)."""
+import torch
+
+
+@torch.no_grad()
+def init_random_weights(model, seed=0):
+    """Reference-equivalent ``init_weights`` under a fixed seed, then re-randomise the
+    sampling-offset / attention-logit Linears: their default init is
+    all-zero weights (OT:1631-1642), which makes every query sample the same points."""
+    torch.manual_seed(seed)
+    for m in (model.backbone, model.neck, model.bbox_head):
+        if m is not None:
+            m.init_weights()
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, p in model.named_parameters():
+        if 'sampling_offsets' in name or 'attention_weights' in name:
+            std = 0.05 if name.endswith('weight') else 0.5
+            p.copy_(torch.randn(p.shape, generator=g) * std)
+        elif 'cls_branches' in name and name.endswith('weight'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)  # spread the proposal scores
+        elif ('kpt_branches' in name) and name.endswith('.6.weight'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    # BN running stats as a trained net would have (non-trivial but well conditioned)
+    for name, b in model.named_buffers():
+        if name.endswith('running_var'):
+            b.copy_(1.0 + 0.1 * torch.rand(b.shape, generator=g))
+        elif name.endswith('running_mean'):
+            b.copy_(0.1 * torch.randn(b.shape, generator=g))
+    for m in model.modules():
+        if m.__class__.__name__ == 'Bottleneck':
+            m.bn3.weight.fill_(0.3)
+    return model
