@@ -116,6 +116,22 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
 int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigmas, double thresh,
                      int32_t* keep, int32_t* order, int n_clips, int N, int K, void* stream);
 
+/*
+ * Fused row epilogues around the library GEMMs / convolutions (HBM-bound, one pass).
+ *   bias_act_rows:      y[r,c] = act(x[r,c] + bias[c] + res[r,c]);  bias / res may be NULL,
+ *                       y may alias x; relu != 0 applies max(.,0).  Replaces the separate
+ *                       bias, residual-add and ReLU kernels behind conv / Linear
+ *                       (mmdet resnet.py Bottleneck.forward, mmcv FFN).
+ *   bias_add_layernorm: y[r,:] = LayerNorm(x[r,:] + bias + res[r,:]) * gamma + beta,
+ *                       C % 4 == 0, C <= 1024 (the 'attn/ffn -> + identity -> norm' step of
+ *                       mmcv BaseTransformerLayer.forward, bricks/transformer.py:1316-1353).
+ */
+int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, float* y,
+                           long long rows, int C, int relu, void* stream);
+int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* res,
+                                const float* gamma, const float* beta, float* y, long long rows,
+                                int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

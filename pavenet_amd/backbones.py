@@ -151,6 +151,45 @@ class ResNet(BaseModule):
         self._folded = (key, f)
         return f
 
+    @staticmethod
+    def _as_rows(x):
+        """channels_last [N, C, H, W] -> ([N*H*W, C] view, (N, H, W))."""
+        n, c, h, w = x.shape
+        return x.permute(0, 2, 3, 1).reshape(-1, c), (n, h, w)
+
+    @staticmethod
+    def _as_map(rows, nhw):
+        n, h, w = nhw
+        return rows.view(n, h, w, rows.shape[-1]).permute(0, 3, 1, 2)  # channels_last 4-D
+
+    def _bottleneck_gemm(self, blk, x, f, name, bi):
+        """Bottleneck with its two 1x1 convolutions as row GEMMs on the NHWC map (hipBLASLt,
+        bias + ReLU / residual in the GEMM epilogue) and ONE fused bias+ReLU pass after each of
+        the 3x3 convolution and the residual GEMM (pave_bias_act_rows_f32)."""
+        from . import ops
+        rows, nhw = self._as_rows(x)
+        w1, b1 = f[(name, bi, 'conv1')]
+        y = torch._addmm_activation(b1, rows, w1.flatten(1).t())          # conv1 + bn1 + relu
+        y = self._as_map(y, nhw)
+        w2, b2 = f[(name, bi, 'conv2')]
+        c2 = blk.conv2
+        y = F.conv2d(y, w2, None, c2.stride, c2.padding, c2.dilation)     # MIOpen 3x3
+        ops.bias_act_rows_(y, b2, None, relu=True)                        # bn2 + relu, one pass
+        yrows, onhw = self._as_rows(y)
+        w3, b3 = f[(name, bi, 'conv3')]
+        if blk.downsample is not None:
+            wd, bd = f[(name, bi, 'ds')]
+            s = blk.downsample[0].stride[0]
+            xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
+            xrows, _ = self._as_rows(xs)
+            idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())          # both biases here
+            out = torch.addmm(idt, yrows, w3.flatten(1).t())
+            ops.bias_act_rows_(out, None, None, relu=True)
+        else:
+            out = torch.addmm(rows, yrows, w3.flatten(1).t())             # + identity in the GEMM
+            ops.bias_act_rows_(out, b3, None, relu=True)
+        return self._as_map(out, onhw)
+
     def forward(self, x):
         if self.input_type == 'mul_frames':
             x = x.flatten(0, 1)  # [B, T, C, H, W] -> [B*T, C, H, W]  (resnet.py:634-639)
@@ -158,12 +197,21 @@ class ResNet(BaseModule):
         f = self._build_folded()
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
+        gemm_path = (self.channels_last and x.is_cuda and x.dtype == torch.float32
+                     and self.style == 'pytorch')
         w, b = f['stem']
-        x = F.relu_(F.conv2d(x, w, b, 2, 3))
+        if gemm_path:
+            from . import ops
+            x = ops.bias_act_rows_(F.conv2d(x, w, None, 2, 3), b, None, relu=True)
+        else:
+            x = F.relu_(F.conv2d(x, w, b, 2, 3))
         x = self.maxpool(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             for bi, blk in enumerate(getattr(self, name)):
+                if gemm_path and isinstance(blk, Bottleneck):
+                    x = self._bottleneck_gemm(blk, x, f, name, bi)
+                    continue
                 identity = x
                 y = x
                 for cn, _, act in blk.pairs:

@@ -99,6 +99,31 @@ def layer_norm_any_layout(norm, x):
     return norm(x)
 
 
+def _fusable(*tensors):
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None):
+    """(x @ W^T + b + identity) [-> LayerNorm], batch-first tensors [..., C].
+
+    Device fp32: the residual rides the GEMM (beta = 1, C = identity) and bias + LayerNorm are
+    one hand-written pass (pave_bias_add_layernorm_f32) -- 2 passes over the activation instead
+    of the 5 of Linear / add / LayerNorm run separately.  Elsewhere: plain torch ops."""
+    C_out = linear.out_features
+    if _fusable(x_bf, identity_bf) and identity_bf.is_contiguous() and x_bf.is_contiguous():
+        from . import ops
+        t = torch.addmm(identity_bf.reshape(-1, C_out), x_bf.reshape(-1, x_bf.shape[-1]),
+                        linear.weight.t())
+        if post_norm is not None:
+            t = ops.bias_add_layernorm(t, linear.bias, None, post_norm.weight, post_norm.bias,
+                                       post_norm.eps)
+        elif linear.bias is not None:
+            ops.bias_act_rows_(t, linear.bias, None, relu=False)
+        return t.view(identity_bf.shape)
+    out = linear(x_bf) + identity_bf
+    return post_norm(out) if post_norm is not None else out
+
+
 class ConvModule(nn.Module):
     """conv -> norm -> act with mmcv's attribute names (``conv``, ``gn`` / ``bn``)."""
 
@@ -158,16 +183,30 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
+    supports_post_norm = True
+
+    def _fast_ok(self, x):
+        return (self.num_fcs == 2 and self.add_identity and isinstance(self.activate, nn.ReLU)
+                and _fusable(x) and x.dim() == 3)
+
+    def forward(self, x, identity=None, post_norm=None):
+        if identity is None:
+            identity = x
+        if self._fast_ok(x):
+            xb, ib = batch_first(x), batch_first(identity)
+            fc1, fc2 = self.layers[0][0], self.layers[1]
+            h = torch._addmm_activation(fc1.bias, xb.reshape(-1, xb.shape[-1]), fc1.weight.t())
+            out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm)
+            return seq_first_view(out)
         if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
             out = self.layers(x.transpose(0, 1)).transpose(0, 1)  # keep the token-major storage
         else:
             out = self.layers(x)
-        if not self.add_identity:
-            return out
-        if identity is None:
-            identity = x
-        return identity + out
+        if self.add_identity:
+            out = identity + out
+        if post_norm is not None:
+            out = layer_norm_any_layout(post_norm, out)
+        return out
 
 
 @MMCV_ATTENTION.register_module()
@@ -283,28 +322,46 @@ class BaseTransformerLayer(BaseModule):
             attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
         else:
             assert len(attn_masks) == self.num_attn
-        for layer in self.operation_order:
+        order = self.operation_order
+        skip_norm = False
+        for pos, layer in enumerate(order):
+            # post-norm layers: hand the following LayerNorm to a module that can fuse it with
+            # its own bias + residual epilogue (one pass instead of three)
+            fuse = {}
+            if (not self.pre_norm and pos + 1 < len(order) and order[pos + 1] == 'norm'
+                    and layer != 'norm'):
+                mod = self.ffns[ffn_index] if layer == 'ffn' else self.attentions[attn_index]
+                if getattr(mod, 'supports_post_norm', False) and query.is_cuda:
+                    fuse = dict(post_norm=self.norms[norm_index])
             if layer == 'self_attn':
                 temp_key = temp_value = query
                 query = self.attentions[attn_index](
                     query, temp_key, temp_value, identity if self.pre_norm else None,
                     query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=query_key_padding_mask, **kwargs)
+                    key_padding_mask=query_key_padding_mask, **fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
-                query = layer_norm_any_layout(self.norms[norm_index], query)
+                if skip_norm:
+                    skip_norm = False
+                else:
+                    query = layer_norm_any_layout(self.norms[norm_index], query)
                 norm_index += 1
+                continue
             elif layer == 'cross_attn':
                 query = self.attentions[attn_index](
                     query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                     query_time_pos=query_time_pos, key_pos=key_pos,
-                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask, **kwargs)
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                    **fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None, **fuse)
                 ffn_index += 1
+            skip_norm = bool(fuse)
+            if fuse:
+                identity = query
         return query
 
 

@@ -530,6 +530,129 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused row epilogues (HBM-bound glue around the library GEMMs / convolutions).
+//
+// bias_act_rows:      y[r, c] = act(x[r, c] + bias[c] (+ res[r, c])), in place allowed.
+//                     One pass (1-2 reads + 1 write) instead of the 2-3 passes of separate
+//                     bias / residual-add / ReLU kernels.  C % 4 == 0; rows are NHWC pixels
+//                     or tokens.
+// bias_add_layernorm: y[r, :] = LayerNorm(x[r, :] (+ bias) (+ res[r, :])) * gamma + beta.
+//                     One wave per row (C <= 1024, C % 4 == 0): float4 loads, two-pass
+//                     mean / variance in registers, wave64 xor-shuffle reductions.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_rows_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ res,
+                                                            float* __restrict__ y,
+                                                            const long long n4, const int c4,
+                                                            const int relu) {
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* b4 = reinterpret_cast<const float4*>(bias);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    if (bias) {
+      const float4 b = b4[i % c4];
+      v.x += b.x;
+      v.y += b.y;
+      v.z += b.z;
+      v.w += b.w;
+    }
+    if (res) {
+      const float4 r = r4[i];
+      v.x += r.x;
+      v.y += r.y;
+      v.z += r.z;
+      v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    y4[i] = v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int VPL>  // float4 vectors per lane: C = 256 * VPL
+__global__ __launch_bounds__(256) void bias_add_layernorm_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    const long long rows, const int C, const float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const int c4 = C >> 2;
+  const float inv_c = 1.f / (float)C;
+  for (long long r = wave; r < rows; r += nwaves) {
+    const float4* x4 = reinterpret_cast<const float4*>(x + r * C);
+    const float4* r4 = res ? reinterpret_cast<const float4*>(res + r * C) : nullptr;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int i = lane + k * 64;
+      if (i < c4) {
+        float4 t = x4[i];
+        if (bias) {
+          const float4 b = reinterpret_cast<const float4*>(bias)[i];
+          t.x += b.x;
+          t.y += b.y;
+          t.z += b.z;
+          t.w += b.w;
+        }
+        if (r4) {
+          const float4 q = r4[i];
+          t.x += q.x;
+          t.y += q.y;
+          t.z += q.z;
+          t.w += q.w;
+        }
+        v[k] = t;
+        s += (t.x + t.y) + (t.z + t.w);
+      } else {
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int i = lane + k * 64;
+      if (i < c4) {
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+    float4* y4 = reinterpret_cast<float4*>(y + r * C);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int i = lane + k * 64;
+      if (i < c4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+        const float4 b = reinterpret_cast<const float4*>(beta)[i];
+        float4 o;
+        o.x = (v[k].x - mean) * rstd * g.x + b.x;
+        o.y = (v[k].y - mean) * rstd * g.y + b.y;
+        o.z = (v[k].z - mean) * rstd * g.z + b.z;
+        o.w = (v[k].w - mean) * rstd * g.w + b.w;
+        y4[i] = o;
+      }
+    }
+  }
+}
+
 template <int MODE, int PPL, int WQ>
 int launch_fused(const FusedParams& p0, hipStream_t stream) {
   FusedParams p = p0;
@@ -716,6 +839,45 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
   const size_t shmem = (size_t)N * (2 * sizeof(int) + sizeof(float));
   hipLaunchKernelGGL(oks_nms_kernel, dim3(n_clips), dim3(256), shmem, st, kpts, scores, sigmas,
                      thresh, keep, order, N, K);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, float* y,
+                           long long rows, int C, int relu, void* stream) {
+  if (!x || !y) return fail(PAVE_E_ARG, "bias_act_rows: null pointer");
+  if (rows <= 0 || C <= 0 || (C & 3)) return fail(PAVE_E_ARG, "bias_act_rows: C must be a positive multiple of 4");
+  const long long n4 = rows * (C >> 2);
+  long long nb = (n4 + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(bias_act_rows_kernel, dim3((unsigned)nb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, bias, res, y, n4, C >> 2, relu);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* res,
+                                const float* gamma, const float* beta, float* y, long long rows,
+                                int C, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta) return fail(PAVE_E_ARG, "bias_add_layernorm: null pointer");
+  if (rows <= 0 || C <= 0 || (C & 3) || C > 1024)
+    return fail(PAVE_E_ARG, "bias_add_layernorm: C must be a multiple of 4, <= 1024");
+  long long nb = (rows + 3) / 4;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int vpl = ((C >> 2) + 63) / 64;
+#define PAVE_LN(V)                                                                              \
+  hipLaunchKernelGGL((bias_add_layernorm_kernel<V>), dim3((unsigned)nb), dim3(256), 0, st, x,   \
+                     bias, res, gamma, beta, y, rows, C, eps)
+  switch (vpl) {
+    case 1: PAVE_LN(1); break;
+    case 2: PAVE_LN(2); break;
+    case 3: PAVE_LN(3); break;
+    default: PAVE_LN(4); break;
+  }
+#undef PAVE_LN
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

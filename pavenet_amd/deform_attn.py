@@ -27,7 +27,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .bricks import BaseModule, batch_first, constant_init, seq_first_view, xavier_init
+from .bricks import (BaseModule, batch_first, constant_init, linear_residual_norm,
+                     seq_first_view, xavier_init)
 from .registry import ATTENTION, MMCV_ATTENTION
 
 
@@ -123,9 +124,11 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
     def _cat_sources(self):
         return [self.sampling_offsets], [self.attention_weights]
 
+    supports_post_norm = True
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, **kwargs):
+                level_start_index=None, post_norm=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -173,10 +176,9 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             out = ops.MultiScaleDeformableAttnFunction.apply(
                 v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
                 aw.contiguous(), self.im2col_step)
-        out = self.output_proj(out)
-        if not self.batch_first:
-            out = seq_first_view(out)
-        return out + identity
+        idt = identity if self.batch_first else batch_first(identity)
+        out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+        return out if self.batch_first else seq_first_view(out)
 
 
 # ---------------------------------------------------------------------------
@@ -229,9 +231,11 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         v = self.value_proj(value_bf)
         return v.view(v.shape[0], v.shape[1], self.num_heads, -1)
 
+    supports_post_norm = True
+
     def forward(self, query, key=None, value=None, residual=None, query_pos=None,
                 query_time_pos=None, key_padding_mask=None, reference_points=None,
-                spatial_shapes=None, level_start_index=None, **kwargs):
+                spatial_shapes=None, level_start_index=None, post_norm=None, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -268,10 +272,9 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         else:
             out = self._unfused(v, proj, reference_points, spatial_shapes, level_start_index, bs,
                                 num_query)
-        out = self.output_proj(out)
-        if not self.batch_first:
-            out = seq_first_view(out)
-        return out + inp_residual
+        idt = inp_residual if self.batch_first else batch_first(inp_residual)
+        out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+        return out if self.batch_first else seq_first_view(out)
 
     def _unfused(self, v, proj, reference_points, spatial_shapes, level_start_index, bs, nq):
         """Shapes the fused kernel does not cover: per-frame launches of the generic sampler
@@ -405,9 +408,11 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         B, T, S, _ = v.shape
         return v.view(B * T, S, self.num_heads, -1)
 
+    supports_post_norm = True
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 query_time_pos=None, key_padding_mask=None, reference_points=None,
-                spatial_shapes=None, level_start_index=None, **kwargs):
+                spatial_shapes=None, level_start_index=None, post_norm=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -458,10 +463,9 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         else:
             out = self._unfused(v, proj, ref, clip_index, spatial_shapes, level_start_index, N,
                                 num_query)
-        out = self.output_proj(out)
-        if not self.batch_first:
-            out = seq_first_view(out)
-        return out + identity
+        idt = identity if self.batch_first else batch_first(identity)
+        out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+        return out if self.batch_first else seq_first_view(out)
 
     def _unfused(self, v, proj, ref, clip_index, spatial_shapes, level_start_index, N, nq):
         T, M, L, P = self.num_frames, self.num_heads, self.num_levels, self.num_points

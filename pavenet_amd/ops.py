@@ -226,3 +226,46 @@ def oks_nms(kpts, scores, sigmas, thresh):
                                   K, _stream_ptr())
     native.check(st, 'oks_nms')
     return keep, order
+
+
+def bias_act_rows_(x, bias=None, res=None, relu=True):
+    """In place: x[r, c] = act(x[r, c] + bias[c] + res[r, c]) over the last (channel) dim.
+    `x` must be dense with channels innermost (token matrix, or an NHWC / channels_last map)."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32, 'bias_act_rows_: fp32 device tensor')
+    C = bias.numel() if bias is not None else x.shape[-1]
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        _require(x.shape[1] == C, 'bias_act_rows_: channel mismatch')
+        if res is not None:
+            _require(res.shape == x.shape and res.is_contiguous(memory_format=torch.channels_last),
+                     'bias_act_rows_: residual layout mismatch')
+    else:
+        _require(x.is_contiguous() and x.shape[-1] == C, 'bias_act_rows_: channels must be innermost')
+        if res is not None:
+            _require(res.shape == x.shape and res.is_contiguous(), 'bias_act_rows_: residual layout')
+    rows = x.numel() // C
+    with torch.cuda.device(x.device), _Timed('bias_act_rows'):
+        st = lib.pave_bias_act_rows_f32(
+            x.data_ptr(), bias.data_ptr() if bias is not None else None,
+            res.data_ptr() if res is not None else None, x.data_ptr(), rows, C, int(bool(relu)),
+            _stream_ptr())
+    native.check(st, 'bias_act_rows')
+    return x
+
+
+def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5):
+    """LayerNorm(x + bias + res) over the last dim; x / res dense row-major [..., C]."""
+    lib = native.load()
+    _dev(x, 'x', torch.float32)
+    C = x.shape[-1]
+    if res is not None:
+        _require(res.shape == x.shape and res.is_contiguous() and res.dtype == torch.float32,
+                 'bias_add_layernorm: residual must match x')
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device), _Timed('bias_add_layernorm'):
+        st = lib.pave_bias_add_layernorm_f32(
+            x.data_ptr(), bias.data_ptr() if bias is not None else None,
+            res.data_ptr() if res is not None else None, gamma.data_ptr(), beta.data_ptr(),
+            out.data_ptr(), x.numel() // C, C, float(eps), _stream_ptr())
+    native.check(st, 'bias_add_layernorm')
+    return out

@@ -419,21 +419,25 @@ class VideoPoseTransformerMulFrames(Transformer):
             output_memory, output_proposals = self.gen_encoder_output_proposals(
                 now_frame_memory, now_frame_mask_flatten if has_padding else None, geom)
             enc_outputs_class = cls_branches[self.decoder.num_layers](output_memory)
-            enc_outputs_kpt_unact = kpt_branches[self.decoder.num_layers](output_memory)
-            enc_outputs_kpt_unact[..., 0::2] += output_proposals[..., 0:1]
-            enc_outputs_kpt_unact[..., 1::2] += output_proposals[..., 1:2]
-            enc_outputs_sigma_unact = sigma_branches[self.decoder.num_layers](output_memory)
             topk = self.two_stage_num_proposals
             topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
             forced = kwargs.pop('force_topk_proposals', None)
             if forced is not None:  # parity harness: follow the reference's selection
                 topk_proposals = forced
             self.last_topk_proposals = topk_proposals
-            topk_kpts_unact = torch.gather(
-                enc_outputs_kpt_unact, 1,
-                topk_proposals.unsqueeze(-1).repeat(1, 1, enc_outputs_kpt_unact.size(-1)))
+            # The reference runs the keypoint / sigma branches on all S tokens and gathers the
+            # top-k rows afterwards (OT:21372-21389); the branches are row-wise, so gathering
+            # first is identical and 74x less work (300 of 22 323 rows).  The all-token
+            # outputs only feed training losses.
             tgt = torch.gather(output_memory, 1,
                                topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
+            top_props = torch.gather(output_proposals, 1,
+                                     topk_proposals.unsqueeze(-1).repeat(1, 1, 2))
+            topk_kpts_unact = kpt_branches[self.decoder.num_layers](tgt)
+            topk_kpts_unact[..., 0::2] += top_props[..., 0:1]
+            topk_kpts_unact[..., 1::2] += top_props[..., 1:2]
+            enc_outputs_kpt_unact = topk_kpts_unact
+            enc_outputs_sigma_unact = sigma_branches[self.decoder.num_layers](tgt)
             reference_points = topk_kpts_unact.sigmoid().repeat(1, T, 1)
             init_reference_out = reference_points
             query_pos, query = torch.split(query_embed, c, dim=1)

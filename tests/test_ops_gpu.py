@@ -164,3 +164,35 @@ def test_full_size_linearity():
     exp = grid_expected(value, shapes, lsi, proj[idx], ref[:, idx], 1,
                         torch.zeros(len(idx), dtype=torch.long))
     np.testing.assert_allclose(a.cpu()[idx].numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('C', [256, 1024, 64, 260])
+def test_bias_add_layernorm_vs_torch(C):
+    from pavenet_amd.ops import bias_add_layernorm
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(37, 5, C, generator=g) * 3
+    res = torch.randn(37, 5, C, generator=g)
+    bias, gamma, beta = (torch.randn(C, generator=g) for _ in range(3))
+    exp = torch.nn.functional.layer_norm(x + bias + res, (C,), gamma, beta, 1e-5)
+    out = bias_add_layernorm(x.cuda(), bias.cuda(), res.cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+    out = bias_add_layernorm(x.cuda(), None, None, gamma.cuda(), beta.cuda(), 1e-5)
+    exp = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_bias_act_rows_vs_torch():
+    from pavenet_amd.ops import bias_act_rows_
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 64, 9, 11, generator=g)
+    res = torch.randn(3, 64, 9, 11, generator=g)
+    bias = torch.randn(64, generator=g)
+    exp = torch.relu(x + bias.view(1, -1, 1, 1) + res)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    rd = res.cuda().contiguous(memory_format=torch.channels_last)
+    out = bias_act_rows_(xd, bias.cuda(), rd, relu=True)
+    assert out.data_ptr() == xd.data_ptr()
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=0, atol=0)
+    t = torch.randn(50, 128, generator=g)
+    out = bias_act_rows_(t.cuda(), bias.repeat(2).cuda(), None, relu=False)
+    np.testing.assert_allclose(out.cpu().numpy(), (t + bias.repeat(2)).numpy(), rtol=0, atol=0)
