@@ -80,6 +80,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
     torch.cuda.set_device(local_rank)
+    # let MIOpen time its solvers per convolution shape once (during warm-up) instead of
+    # trusting the immediate-mode heuristic of a cold find-db
+    torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:

@@ -162,7 +162,7 @@ class ResNet(BaseModule):
         n, h, w = nhw
         return rows.view(n, h, w, rows.shape[-1]).permute(0, 3, 1, 2)  # channels_last 4-D
 
-    def _bottleneck_gemm(self, blk, x, f, name, bi):
+    def _bottleneck_gemm(self, blk, x, f, name, bi, inplace_identity=False):
         """Bottleneck with its two 1x1 convolutions as row GEMMs on the NHWC map (hipBLASLt,
         bias + ReLU / residual in the GEMM epilogue) and ONE fused bias+ReLU pass after each of
         the 3x3 convolution and the residual GEMM (pave_bias_act_rows_f32)."""
@@ -185,6 +185,9 @@ class ResNet(BaseModule):
             idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())          # both biases here
             out = torch.addmm(idt, yrows, w3.flatten(1).t())
             ops.bias_act_rows_(out, None, None, relu=True)
+        elif inplace_identity:
+            out = rows.addmm_(yrows, w3.flatten(1).t())                   # identity += y @ W3
+            ops.bias_act_rows_(out, b3, None, relu=True)
         else:
             out = torch.addmm(rows, yrows, w3.flatten(1).t())             # + identity in the GEMM
             ops.bias_act_rows_(out, b3, None, relu=True)
@@ -210,7 +213,9 @@ class ResNet(BaseModule):
         for i, name in enumerate(self.res_layers):
             for bi, blk in enumerate(getattr(self, name)):
                 if gemm_path and isinstance(blk, Bottleneck):
-                    x = self._bottleneck_gemm(blk, x, f, name, bi)
+                    # blocks after the first of a stage read a temporary (the previous
+                    # block's output, never a stage output): accumulate into it
+                    x = self._bottleneck_gemm(blk, x, f, name, bi, inplace_identity=bi > 0)
                     continue
                 identity = x
                 y = x

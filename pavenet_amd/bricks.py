@@ -103,7 +103,7 @@ def _fusable(*tensors):
     return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
-def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None):
+def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False):
     """(x @ W^T + b + identity) [-> LayerNorm], batch-first tensors [..., C].
 
     Device fp32: the residual rides the GEMM (beta = 1, C = identity) and bias + LayerNorm are
@@ -112,8 +112,12 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None):
     C_out = linear.out_features
     if _fusable(x_bf, identity_bf) and identity_bf.is_contiguous() and x_bf.is_contiguous():
         from . import ops
-        t = torch.addmm(identity_bf.reshape(-1, C_out), x_bf.reshape(-1, x_bf.shape[-1]),
-                        linear.weight.t())
+        idt2 = identity_bf.reshape(-1, C_out)
+        x2 = x_bf.reshape(-1, x_bf.shape[-1])
+        if inplace:  # caller guarantees nobody else reads identity: no copy of C into D
+            t = idt2.addmm_(x2, linear.weight.t())
+        else:
+            t = torch.addmm(idt2, x2, linear.weight.t())
         if post_norm is not None:
             t = ops.bias_add_layernorm(t, linear.bias, None, post_norm.weight, post_norm.bias,
                                        post_norm.eps)
@@ -189,14 +193,15 @@ class FFN(BaseModule):
         return (self.num_fcs == 2 and self.add_identity and isinstance(self.activate, nn.ReLU)
                 and _fusable(x) and x.dim() == 3)
 
-    def forward(self, x, identity=None, post_norm=None):
+    def forward(self, x, identity=None, post_norm=None, inplace_residual=False):
         if identity is None:
             identity = x
         if self._fast_ok(x):
             xb, ib = batch_first(x), batch_first(identity)
             fc1, fc2 = self.layers[0][0], self.layers[1]
             h = torch._addmm_activation(fc1.bias, xb.reshape(-1, xb.shape[-1]), fc1.weight.t())
-            out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm)
+            out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm,
+                                       inplace=inplace_residual)
             return seq_first_view(out)
         if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
             out = self.layers(x.transpose(0, 1)).transpose(0, 1)  # keep the token-major storage
@@ -357,6 +362,8 @@ class BaseTransformerLayer(BaseModule):
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
+                if kwargs.get('inplace_residual', False):
+                    fuse = dict(fuse, inplace_residual=True)
                 query = self.ffns[ffn_index](query, identity if self.pre_norm else None, **fuse)
                 ffn_index += 1
             skip_norm = bool(fuse)

@@ -177,7 +177,8 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                 v.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
                 aw.contiguous(), self.im2col_step)
         idt = identity if self.batch_first else batch_first(identity)
-        out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+        out = linear_residual_norm(out, self.output_proj, idt, post_norm,
+                                   inplace=kwargs.get('inplace_residual', False))
         return out if self.batch_first else seq_first_view(out)
 
 
