@@ -109,7 +109,7 @@ def main():
         packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1),
                             res['keep'].float()], dim=1)  # [B, N*5 + N*K*3 + N]
         if dist is not None:
-            out = torch.empty((world,) + tuple(packed.shape), device=dev)
+            out = torch.empty((world * packed.shape[0], packed.shape[1]), device=dev)
             dist.all_gather_into_tensor(out, packed)
             packed = out
         return packed.cpu()  # results on the host, as simple_test returns them

@@ -57,10 +57,13 @@ class _CatProj:
     def _cat_sources(self):
         raise NotImplementedError
 
-    def _cat_proj(self):
+    def _cat_proj(self, frames=None):
+        """frames: optional tuple of frame indices (frame-sharded multi-GPU: local frames)."""
         offs, logits = self._cat_sources()
+        if frames is not None:
+            offs, logits = [offs[t] for t in frames], [logits[t] for t in frames]
         srcs = [m.weight for m in offs + logits] + [m.bias for m in offs + logits]
-        key = tuple((p.data_ptr(), p._version) for p in srcs)
+        key = (frames,) + tuple((p.data_ptr(), p._version) for p in srcs)
         if getattr(self, '_cat_key', None) != key:
             with torch.no_grad():
                 self._cat_w = torch.cat([m.weight for m in offs + logits], 0).contiguous()
@@ -256,6 +259,13 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         else:
             vb = batch_first(value) if not self.batch_first else value
             v = self.project_value(vb, key_padding_mask)
+        shard = kwargs.get('frame_shard')
+        if shard is not None:
+            out = self._forward_sharded(q, v, reference_points, spatial_shapes,
+                                        level_start_index, shard)
+            idt = inp_residual if self.batch_first else batch_first(inp_residual)
+            out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+            return out if self.batch_first else seq_first_view(out)
         assert v.shape[0] == bs * T, 'value must hold num_frames slabs per clip'
         w, b = self._cat_proj()
         proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
@@ -276,6 +286,32 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         idt = inp_residual if self.batch_first else batch_first(inp_residual)
         out = linear_residual_norm(out, self.output_proj, idt, post_norm)
         return out if self.batch_first else seq_first_view(out)
+
+    def _forward_sharded(self, q, v, reference_points, spatial_shapes, level_start_index, shard):
+        """Frame-sharded multi-GPU: v holds only this rank's frames [bs*T_loc, S, 8, 32]; the
+        partial row + per-head (max, sum-exp) of the local frames are merged across ranks with
+        one all-gather (pavenet_amd/dist.py)."""
+        from . import dist as pdist
+        T, L, K = self.num_frames, self.num_levels, self.num_points
+        bs, num_query, _ = q.shape
+        Tl = shard.n_local
+        assert _fused_ok(self, q, v) and L <= 4 and K <= 24, 'sharded path needs the fused kernel'
+        if Tl > 0:
+            assert v.shape[0] == bs * Tl
+            w, b = self._cat_proj(frames=tuple(shard.local))
+            proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+            ref = reference_points.view(bs, T, num_query, L, 2 * K)[:, shard.local].reshape(
+                bs, Tl * num_query, L, 2 * K).contiguous()
+            row, smax, ssum = ops.deform_attn_pose_fused(
+                v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
+                proj, ref, T=Tl, n_clips=bs, num_query=num_query, num_keypoints=K,
+                return_stats=True)
+        else:
+            row = q.new_zeros(bs * num_query, self.embed_dims)
+            smax = q.new_full((bs * num_query, self.num_heads), float('-inf'))
+            ssum = q.new_zeros(bs * num_query, self.num_heads)
+        out = pdist.all_gather_merge(row, smax, ssum, group=shard.group)
+        return out.view(bs, num_query, self.embed_dims)
 
     def _unfused(self, v, proj, reference_points, spatial_shapes, level_start_index, bs, nq):
         """Shapes the fused kernel does not cover: per-frame launches of the generic sampler
@@ -425,9 +461,11 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         N, num_query, _ = q.shape
         clip_index = kwargs.get('memory_clip_index')
         projected = kwargs.get('value_projected')
+        shard = kwargs.get('frame_shard')
+        Tv = T if shard is None else max(shard.n_local, 1)  # frames present in `value`
         if projected is not None:
             v = projected
-            n_clips = v.shape[0] // T
+            n_clips = v.shape[0] // Tv
             if clip_index is None:
                 assert n_clips == 1 or n_clips == N
                 clip_index = torch.arange(N, device=q.device) if n_clips == N and N > 1 else \
@@ -445,12 +483,34 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
                 assert n in (1, N), 'value must carry one slab set per pose or per clip'
                 clip_index = torch.arange(N, device=q.device) if (n == N and N > 1) else \
                     torch.zeros(N, dtype=torch.long, device=q.device)
-            assert vb.shape[1] == T
+            assert vb.shape[1] == Tv
             v = self.project_value(vb, mask)
             n_clips = n
         if reference_points.shape[-1] != 2:
             raise ValueError('MulFrames joint attention is built for 2-d reference points '
                              f'(got last dim {reference_points.shape[-1]})')
+        if shard is not None:
+            from . import dist as pdist
+            Tl = shard.n_local
+            assert _fused_ok(self, q, v) and L == 4 and P == 4
+            if Tl > 0:
+                w, b = self._cat_proj(frames=tuple(shard.local))
+                proj = F.linear(q.reshape(N * num_query, self.embed_dims), w, b)
+                ref = reference_points.reshape(T, N * num_query, L, 2)[shard.local].contiguous()
+                unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
+                row, smax, ssum = ops.deform_attn_grid_fused(
+                    v if v.is_contiguous() else v.contiguous(), spatial_shapes,
+                    level_start_index, proj, ref, T=Tl, n_clips=v.shape[0] // Tl,
+                    units_per_clip=num_query, unit_clip=unit_clip, return_stats=True)
+            else:
+                row = q.new_zeros(N * num_query, self.embed_dims)
+                smax = q.new_full((N * num_query, M), float('-inf'))
+                ssum = q.new_zeros(N * num_query, M)
+            out = pdist.all_gather_merge(row, smax, ssum, group=shard.group)
+            out = out.view(N, num_query, self.embed_dims)
+            idt = identity if self.batch_first else batch_first(identity)
+            out = linear_residual_norm(out, self.output_proj, idt, post_norm)
+            return out if self.batch_first else seq_first_view(out)
         w, b = self._cat_proj()
         proj = F.linear(q.reshape(N * num_query, self.embed_dims), w, b)
         ref = reference_points.reshape(T, N * num_query, L, 2)

@@ -57,7 +57,10 @@ class VideoPoseV1(BaseModule):
     @torch.no_grad()
     def forward_device(self, img, img_metas, rescale=False, **head_kwargs):
         """img [B, T, 3, H, W] on the device; img_metas: one dict per clip.  Returns the
-        head's fixed-shape device result dict (see VideoPoseHeadMulFrames.get_bboxes)."""
+        head's fixed-shape device result dict (see VideoPoseHeadMulFrames.get_bboxes).
+
+        Frame-sharded multi-GPU: pass ``frame_shard=FrameShard(T, rank, world)`` and only the
+        rank's frames, img [B, T_loc, 3, H, W] (frames t with t % world == rank, in order)."""
         feat = self.extract_feat(img)
         outs = self.bbox_head(feat, img_metas, **head_kwargs)
         return self.bbox_head.get_bboxes(outs, img_metas, rescale=rescale)

@@ -205,11 +205,11 @@ class VideoPoseHeadMulFrames(BaseModule):
         return [getattr(self, fp + suffix) for fp in self.frame_prefixes]
 
     # HEAD:429-445 ----------------------------------------------------------
-    def make_masks(self, mlvl_feats, img_metas):
+    def make_masks(self, mlvl_feats, img_metas, frames_per_clip=None):
         """Padding masks + sine encodings per level.  When no clip is padded they are built
         once for a single frame (they are identical for every frame) and broadcast."""
         n = mlvl_feats[0].size(0)
-        T = self.num_frames
+        T = frames_per_clip or self.num_frames
         H, W = img_metas[0]['batch_input_shape']
         shapes = [tuple(int(v) for v in img_metas[i // T]['img_shape'][:2]) for i in range(n)]
         has_padding = any(s != (H, W) for s in shapes)
@@ -237,7 +237,9 @@ class VideoPoseHeadMulFrames(BaseModule):
     def forward(self, mlvl_feats, img_metas, **tr_kwargs):
         T, Q = self.num_frames, self.num_query
         c = T // 2
-        mlvl_masks, mlvl_pos, has_padding = self.make_masks(mlvl_feats, img_metas)
+        shard = tr_kwargs.get('frame_shard')
+        mlvl_masks, mlvl_pos, has_padding = self.make_masks(
+            mlvl_feats, img_metas, shard.n_local if shard is not None else None)
         hs, init_reference, inter_references, enc_outputs_class, enc_outputs_kpt, \
             enc_outputs_sigma, hm_proto, memory = self.transformer(
                 mlvl_feats, mlvl_masks, self.query_embedding.weight, mlvl_pos,
@@ -275,10 +277,12 @@ class VideoPoseHeadMulFrames(BaseModule):
                     enc_cls_scores=enc_outputs_class, enc_kpt_preds=enc_outputs_kpt.sigmoid(),
                     enc_sigma_preds=enc_outputs_sigma.sigmoid(), memory=memory,
                     mlvl_masks=mlvl_masks, has_padding=has_padding, aux_poses=aux_poses,
+                    frame_shard=shard,
                     hs=hs, init_reference=init_reference, inter_references=inter_references)
 
     # HEAD:569-674 (inference branch) ----------------------------------------
-    def forward_refine(self, memory, mlvl_masks, frame_poses, img_inds, has_padding=True):
+    def forward_refine(self, memory, mlvl_masks, frame_poses, img_inds, has_padding=True,
+                       frame_shard=None):
         """frame_poses: list of T tensors [Ntot, 2K] (centre = selected kpt preds).
         Returns (kpts [Ntot, K, 2] normalised, score [Ntot, K, 1], sigma [Ntot, K, 2]) of the last
         refine layer plus all intermediates."""
@@ -286,10 +290,12 @@ class VideoPoseHeadMulFrames(BaseModule):
         c = T // 2
         pos_kpt_preds = torch.cat(frame_poses, dim=0)  # frame-major, HEAD:610
         S = memory.size(0)
-        mem4 = memory.reshape(S, -1, T, memory.size(-1))  # [S, B, T, C] view
+        Tl = T if frame_shard is None else frame_shard.n_local
+        mem4 = memory.reshape(S, -1, Tl, memory.size(-1))  # [S, B, T(_loc), C] view
         hs, init_reference, inter_references = self.transformer.forward_refine(
             mlvl_masks, mem4, pos_kpt_preds.detach(), img_inds,
-            frame_kpt_branches=self._branches('refine_kpt_branches'), has_padding=has_padding)
+            frame_kpt_branches=self._branches('refine_kpt_branches'), has_padding=has_padding,
+            frame_shard=frame_shard)
         hs = hs.permute(0, 2, 1, 3)
         outs_kpt, outs_sigma, outs_score = [], [], []
         for lvl in range(hs.shape[0]):
@@ -347,7 +353,7 @@ class VideoPoseHeadMulFrames(BaseModule):
         img_inds = torch.arange(B, device=cls_scores.device).repeat_interleave(N)
         r_kpts, r_scores, r_sigmas, r_hs = self.forward_refine(
             outs['memory'], outs['mlvl_masks'], frame_poses, img_inds,
-            has_padding=outs['has_padding'])
+            has_padding=outs['has_padding'], frame_shard=outs.get('frame_shard'))
         det_kpts = r_kpts[-1].view(B, N, K, 2)
         det_sigmas = r_sigmas[-1].view(B, N, K, 2)
         if taps is not None:

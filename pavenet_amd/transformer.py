@@ -374,9 +374,13 @@ class VideoPoseTransformerMulFrames(Transformer):
 
     # -- a4: forward (OT:21218-21456) ----------------------------------------
     def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, cls_branches=None,
-                sigma_branches=None, has_padding=True, **kwargs):
+                sigma_branches=None, has_padding=True, frame_shard=None, **kwargs):
+        """frame_shard (pavenet_amd.dist.FrameShard): mlvl_feats hold only this rank's frames
+        ([B*T_loc, C, h, w]); the encoder runs on them, the centre-frame proposals are broadcast
+        from their owner, and the T-frame attentions merge per-rank partial rows."""
         assert self.as_two_stage or query_embed is not None
         T = self.num_frames
+        Tl = T if frame_shard is None else frame_shard.n_local
         branches = self._frame_branch_lists(kwargs, 'kpt_branches')
         kpt_branches = branches[T // 2] if branches is not None else None
         dev = mlvl_feats[0].device
@@ -414,10 +418,16 @@ class VideoPoseTransformerMulFrames(Transformer):
             level_start_index=level_start_index, valid_ratios=valid_ratios, **extra)
         memory = batch_first(memory)                                   # [B*T, S, C]
         c = memory.shape[-1]
-        ctr = slice(T // 2, None, T)
+        n_clips = bs // Tl
+        if frame_shard is None:
+            ctr = slice(T // 2, None, T)
+        elif frame_shard.owns_center():
+            ctr = slice(frame_shard.local_index_of_center(), None, Tl)
+        else:
+            ctr = slice(0, None, Tl)  # stand-in rows; the owner's proposals are broadcast below
         now_frame_memory = memory[ctr]
         now_frame_mask_flatten = mask_flatten[ctr] if mask_flatten.shape[0] == bs else mask_flatten
-        now_frame_valid_ratios = valid_ratios[ctr]
+        now_frame_valid_ratios = valid_ratios[ctr]  # equal for every frame of a clip
         if self.as_two_stage:
             output_memory, output_proposals = self.gen_encoder_output_proposals(
                 now_frame_memory, now_frame_mask_flatten if has_padding else None, geom)
@@ -441,11 +451,15 @@ class VideoPoseTransformerMulFrames(Transformer):
             topk_kpts_unact[..., 1::2] += top_props[..., 1:2]
             enc_outputs_kpt_unact = topk_kpts_unact
             enc_outputs_sigma_unact = sigma_branches[self.decoder.num_layers](tgt)
+            if frame_shard is not None:
+                from . import dist as pdist
+                for t_ in (tgt, topk_kpts_unact, enc_outputs_sigma_unact):
+                    pdist.broadcast_from(t_, frame_shard.center_owner, frame_shard.group)
             reference_points = topk_kpts_unact.sigmoid().repeat(1, T, 1)
             init_reference_out = reference_points
             query_pos, query = torch.split(query_embed, c, dim=1)
-            query_pos = query_pos.unsqueeze(0).expand(bs // T, -1, -1)
-            query = query.unsqueeze(0).expand(bs // T, -1, -1)
+            query_pos = query_pos.unsqueeze(0).expand(n_clips, -1, -1)
+            query = query.unsqueeze(0).expand(n_clips, -1, -1)
             query = tgt + query
         else:
             query_pos, query = torch.split(query_embed, c, dim=1)
@@ -457,6 +471,8 @@ class VideoPoseTransformerMulFrames(Transformer):
         dec_kwargs = {}
         if branches is not None:
             dec_kwargs['frame_kpt_branches'] = branches
+        if frame_shard is not None:
+            dec_kwargs['frame_shard'] = frame_shard
         if self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
                 for l in self.decoder.layers):
@@ -476,10 +492,12 @@ class VideoPoseTransformerMulFrames(Transformer):
 
     # -- a9: forward_refine (OT:21458-21536) ---------------------------------
     def forward_refine(self, mlvl_masks, memory, reference_points_pose, img_inds,
-                       has_padding=True, **kwargs):
+                       has_padding=True, frame_shard=None, **kwargs):
         """memory [S, B, T, C] (view of [B, T, S, C]); reference_points_pose [T*N, 2K]
-        frame-major; img_inds [N] clip index of each pose."""
+        frame-major; img_inds [N] clip index of each pose.  With frame_shard, memory and masks
+        hold only the local frames ([S, B, T_loc, C])."""
         T = self.num_frames
+        Tl = T if frame_shard is None else frame_shard.n_local
         branches = self._frame_branch_lists(kwargs, 'kpt_branches')
         dev = memory.device
         geom = self.geometry([m.shape[-2:] for m in mlvl_masks], dev)
@@ -487,20 +505,25 @@ class VideoPoseTransformerMulFrames(Transformer):
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
         B = memory.shape[1]
-        if valid_ratios.shape[0] != B * T:
-            valid_ratios = valid_ratios.expand(B * T, -1, -1)
-            mask_flatten = mask_flatten.expand(B * T, -1)
+        if valid_ratios.shape[0] != B * Tl:
+            valid_ratios = valid_ratios.expand(B * Tl, -1, -1)
+            mask_flatten = mask_flatten.expand(B * Tl, -1)
         rq = self.refine_query_embedding.weight
         query_pos, query = torch.split(rq, rq.size(1) // 2, dim=1)
         pos_num = reference_points_pose.size(0) // T
         query_pos = query_pos.unsqueeze(0).expand(pos_num, -1, -1)
         query = query.unsqueeze(0).expand(pos_num, -1, -1)
         reference_points = reference_points_pose.reshape(-1, reference_points_pose.size(1) // 2, 2)
-        mask_bt = mask_flatten.reshape(-1, T, mask_flatten.size(-1))          # [B, T, S]
-        vr = valid_ratios.reshape(-1, T, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
+        mask_bt = mask_flatten.reshape(-1, Tl, mask_flatten.size(-1))         # [B, T_loc, S]
+        vr = valid_ratios.reshape(-1, Tl, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
+        if frame_shard is not None:
+            # every frame of a clip has the same valid ratios: rebuild the [N, T, L, 2] table
+            vr = vr[:, :1].expand(-1, T, -1, -1)
         dec_kwargs = {}
         if branches is not None:
             dec_kwargs['frame_reg_branches'] = branches
+        if frame_shard is not None:
+            dec_kwargs['frame_shard'] = frame_shard
         mem_bt = memory.permute(1, 2, 0, 3)                                   # [B, T, S, C]
         attn_mask = mask_bt if has_padding else None
         if self.hoist_value_proj and all(

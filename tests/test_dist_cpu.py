@@ -1,0 +1,99 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the N > 1 host logic: clip-parallel result
+exchange and the exact merge of frame-sharded partial softmax rows."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partial(logits, vals, frames):
+    """Reference partial attention of a frame subset: (row normalised by its own sum, max, sum).
+    logits [U, T, H, P], vals [U, T, H, P, D]."""
+    lg = logits[:, frames].permute(0, 2, 1, 3).reshape(logits.shape[0], logits.shape[2], -1)
+    v = vals[:, frames].permute(0, 2, 1, 3, 4).reshape(lg.shape[0], lg.shape[1], lg.shape[2], -1)
+    m = lg.max(-1)[0]
+    e = torch.exp(lg - m[..., None])
+    s = e.sum(-1)
+    row = (e[..., None] * v).sum(2) / s[..., None]
+    return row.flatten(1), m, s
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pavenet_amd import dist as pd
+        # --- clip-parallel exchange
+        B, N, K = 2, 5, 15
+        g = torch.Generator().manual_seed(100 + rank)
+        res = dict(bboxes=torch.randn(B, N, 5, generator=g), kpts=torch.randn(B, N, K, 3, generator=g),
+                   keep=(torch.rand(B, N, generator=g) > 0.5).int())
+        allr = pd.all_gather_results(res)
+        assert allr.shape == (world, B, N * (5 + 3 * K + 1))
+        mine = pd.unpack_results(allr[rank], N, K)
+        assert torch.equal(mine['bboxes'], res['bboxes']) and torch.equal(mine['kpts'], res['kpts'])
+        assert torch.equal(mine['keep'], res['keep'].bool())
+        for r in range(world):  # every rank sees every rank's rows
+            gr = torch.Generator().manual_seed(100 + r)
+            assert torch.equal(pd.unpack_results(allr[r], N, K)['bboxes'],
+                               torch.randn(B, N, 5, generator=gr))
+        # --- frame-sharded softmax merge, T = 5 frames over 2 ranks (rank 1 owns frames 1, 3)
+        T, U, H, P, D = 5, 7, 8, 16, 32
+        gs = torch.Generator().manual_seed(7)  # same data on both ranks
+        logits = torch.randn(U, T, H, P, generator=gs) * 4
+        logits[0, 1] += 60.0   # one frame dominates: exercises the max rescale
+        vals = torch.randn(U, T, H, P, D, generator=gs)
+        shard = pd.FrameShard(T, rank, world)
+        assert shard.local == [t for t in range(T) if t % world == rank]
+        assert shard.center == 2 and shard.center_owner == 0
+        row, m, s = _partial(logits, vals, shard.local)
+        merged = pd.all_gather_merge(row, m, s)
+        full, _, _ = _partial(logits, vals, list(range(T)))
+        np.testing.assert_allclose(merged.numpy(), full.numpy(), rtol=1e-5, atol=1e-5)
+        # a rank with no frames (world > T) drops out of the merge
+        empty_row = torch.zeros(U, H * D)
+        rows = torch.stack([full, empty_row])
+        mm = torch.stack([m, torch.full_like(m, float('-inf'))])
+        ss = torch.stack([s, torch.zeros_like(s)])
+        np.testing.assert_allclose(pd.merge_softmax_partials(rows, mm, ss).numpy(), full.numpy(),
+                                   rtol=1e-6)
+        # broadcast of the centre-frame proposals
+        t = torch.full((3,), float(rank))
+        pd.broadcast_from(t, shard.center_owner)
+        assert t.tolist() == [0.0, 0.0, 0.0]
+        open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_merge_is_exact_for_any_split():
+    from pavenet_amd import dist as pd
+    T, U, H, P, D = 7, 4, 8, 15, 32
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(U, T, H, P, generator=g) * 3
+    vals = torch.randn(U, T, H, P, D, generator=g)
+    full, _, _ = _partial(logits, vals, list(range(T)))
+    for G in (2, 3, 4, 7):
+        parts = [_partial(logits, vals, pd.FrameShard(T, r, G).local) for r in range(G)]
+        merged = pd.merge_softmax_partials(torch.stack([p[0] for p in parts]),
+                                           torch.stack([p[1] for p in parts]),
+                                           torch.stack([p[2] for p in parts]))
+        np.testing.assert_allclose(merged.numpy(), full.numpy(), rtol=1e-5, atol=1e-5)

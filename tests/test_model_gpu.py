@@ -192,3 +192,24 @@ def test_oks_nms_kernel_vs_oracle():
         assert sorted(np.nonzero(keep[b].cpu().numpy())[0].tolist()) == sorted(int(i) for i in exp)
         assert order[b].cpu().tolist() == list(range(N))
     assert 0 < int(keep.sum()) < B * N
+
+
+@pytest.mark.parametrize('T', [3, 5])
+def test_frame_sharded_two_ranks(T):
+    """Frame-sharded path (SURVEY 8e ii) with REAL collectives: two processes on this box's one
+    GPU, frames t % 2 == rank each, partial-softmax rows merged by all-gather; must equal the
+    un-sharded model."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'tests', 'sharded_worker.py'), str(T)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'sharded == unsharded: True' in r.stdout
