@@ -241,6 +241,60 @@ def gen_e2e(which=None):
               cls_last=taps['cls_all'][-1], score_topk=score_topk,
               det_bboxes=det_bboxes, det_labels=det_labels, det_kpts=det_kpts, **extra)
 
+PETR_E2E = {
+    'e2e_petr_r50': 'configs/petr/petr_r50_16x2_100e_coco.py',
+    'e2e_vedpose_r50': 'configs/vedpose/single_frame_posetrack_resnet50_inference.py',
+}
+
+
+def gen_petr(which=None):
+    """Single-image PETR (BASELINE configs[0]) and the vedpose single-frame head."""
+    for name, cfg_path in PETR_E2E.items():
+        if which and which != name:
+            continue
+
+        def small(cfg):
+            cfg.model['test_cfg'] = dict(max_per_img=20)
+
+        model, cfg = ref_shim.build_reference_model(cfg_path, cfg_overrides=small)
+        keys = _load_seeded(model)
+        H, W = 128, 160
+        img = _t(seeded_array(f'{name}.img', (1, 3, H, W)))
+        meta = [dict(batch_input_shape=(H, W), img_shape=(120, 150, 3),
+                     scale_factor=(1., 1., 1., 1.))]
+        taps = {}
+        tr = model.bbox_head.transformer
+
+        def enc_hook(mod, args, kwargs, out):
+            taps['memory'] = out.permute(1, 0, 2).detach().clone()
+
+        def dec_hook(mod, args, kwargs, out):
+            taps['hs'], taps['inter_references'] = out[0].detach().clone(), out[1].detach().clone()
+
+        head_forward = model.bbox_head.forward
+
+        def tapped_forward(*a, **k):
+            out = head_forward(*a, **k)
+            taps['cls_all'] = out[0].detach().clone()
+            return out
+
+        model.bbox_head.forward = tapped_forward
+        hs = [tr.encoder.register_forward_hook(enc_hook, with_kwargs=True),
+              tr.decoder.register_forward_hook(dec_hook, with_kwargs=True)]
+        with torch.no_grad():
+            feats = model.extract_feat(img)
+            res = model.bbox_head.simple_test(feats, meta, rescale=False)
+        for h in hs:
+            h.remove()
+        det_bboxes, det_labels, det_kpts = res[0]
+        N = model.bbox_head.test_cfg['max_per_img']
+        score_topk = taps['cls_all'][-1][0].sigmoid().view(-1).topk(N)[1]
+        _save(name, keys=keys, img=img, img_shape=np.array([120, 150, 3]),
+              memory=taps['memory'], hs=taps['hs'], inter_references=taps['inter_references'],
+              cls_last=taps['cls_all'][-1], score_topk=score_topk, det_bboxes=det_bboxes,
+              det_labels=det_labels, det_kpts=det_kpts)
+
+
 if __name__ == '__main__':
     import logging
     logging.disable(logging.INFO)
@@ -251,3 +305,5 @@ if __name__ == '__main__':
         gen_modules()
     if what in ('e2e', 'all'):
         gen_e2e(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ('petr', 'all'):
+        gen_petr(sys.argv[2] if len(sys.argv) > 2 else None)

@@ -181,6 +181,7 @@ def ffn(sd, pre, x):
 # --------------------------------------------------------------------------
 def msda_module(sd, pre, query, query_pos, key_padding_mask, reference_points, shapes, lsi,
                 M=8, L=4, P=4, value=None):
+    """value=None: self-attention over `query` (encoder); else cross-attention (refine decoder)."""
     identity = query
     if value is None:
         value = query
@@ -727,3 +728,125 @@ def videopose_simple_test(sd, cfg, img, img_shape=None, rescale_factor=None, tap
     keep = oks_nms(det_kpts, scores, 0.45, sig)
     keep = torch.as_tensor(np.asarray(keep, dtype=np.int64))
     return det_bboxes[keep], det_labels[keep], det_kpts[keep]
+
+
+# --------------------------------------------------------------------------
+# a15 / a16: single-image PETR and the vedpose single-frame head
+#   PETRTransformer.forward / forward_refine  OT:4448-4693
+#   PetrTransformerDecoder                    OT:4148-4231
+#   DeformableDetrTransformerDecoder          MT:705-791
+#   PETRHead.forward / _get_bboxes_single     petr_head.py:213-300, 956-1037
+#   VedPoseHeadV2._get_bboxes_single          vedpose_head_v2.py:1066-1180
+# --------------------------------------------------------------------------
+def petr_simple_test(sd, cfg, img, img_shape=None, taps=None):
+    """img [1, 3, H, W] -> (bboxes [N,5], labels [N], kpts [N,K,3]).  cfg: num_keypoints,
+    num_query, max_per_img, head in {'petr', 'vedpose'}."""
+    K, Q, N = cfg['num_keypoints'], cfg['num_query'], cfg.get('max_per_img', 100)
+    n_dec, n_ref = cfg.get('dec_layers', 3), cfg.get('refine_layers', 2)
+    vedpose = cfg.get('head', 'petr') == 'vedpose'
+    hpre, tpre = 'bbox_head', 'bbox_head.transformer'
+    H, W = img.shape[-2:]
+    if img_shape is None:
+        img_shape = (H, W, 3)
+    feats = channel_mapper(sd, 'neck', resnet_forward(sd, 'backbone', img, depth=cfg.get('depth', 50)))
+    masks, poss = make_masks_and_pos(feats, (H, W), img_shape)
+    feat_f, mask_f, pos_f, shapes, lsi, valid_ratios = flatten_levels(sd, tpre, feats, masks, poss)
+    reference_points = get_reference_points(shapes, valid_ratios)
+    memory = encoder_forward(sd, tpre + '.encoder', cfg.get('enc_layers', 6),
+                             feat_f.permute(1, 0, 2), pos_f.permute(1, 0, 2), mask_f,
+                             reference_points, shapes, lsi).permute(1, 0, 2)
+    bs, _, c = memory.shape
+    if taps is not None:
+        taps['memory'] = memory
+    output_memory, output_proposals = gen_encoder_output_proposals(sd, tpre, memory, mask_f, shapes)
+    enc_cls = linear(sd, f'{hpre}.cls_branches.{n_dec}', output_memory)
+    enc_kpt = kpt_branch(sd, f'{hpre}.kpt_branches.{n_dec}', output_memory)
+    enc_kpt[..., 0::2] += output_proposals[..., 0:1]
+    enc_kpt[..., 1::2] += output_proposals[..., 1:2]
+    topk_idx = torch.topk(enc_cls[..., 0], Q, dim=1)[1]
+    if taps is not None:
+        taps['topk_idx'] = topk_idx
+    topk_kpts = torch.gather(enc_kpt, 1, topk_idx.unsqueeze(-1).repeat(1, 1, enc_kpt.size(-1)))
+    reference_points = topk_kpts.sigmoid()
+    init_reference = reference_points
+    query_pos, query = torch.split(sd[hpre + '.query_embedding.weight'], c, dim=1)
+    query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1).permute(1, 0, 2)
+    out = query.unsqueeze(0).expand(bs, -1, -1).permute(1, 0, 2)  # no memory rows added (OT:4596)
+    value = memory.permute(1, 0, 2)
+    inter, inter_refs = [], []
+    for lid in range(n_dec):
+        lp = f'{tpre}.decoder.layers.{lid}'
+        ref_in = reference_points[:, :, None] * valid_ratios.repeat(1, 1, K)[:, None]
+        out = mha(sd, lp + '.attentions.0', out, query_pos)
+        out = layer_norm(sd, lp + '.norms.0', out)
+        out = pose_attn_single(sd, lp + '.attentions.1', out, value, query_pos, mask_f, ref_in,
+                               shapes, lsi, K=K)
+        out = layer_norm(sd, lp + '.norms.1', out)
+        out = ffn(sd, lp + '.ffns.0', out)
+        out = layer_norm(sd, lp + '.norms.2', out)
+        tmp = kpt_branch(sd, f'{hpre}.kpt_branches.{lid}', out.permute(1, 0, 2))
+        reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
+        inter.append(out)
+        inter_refs.append(reference_points)
+    hs = torch.stack(inter).permute(0, 2, 1, 3)
+    inter_refs = torch.stack(inter_refs)
+    lvl = n_dec - 1
+    reference = init_reference if lvl == 0 else inter_refs[lvl - 1]
+    cls = linear(sd, f'{hpre}.cls_branches.{lvl}', hs[lvl])
+    kpt = (kpt_branch(sd, f'{hpre}.kpt_branches.{lvl}', hs[lvl]) + inverse_sigmoid(reference)).sigmoid()
+    if taps is not None:
+        taps.update(hs=torch.stack(inter), inter_references=inter_refs, cls_last=cls)
+    cls_score = cls[0].sigmoid()
+    scores, indexs = cls_score.view(-1).topk(N)
+    if taps is not None:
+        taps['score_topk_idx'] = indexs
+    det_labels, bbox_index = indexs % 1, indexs // 1
+    kpt_pred = kpt[0][bbox_index]
+    # forward_refine OT:4638-4693 (memory replicated per pose)
+    img_inds = (torch.arange(N)[:, None] / Q).squeeze(1).to(torch.int64)
+    rq = sd[tpre + '.refine_query_embedding.weight']
+    rpos, rquery = torch.split(rq, rq.size(1) // 2, dim=1)
+    rpos = rpos.unsqueeze(0).expand(N, -1, -1).permute(1, 0, 2)
+    rout = rquery.unsqueeze(0).expand(N, -1, -1).permute(1, 0, 2)
+    rref = kpt_pred.reshape(N, kpt_pred.size(1) // 2, 2)
+    pos_memory = value[:, img_inds, :]
+    rmask = mask_f[img_inds, :]
+    rvr = valid_ratios[img_inds, ...]
+    rinit = rref
+    rinter, rrefs = [], []
+    for lid in range(n_ref):
+        lp = f'{tpre}.refine_decoder.layers.{lid}'
+        ref_in = rref[:, :, None] * rvr[:, None]
+        rout = mha(sd, lp + '.attentions.0', rout, rpos)
+        rout = layer_norm(sd, lp + '.norms.0', rout)
+        rout = msda_module(sd, lp + '.attentions.1', rout, rpos, rmask, ref_in, shapes, lsi,
+                           value=pos_memory)
+        rout = layer_norm(sd, lp + '.norms.1', rout)
+        rout = ffn(sd, lp + '.ffns.0', rout)
+        rout = layer_norm(sd, lp + '.norms.2', rout)
+        tmp = refine_kpt_branch(sd, f'{hpre}.refine_kpt_branches.{lid}', rout.permute(1, 0, 2))
+        rref = (tmp + inverse_sigmoid(rref)).sigmoid()  # MT:764-770 with 2-d references
+        rinter.append(rout)
+        rrefs.append(rref)
+    rhs = torch.stack(rinter).permute(0, 2, 1, 3)
+    rl = n_ref - 1
+    reference = inverse_sigmoid(rinit if rl == 0 else rrefs[rl - 1])
+    det_kpts = (refine_kpt_branch(sd, f'{hpre}.refine_kpt_branches.{rl}', rhs[rl]) + reference).sigmoid()
+    det_kpts[..., 0] = det_kpts[..., 0] * img_shape[1]
+    det_kpts[..., 1] = det_kpts[..., 1] * img_shape[0]
+    det_kpts[..., 0].clamp_(min=0, max=img_shape[1])
+    det_kpts[..., 1].clamp_(min=0, max=img_shape[0])
+    x1 = det_kpts[..., 0].min(dim=1, keepdim=True)[0]
+    y1 = det_kpts[..., 1].min(dim=1, keepdim=True)[0]
+    x2 = det_kpts[..., 0].max(dim=1, keepdim=True)[0]
+    y2 = det_kpts[..., 1].max(dim=1, keepdim=True)[0]
+    det_bboxes = torch.cat([x1, y1, x2, y2, scores.unsqueeze(1)], dim=1)
+    if vedpose:
+        sigma = sigma_branch(sd, f'{hpre}.refine_fc_sigma_branches.{rl}', rhs[rl]).sigmoid()
+        p = get_p(sigma)
+        det_kpts = (det_kpts * p**5) / (p**5 + 1e-10)
+        kscore = scores[:, None, None] * p
+    else:
+        kscore = det_kpts.new_ones(det_kpts[..., :1].shape)
+    det_kpts = torch.cat((det_kpts, kscore), dim=2)
+    return det_bboxes, det_labels, det_kpts

@@ -147,7 +147,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         v = self.value_proj(v)
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
-        v = v.view(bs, num_value, self.num_heads, -1)
+        v = v.view(v.shape[0], num_value, self.num_heads, -1)
         fused = (_fused_ok(self, q, v) and self.num_levels == 4 and self.num_points == 4
                  and reference_points.shape[-1] == 2)
         if fused:
@@ -156,9 +156,13 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             ref = reference_points.reshape(1, bs * num_query, self.num_levels, 2)
             if not ref.is_contiguous():
                 ref = ref.contiguous()
+            clip_index = kwargs.get('memory_clip_index')
+            unit_clip = None
+            if clip_index is not None:  # queries of pose n read the memory of image clip_index[n]
+                unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
             out = ops.deform_attn_grid_fused(
-                v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=bs,
-                units_per_clip=num_query, order=kwargs.get('unit_order'))
+                v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=v.shape[0],
+                units_per_clip=num_query, unit_clip=unit_clip, order=kwargs.get('unit_order'))
             out = out.view(bs, num_query, self.embed_dims)
         else:
             off = self.sampling_offsets(q).view(bs, num_query, self.num_heads, self.num_levels,
@@ -166,6 +170,8 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             aw = self.attention_weights(q).view(bs, num_query, self.num_heads,
                                                 self.num_levels * self.num_points).softmax(-1)
             aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+            if kwargs.get('memory_clip_index') is not None:
+                v = v[kwargs['memory_clip_index']]  # generic path: one slab per pose
             if reference_points.shape[-1] == 2:
                 norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
                 loc = reference_points[:, :, None, :, None, :] + \

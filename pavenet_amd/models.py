@@ -1,7 +1,8 @@
 """Importing this module registers every class of the PAVE-Net forward path under the
 reference's type names, and offers the re-stated model dicts (the reference's config files do
 not travel to the GPU box; the dicts below keep their type names and kwargs)."""
-from . import backbones, bricks, deform_attn, detectors, heads, necks, transformer  # noqa: F401
+from . import (backbones, bricks, deform_attn, detectors, heads, necks, petr,  # noqa: F401
+               transformer)
 from .registry import build_model  # noqa: F401
 
 
@@ -79,5 +80,48 @@ def videopose_r50_cfg(num_frames=3, num_keypoints=15, num_query=300, max_per_img
             loss_kpt_refine=dict(type='opera.RLELoss', loss_weight=1.0),
             loss_oks_refine=dict(type='opera.OKSLoss', num_keypoints=num_keypoints,
                                  loss_weight=0.0)),
+        train_cfg=None,
+        test_cfg=dict(max_per_img=max_per_img))
+
+
+def petr_r50_cfg(num_keypoints=17, num_query=300, max_per_img=100, head='opera.PETRHead',
+                 depth=50):
+    """Model dict equivalent to configs/petr/petr_r50_16x2_100e_coco.py:4-115 (PETRHead, K = 17)
+    and configs/vedpose/single_frame_posetrack_resnet50_inference.py (VedPoseHeadV2, K = 15)."""
+    K = num_keypoints
+    enc = lambda levels: dict(  # noqa: E731
+        type='mmcv.DetrTransformerEncoder', num_layers=6 if levels == 4 else 1,
+        transformerlayers=dict(
+            type='mmcv.BaseTransformerLayer',
+            attn_cfgs=dict(type='mmcv.MultiScaleDeformableAttention', embed_dims=256,
+                           num_levels=levels),
+            feedforward_channels=1024, ffn_dropout=0.1,
+            operation_order=('self_attn', 'norm', 'ffn', 'norm')))
+    return dict(
+        type='opera.PETR',
+        backbone=dict(type='mmdet.ResNet', depth=depth, num_stages=4, out_indices=(1, 2, 3),
+                      frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=False),
+                      norm_eval=True, style='pytorch'),
+        neck=dict(type='mmdet.ChannelMapper', in_channels=[512, 1024, 2048], kernel_size=1,
+                  out_channels=256, act_cfg=None, norm_cfg=dict(type='GN', num_groups=32),
+                  num_outs=4),
+        bbox_head=dict(
+            type=head, num_keypoints=K, num_query=num_query, num_classes=1, in_channels=2048,
+            sync_cls_avg_factor=True, with_kpt_refine=True, as_two_stage=True,
+            transformer=dict(
+                type='opera.PETRTransformer', num_keypoints=K, encoder=enc(4),
+                decoder=dict(type='opera.PetrTransformerDecoder', num_keypoints=K, num_layers=3,
+                             return_intermediate=True,
+                             transformerlayers=_decoder_layer(
+                                 'opera.MultiScaleDeformablePoseAttention', num_points=K)),
+                hm_encoder=enc(1),
+                refine_decoder=dict(type='mmcv.DeformableDetrTransformerDecoder', num_layers=2,
+                                    return_intermediate=True,
+                                    transformerlayers=_decoder_layer(
+                                        'mmcv.MultiScaleDeformableAttention'))),
+            positional_encoding=dict(type='mmcv.SinePositionalEncoding', num_feats=128,
+                                     normalize=True, offset=-0.5),
+            loss_cls=dict(type='mmdet.FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
+                          loss_weight=2.0)),
         train_cfg=None,
         test_cfg=dict(max_per_img=max_per_img))

@@ -64,6 +64,15 @@ def test_state_dict_contract(golden_dir):
         assert mine == ref[name]
 
 
+def test_state_dict_contract_petr(golden_dir):
+    from pavenet_amd.models import build_model, petr_r50_cfg
+    ref = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))
+    for name, kw in (('petr_r50', dict(num_keypoints=17, head='opera.PETRHead')),
+                     ('vedpose_r50', dict(num_keypoints=15, head='opera.VedPoseHeadV2'))):
+        m = build_model(petr_r50_cfg(**kw))
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref[name]
+
+
 def test_generalised_frame_prefixes():
     from pavenet_amd.deform_attn import frame_prefixes
     assert frame_prefixes(1) == ['']
@@ -132,7 +141,10 @@ def test_reference_config_files_build(golden_dir):
     from pavenet_amd.models import build_model
     for path, name in ((ref, 'videopose_r50_t3'),
                        ('/root/reference/configs/videopose/2025-2-7/'
-                        '2025_2_7_res50_num_frames_5_posetrack17.py', 'videopose_r50_t5')):
+                        '2025_2_7_res50_num_frames_5_posetrack17.py', 'videopose_r50_t5'),
+                       ('/root/reference/configs/petr/petr_r50_16x2_100e_coco.py', 'petr_r50'),
+                       ('/root/reference/configs/vedpose/'
+                        'single_frame_posetrack_resnet50_inference.py', 'vedpose_r50')):
         cfg = Config.fromfile(path)
         model = cfg.model.to_dict()
         model.pop('init_cfg', None)

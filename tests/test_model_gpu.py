@@ -213,3 +213,45 @@ def test_frame_sharded_two_ranks(T):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'sharded == unsharded: True' in r.stdout
+
+
+@pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'opera.PETRHead'),
+                                         ('e2e_vedpose_r50', 15, 'opera.VedPoseHeadV2')])
+def test_petr_end_to_end_vs_reference_golden(golden_dir, name, K, head):
+    """BASELINE configs[0] (single-image PETR R-50) and the configs/vedpose single-frame head
+    against the reference's own outputs."""
+    from pavenet_amd.models import build_model, petr_r50_cfg
+    g = _g(golden_dir, name)
+    N = int(g['score_topk'].shape[0])
+    m = _seed(build_model(petr_r50_cfg(num_keypoints=K, max_per_img=N, head=head)), g).cuda().eval()
+    hs_, ws_ = int(g['img_shape'][0]), int(g['img_shape'][1])
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(hs_, ws_, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    with torch.no_grad():
+        feat = m.extract_feat(_t(g['img']).cuda())
+        outs = m.bbox_head(feat, metas)
+        np.testing.assert_allclose(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
+                                   rtol=2e-3, atol=5e-4)
+        np.testing.assert_allclose(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
+                                   rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(outs['inter_references'].cpu().numpy(), g['inter_references'],
+                                   rtol=1e-3, atol=2e-4)
+        res = m.bbox_head.get_bboxes(outs, metas)
+        (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
+    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+
+
+def test_petr_batched_vs_oracle():
+    from pavenet_amd.models import build_model, petr_r50_cfg
+    m = _seed(build_model(petr_r50_cfg(num_keypoints=17, max_per_img=10))).cuda().eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    img = _t(seeded_array('petr.batched', (2, 3, 128, 160)))
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(128, 160, 3),
+                  scale_factor=(1., 1., 1., 1.)) for _ in range(2)]
+    got = m.bbox_head.results_to_list(m.forward_device(img.cuda(), metas))
+    for b in range(2):
+        with torch.no_grad():
+            eb, el, ek = R.petr_simple_test(sd, dict(num_keypoints=17, num_query=300,
+                                                     max_per_img=10), img[b:b + 1])
+        np.testing.assert_allclose(got[b][2].cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)

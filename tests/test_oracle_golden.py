@@ -131,3 +131,23 @@ def test_end_to_end(golden_dir, T):
     assert kpts.shape == g['det_kpts'].shape
     np.testing.assert_allclose(kpts.numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)  # pixels
     np.testing.assert_allclose(bboxes.numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'petr'), ('e2e_vedpose_r50', 15, 'vedpose')])
+def test_end_to_end_petr(golden_dir, name, K, head):
+    """Single-image PETR (BASELINE configs[0]) and the vedpose single-frame head."""
+    g = _load(golden_dir, name)
+    sd = _sd(g)
+    N = int(g['score_topk'].shape[0])
+    cfg = dict(num_keypoints=K, num_query=300, max_per_img=N, head=head)
+    taps = {}
+    with torch.no_grad():
+        bboxes, labels, kpts = R.petr_simple_test(
+            sd, cfg, _t(g['img']), img_shape=tuple(int(v) for v in g['img_shape']), taps=taps)
+    np.testing.assert_allclose(taps['memory'].numpy(), g['memory'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(taps['hs'].numpy(), g['hs'], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(taps['inter_references'].numpy(), g['inter_references'],
+                               rtol=1e-3, atol=1e-4)
+    assert taps['score_topk_idx'].tolist() == g['score_topk'].tolist()
+    np.testing.assert_allclose(kpts.numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(bboxes.numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
