@@ -132,6 +132,23 @@ int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* 
                                 const float* gamma, const float* beta, float* y, long long rows,
                                 int C, float eps, void* stream);
 
+/*
+ * Encoder deformable attention ([R2], T = 1, L = 4, P = 4) with an LDS-staged value window for
+ * the level-0 queries (75 % of the tokens at 800x1344) and the direct-gather kernel for the
+ * listed remaining units.  Same inputs / outputs / results as
+ * pave_deform_attn_grid_fused_f32 with T = 1; ref is [n_frames*S, 4, 2].
+ *   levels_hw   HOST array of 8 ints (h0, w0, ..., h3, w3): host copy of spatial_shapes, so the
+ *               kernel prologue has no dependent loads
+ *   grid_ref    1 if every reference point is the query's own pixel centre on all levels (no
+ *               padded frame): window origins are then computed without loading ref
+ *   rest_order  [n_rest] int32 unit indices (frame*S + token) of all tokens of levels 1..3
+ */
+int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start, const float* proj,
+                                    const float* ref, const int32_t* rest_order, float* out,
+                                    int n_frames, int S, const int* levels_hw, int grid_ref,
+                                    int n_rest, int proj_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,12 +157,19 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             if not ref.is_contiguous():
                 ref = ref.contiguous()
             clip_index = kwargs.get('memory_clip_index')
+            plan = kwargs.get('window_plan')
             unit_clip = None
             if clip_index is not None:  # queries of pose n read the memory of image clip_index[n]
                 unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
-            out = ops.deform_attn_grid_fused(
-                v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=v.shape[0],
-                units_per_clip=num_query, unit_clip=unit_clip, order=kwargs.get('unit_order'))
+            if plan is not None and clip_index is None and num_query == num_value:
+                out = ops.deform_attn_enc_window(v, spatial_shapes, level_start_index, proj, ref,
+                                                 levels_hw=plan[0], rest_order=plan[1],
+                                                 grid_ref=plan[2])
+            else:
+                out = ops.deform_attn_grid_fused(
+                    v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=v.shape[0],
+                    units_per_clip=num_query, unit_clip=unit_clip,
+                    order=kwargs.get('unit_order'))
             out = out.view(bs, num_query, self.embed_dims)
         else:
             off = self.sampling_offsets(q).view(bs, num_query, self.num_heads, self.num_levels,

@@ -32,7 +32,17 @@ def encoder_unit_order(levels, n_frames, mode='band'):
         xs.append(np.tile(np.arange(w), h))
         lv.append(np.full(h * w, l))
     ys, lv, xs = np.concatenate(ys), np.concatenate(lv), np.concatenate(xs)
-    tok = np.lexsort((xs, lv, ys))  # primary key: y centre
+    if mode == 'quad':
+        # 2x2 pixel patches are consecutive, so the 4 waves of a workgroup gather overlapping
+        # corner rows (a 2x2 patch with equal offsets touches 3x3 rows instead of 4x4)
+        rows = np.concatenate([np.repeat(np.arange(int(h)), int(w)) for h, w in levels])
+        py, qy = rows // 2, rows % 2
+        pxx, qx = xs // 2, xs % 2
+        ysq = np.concatenate([((np.repeat(np.arange(int(h)), int(w)) // 2) * 2 + 1.0) / int(h)
+                              for h, w in levels])
+        tok = np.lexsort((qx, qy, pxx, lv, ysq))
+    else:
+        tok = np.lexsort((xs, lv, ys))  # primary key: y centre
     bounds = [(S * i) // N_XCD for i in range(N_XCD + 1)]
     out = []
     for b in range(N_XCD):
@@ -42,3 +52,12 @@ def encoder_unit_order(levels, n_frames, mode='band'):
     order = np.concatenate(out).astype(np.int32)
     assert order.shape[0] == n_frames * S
     return torch.from_numpy(order)
+
+
+def rest_unit_order(levels, n_frames):
+    """Units (frame * S + token) of levels 1.. in band order -- what the LDS-window encoder
+    kernel leaves to the direct-gather kernel."""
+    S = sum(int(h) * int(w) for h, w in levels)
+    n0 = int(levels[0][0]) * int(levels[0][1])
+    full = encoder_unit_order(levels, n_frames).numpy()
+    return torch.from_numpy(full[(full % S) >= n0].copy())

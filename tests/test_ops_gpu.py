@@ -196,3 +196,35 @@ def test_bias_act_rows_vs_torch():
     t = torch.randn(50, 128, generator=g)
     out = bias_act_rows_(t.cuda(), bias.repeat(2).cuda(), None, relu=False)
     np.testing.assert_allclose(out.cpu().numpy(), (t + bias.repeat(2)).numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('sigma', [0.7, 3.0, 12.0])
+@pytest.mark.parametrize('gr', [False, True])
+@pytest.mark.parametrize('levels', [[(24, 40), (12, 20), (6, 10), (3, 5)],
+                                    [(25, 42), (13, 21), (7, 11), (4, 6)]])
+def test_enc_window_kernel_equals_direct_and_oracle(levels, sigma, gr):
+    """LDS-window encoder kernel == direct-gather kernel == oracle, for small offsets (all
+    corners served from LDS), medium and huge offsets (mostly the global fallback), maps whose
+    sizes are not multiples of the tile, and reference points scaled by valid ratios."""
+    from pavenet_amd.locality import rest_unit_order
+    from pavenet_amd.ops import deform_attn_enc_window, deform_attn_grid_fused
+    shapes, lsi, sd, ld = _levels(levels)
+    S = int(shapes.prod(1).sum())
+    F = 2
+    value = _t(seeded_array(f'win.value.{S}', (F, S, 8, 32)))
+    proj = _t(seeded_array(f'win.proj.{S}.{sigma}', (F * S, 384)))
+    proj[:, :256] *= sigma
+    vr = (torch.ones(F, 2) if gr else torch.tensor([[1.0, 1.0], [0.83, 0.9]])).view(F, 1, 1, 2)
+    ys = torch.cat([((torch.arange(h * w) // w).float() + 0.5) / h for h, w in levels])
+    xs = torch.cat([((torch.arange(h * w) % w).float() + 0.5) / w for h, w in levels])
+    ref = (torch.stack([xs, ys], -1)[None, :, None, :] * vr).expand(F, S, 4, 2)
+    ref = ref.reshape(1, F * S, 4, 2).contiguous()
+    rest = rest_unit_order(levels, F).cuda()
+    a = deform_attn_enc_window(value.cuda(), sd, ld, proj.cuda(), ref.cuda(),
+                               levels_hw=levels, rest_order=rest, grid_ref=gr)
+    b = deform_attn_grid_fused(value.cuda(), sd, ld, proj.cuda(), ref.cuda(), T=1, n_clips=F,
+                               units_per_clip=S)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    idx = torch.arange(0, F * S, 7)
+    exp = grid_expected(value, shapes, lsi, proj[idx], ref[:, idx], 1, idx // S)
+    np.testing.assert_allclose(a.cpu()[idx].numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)

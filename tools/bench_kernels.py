@@ -58,6 +58,12 @@ def main():
     alg = 4 * (F * S * 256 + U * 384 + U * 256)
     print(f'enc_fused   frames={F} order={args.order}: {us:9.1f} us  {us / F:8.1f} us/frame  '
           f'alg {alg / us / 1e3:7.1f} GB/s')
+    from pavenet_amd.locality import rest_unit_order
+    rest = rest_unit_order(LEVELS, F).to(dev)
+    us = timeit(lambda: ops.deform_attn_enc_window(value, shapes, lsi, proj, ref,
+                                                   levels_hw=LEVELS, rest_order=rest, grid_ref=True))
+    print(f'enc_window  frames={F}: {us:9.1f} us  {us / F:8.1f} us/frame  '
+          f'alg {alg / us / 1e3:7.1f} GB/s')
     # the un-fused reference-shaped op on the same work
     off = proj[:, :256].view(F, S, 8, 4, 4, 2)
     norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
