@@ -244,6 +244,7 @@ def gen_e2e(which=None):
 PETR_E2E = {
     'e2e_petr_r50': 'configs/petr/petr_r50_16x2_100e_coco.py',
     'e2e_vedpose_r50': 'configs/vedpose/single_frame_posetrack_resnet50_inference.py',
+    'e2e_petr_hrnetw48': 'configs/petr/petr_hrnetw48_16x2_100e_coco.py',
 }
 
 

@@ -232,3 +232,213 @@ class ResNet(BaseModule):
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
+
+
+# ---------------------------------------------------------------------------
+# HRNet (a14): third_party/mmdetection/mmdet/models/backbones/hrnet.py, incl. the fork's
+# `return y_list[1:]` (:583).  Same ctor kwargs (`extra`) and state-dict keys.
+# ---------------------------------------------------------------------------
+class _Block(nn.Module):
+    """Runs a BasicBlock / Bottleneck parameter container (module forward, eval BN)."""
+
+    @staticmethod
+    def run(blk, x):
+        identity = x
+        y = x
+        for cn, bn, act in blk.pairs:
+            y = getattr(blk, bn)(getattr(blk, cn)(y))
+            if act:
+                y = F.relu(y)
+        if blk.downsample is not None:
+            identity = blk.downsample(x)
+        return F.relu(y + identity)
+
+
+class _BlockSeq(nn.Sequential):
+
+    def forward(self, x):
+        for blk in self:
+            x = _Block.run(blk, x)
+        return x
+
+
+class HRModule(nn.Module):
+    """hrnet.py:13-214."""
+
+    def __init__(self, num_branches, block, num_blocks, in_channels, num_channels,
+                 multiscale_output=True, norm_cfg=dict(type='BN')):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_branches = num_branches
+        self.multiscale_output = multiscale_output
+        self.norm_cfg = norm_cfg
+        self.branches = nn.ModuleList([
+            self._make_one_branch(i, block, num_blocks, num_channels) for i in range(num_branches)])
+        self.fuse_layers = self._make_fuse_layers()
+
+    def _make_one_branch(self, i, block, num_blocks, num_channels, stride=1):
+        downsample = None
+        if stride != 1 or self.in_channels[i] != num_channels[i] * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.in_channels[i], num_channels[i] * block.expansion, 1, stride,
+                          bias=False),
+                build_norm_layer(self.norm_cfg, num_channels[i] * block.expansion)[1])
+        layers = [block(self.in_channels[i], num_channels[i], stride, downsample=downsample,
+                        norm_cfg=self.norm_cfg)]
+        self.in_channels[i] = num_channels[i] * block.expansion
+        for _ in range(1, num_blocks[i]):
+            layers.append(block(self.in_channels[i], num_channels[i], norm_cfg=self.norm_cfg))
+        return _BlockSeq(*layers)
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        nb, ic = self.num_branches, self.in_channels
+        fuse_layers = []
+        for i in range(nb if self.multiscale_output else 1):
+            fuse_layer = []
+            for j in range(nb):
+                if j > i:
+                    fuse_layer.append(nn.Sequential(
+                        nn.Conv2d(ic[j], ic[i], 1, 1, 0, bias=False),
+                        build_norm_layer(self.norm_cfg, ic[i])[1],
+                        nn.Upsample(scale_factor=2**(j - i), mode='nearest')))
+                elif j == i:
+                    fuse_layer.append(None)
+                else:
+                    convs = []
+                    for k in range(i - j):
+                        if k == i - j - 1:
+                            convs.append(nn.Sequential(
+                                nn.Conv2d(ic[j], ic[i], 3, 2, 1, bias=False),
+                                build_norm_layer(self.norm_cfg, ic[i])[1]))
+                        else:
+                            convs.append(nn.Sequential(
+                                nn.Conv2d(ic[j], ic[j], 3, 2, 1, bias=False),
+                                build_norm_layer(self.norm_cfg, ic[j])[1], nn.ReLU(inplace=False)))
+                    fuse_layer.append(nn.Sequential(*convs))
+            fuse_layers.append(nn.ModuleList(fuse_layer))
+        return nn.ModuleList(fuse_layers)
+
+    def forward(self, x):
+        if self.num_branches == 1:
+            return [self.branches[0](x[0])]
+        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        x_fuse = []
+        for i in range(len(self.fuse_layers)):
+            y = 0
+            for j in range(self.num_branches):
+                y = y + (x[j] if i == j else self.fuse_layers[i][j](x[j]))
+            x_fuse.append(F.relu(y))
+        return x_fuse
+
+
+class _ModuleSeq(nn.Sequential):
+
+    def forward(self, x):
+        for m in self:
+            x = m(x)
+        return x
+
+
+@MMDET_MODELS.register_module()
+class HRNet(BaseModule):
+    blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
+
+    def __init__(self, extra, in_channels=3, conv_cfg=None, norm_cfg=dict(type='BN'),
+                 norm_eval=True, with_cp=False, zero_init_residual=False,
+                 multiscale_output=True, pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        assert all(f'stage{i + 1}' in extra for i in range(4))
+        self.extra = extra
+        self.norm_cfg = norm_cfg
+        self.norm_eval = norm_eval
+        self.conv1 = nn.Conv2d(in_channels, 64, 3, 2, 1, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, 64)[1]
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = build_norm_layer(norm_cfg, 64)[1]
+        cfg1 = extra['stage1']
+        block = self.blocks_dict[cfg1['block']]
+        nc = cfg1['num_channels'][0]
+        self.layer1 = self._make_layer(block, 64, nc, cfg1['num_blocks'][0])
+        pre = [nc * block.expansion]
+        for s in (2, 3, 4):
+            cfg = extra[f'stage{s}']
+            block = self.blocks_dict[cfg['block']]
+            chans = [c * block.expansion for c in cfg['num_channels']]
+            setattr(self, f'transition{s - 1}', self._make_transition_layer(pre, chans))
+            stage, pre = self._make_stage(cfg, chans,
+                                          multiscale_output if s == 4 else True)
+            setattr(self, f'stage{s}', stage)
+            setattr(self, f'stage{s}_cfg', cfg)
+
+    def _make_transition_layer(self, pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(nn.Sequential(
+                        nn.Conv2d(pre[i], cur[i], 3, 1, 1, bias=False),
+                        build_norm_layer(self.norm_cfg, cur[i])[1], nn.ReLU(inplace=True)))
+                else:
+                    layers.append(None)
+            else:
+                convs = []
+                for j in range(i + 1 - len(pre)):
+                    ic = pre[-1]
+                    oc = cur[i] if j == i - len(pre) else ic
+                    convs.append(nn.Sequential(
+                        nn.Conv2d(ic, oc, 3, 2, 1, bias=False),
+                        build_norm_layer(self.norm_cfg, oc)[1], nn.ReLU(inplace=True)))
+                layers.append(nn.Sequential(*convs))
+        return nn.ModuleList(layers)
+
+    def _make_layer(self, block, inplanes, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(inplanes, planes * block.expansion, 1, stride, bias=False),
+                build_norm_layer(self.norm_cfg, planes * block.expansion)[1])
+        layers = [block(inplanes, planes, stride, downsample=downsample, norm_cfg=self.norm_cfg)]
+        inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(inplanes, planes, norm_cfg=self.norm_cfg))
+        return _BlockSeq(*layers)
+
+    def _make_stage(self, cfg, in_channels, multiscale_output=True):
+        block = self.blocks_dict[cfg['block']]
+        mods = []
+        for i in range(cfg['num_modules']):
+            ms = not (not multiscale_output and i == cfg['num_modules'] - 1)
+            mods.append(HRModule(cfg['num_branches'], block, cfg['num_blocks'], in_channels,
+                                 cfg['num_channels'], ms, norm_cfg=self.norm_cfg))
+        return _ModuleSeq(*mods), in_channels
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._is_init = True
+
+    def forward(self, x):
+        if x.dim() == 5:  # [B, T, C, H, W]: the reference HRNet has no frame flatten (SURVEY 8c)
+            x = x.flatten(0, 1)
+        assert not self.training
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        y_list = [x]
+        for s in (2, 3, 4):
+            cfg = getattr(self, f'stage{s}_cfg')
+            tr = getattr(self, f'transition{s - 1}')
+            x_list = []
+            for i in range(cfg['num_branches']):
+                if tr[i] is not None:
+                    x_list.append(tr[i](y_list[-1] if s > 2 else x))
+                else:
+                    x_list.append(y_list[i] if s > 2 else x)
+            y_list = getattr(self, f'stage{s}')(x_list)
+        return tuple(y_list[1:])  # hrnet.py:583 (fork)

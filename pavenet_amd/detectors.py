@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .bricks import BaseModule
-from .registry import DETECTORS, build_backbone, build_head, build_neck
+from .registry import DETECTORS, MMDET_MODELS
 
 
 def bbox_kpt2result(bboxes, labels, kpts, num_classes):
@@ -35,12 +35,15 @@ class VideoPoseV1(BaseModule):
         backbone = dict(backbone)
         if pretrained:
             backbone['pretrained'] = pretrained
-        self.backbone = build_backbone(backbone)
-        self.neck = build_neck(neck) if neck is not None else None
+        # the reference detectors derive from mmdet's SingleStageDetector, whose __init__ builds
+        # its parts through mmdet's registry (single_stage.py:29-38): bare names such as
+        # 'HRNet' resolve in the mmdet scope, 'opera.X' walks up to the root and down again
+        self.backbone = MMDET_MODELS.build(backbone)
+        self.neck = MMDET_MODELS.build(neck) if neck is not None else None
         bbox_head = dict(bbox_head)
         bbox_head.update(train_cfg=train_cfg)
         bbox_head.update(test_cfg=test_cfg)
-        self.bbox_head = build_head(bbox_head)
+        self.bbox_head = MMDET_MODELS.build(bbox_head)
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
 

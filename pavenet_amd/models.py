@@ -125,3 +125,25 @@ def petr_r50_cfg(num_keypoints=17, num_query=300, max_per_img=100, head='opera.P
                           loss_weight=2.0)),
         train_cfg=None,
         test_cfg=dict(max_per_img=max_per_img))
+
+
+HRNET_W48_EXTRA = dict(
+    stage1=dict(num_modules=1, num_branches=1, block='BOTTLENECK', num_blocks=(4,),
+                num_channels=(64,)),
+    stage2=dict(num_modules=1, num_branches=2, block='BASIC', num_blocks=(4, 4),
+                num_channels=(48, 96)),
+    stage3=dict(num_modules=4, num_branches=3, block='BASIC', num_blocks=(4, 4, 4),
+                num_channels=(48, 96, 192)),
+    stage4=dict(num_modules=3, num_branches=4, block='BASIC', num_blocks=(4, 4, 4, 4),
+                num_channels=(48, 96, 192, 384)))
+
+
+def with_hrnet_w48(model_cfg):
+    """Swap the backbone / neck of a model dict for HRNet-w48 as in
+    configs/petr/petr_hrnetw48_16x2_100e_coco.py:7-45 (BASELINE configs[3]: the reference has
+    no HRNet PAVE-Net config; this composes its HRNet backbone dict with the MulFrames head)."""
+    import copy
+    cfg = copy.deepcopy(model_cfg)
+    cfg['backbone'] = dict(type='HRNet', in_channels=3, extra=copy.deepcopy(HRNET_W48_EXTRA))
+    cfg['neck']['in_channels'] = [96, 192, 384]
+    return cfg

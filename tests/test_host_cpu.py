@@ -143,11 +143,14 @@ def test_reference_config_files_build(golden_dir):
                        ('/root/reference/configs/videopose/2025-2-7/'
                         '2025_2_7_res50_num_frames_5_posetrack17.py', 'videopose_r50_t5'),
                        ('/root/reference/configs/petr/petr_r50_16x2_100e_coco.py', 'petr_r50'),
+                       ('/root/reference/configs/petr/petr_hrnetw48_16x2_100e_coco.py',
+                        'petr_hrnetw48'),
                        ('/root/reference/configs/vedpose/'
                         'single_frame_posetrack_resnet50_inference.py', 'vedpose_r50')):
         cfg = Config.fromfile(path)
         model = cfg.model.to_dict()
         model.pop('init_cfg', None)
+        model['backbone'].pop('init_cfg', None)
         model['train_cfg'] = None
         m = build_model(model)
         want = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))[name]

@@ -255,3 +255,35 @@ def test_petr_batched_vs_oracle():
             eb, el, ek = R.petr_simple_test(sd, dict(num_keypoints=17, num_query=300,
                                                      max_per_img=10), img[b:b + 1])
         np.testing.assert_allclose(got[b][2].cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)
+
+
+def test_petr_hrnet_w48_vs_reference_golden(golden_dir):
+    """HRNet-w48 backbone (BASELINE configs[3]) under the PETR head against the reference."""
+    from pavenet_amd.models import build_model, petr_r50_cfg, with_hrnet_w48
+    g = _g(golden_dir, 'e2e_petr_hrnetw48')
+    N = int(g['score_topk'].shape[0])
+    m = build_model(with_hrnet_w48(petr_r50_cfg(num_keypoints=17, max_per_img=N)))
+    m = _seed(m, g).cuda().eval()
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    with torch.no_grad():
+        feat = m.extract_feat(_t(g['img']).cuda())
+        outs = m.bbox_head(feat, metas)
+        np.testing.assert_allclose(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
+                                   rtol=2e-3, atol=5e-4)
+        res = m.bbox_head.get_bboxes(outs, metas)
+        (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
+    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+
+
+def test_videopose_hrnet_t7_runs_and_matches_structure():
+    """BASELINE configs[3] shape: HRNet-w48 + MulFrames head, T = 7 (no reference config
+    exists; the backbone is pinned above and the head by the R-50 tests)."""
+    from pavenet_amd.models import build_model, videopose_r50_cfg, with_hrnet_w48
+    m = _seed(build_model(with_hrnet_w48(videopose_r50_cfg(num_frames=7, max_per_img=10))))
+    m = m.cuda().eval()
+    img = _t(seeded_array('hrnet.t7', (1, 7, 3, 128, 160))).cuda()
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(128, 160, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    res = m.forward_device(img, metas)
+    assert res['kpts'].shape == (1, 10, 15, 3) and torch.isfinite(res['kpts']).all()
