@@ -43,6 +43,9 @@ def parse():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--max-per-img', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
+                         'the 28-frame headline batch is GPU-bound without it)')
     ap.add_argument('--cpu-baseline-frames', type=int, default=None)
     return ap.parse_args()
 
@@ -104,8 +107,13 @@ def main():
              for _ in range(B)]
     N, K = args.max_per_img, 15
 
+    graphed = None
+    if args.graph:
+        from pavenet_amd.graph import GraphedForward
+        graphed = GraphedForward(model, img, metas)
+
     def step():
-        res = model.forward_device(img, metas)
+        res = graphed(img) if graphed is not None else model.forward_device(img, metas)
         packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1),
                             res['keep'].float()], dim=1)  # [B, N*5 + N*K*3 + N]
         if dist is not None:

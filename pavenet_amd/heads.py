@@ -316,6 +316,21 @@ class VideoPoseHeadMulFrames(BaseModule):
         p = p[:, :, 0] * p[:, :, 1]
         return p[:, :, None] * 0.7
 
+    def _meta_scales(self, img_metas, device):
+        """[B,1,1,2] (w, h) and scale-factor tensors of the clips, cached on the device (a
+        host->device copy per call would also break hipGraph capture)."""
+        key = ('scales', str(device),
+               tuple((tuple(m['img_shape'][:2]), tuple(float(v) for v in m['scale_factor'][:2]))
+                     for m in img_metas))
+        if key not in self._consts:
+            B = len(img_metas)
+            wh = torch.tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas],
+                              dtype=torch.float32, device=device).view(B, 1, 1, 2)
+            sf = torch.tensor([list(m['scale_factor'][:2]) for m in img_metas],
+                              dtype=torch.float32, device=device).view(B, 1, 1, 2)
+            self._consts[key] = (wh, sf)
+        return self._consts[key]
+
     def _sigmas(self, device):
         key = ('oks_sigmas', str(device))
         if key not in self._consts:
@@ -360,13 +375,10 @@ class VideoPoseHeadMulFrames(BaseModule):
             taps.update(score_topk=indexs, refine_hs=r_hs, refine_kpts=det_kpts.clone(),
                         refine_sigma=det_sigmas)
         dev = det_kpts.device
-        wh = torch.tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas],
-                          dtype=torch.float32, device=dev).view(B, 1, 1, 2)
+        wh, sf = self._meta_scales(img_metas, dev)
         det_kpts = det_kpts * wh
         det_kpts = torch.minimum(det_kpts.clamp(min=0), wh)
         if rescale:
-            sf = torch.tensor([list(m['scale_factor'][:2]) for m in img_metas],
-                              dtype=torch.float32, device=dev).view(B, 1, 1, 2)
             det_kpts = det_kpts / sf
         x1 = det_kpts[..., 0].min(dim=2, keepdim=True)[0]
         y1 = det_kpts[..., 1].min(dim=2, keepdim=True)[0]

@@ -242,6 +242,7 @@ class PETRHead(BaseModule):
         self._is_init = True
 
     make_masks = VideoPoseHeadMulFrames.make_masks
+    _meta_scales = VideoPoseHeadMulFrames._meta_scales
     get_p = staticmethod(VideoPoseHeadMulFrames.get_p)
     results_to_list = staticmethod(VideoPoseHeadMulFrames.results_to_list)
 
@@ -301,12 +302,9 @@ class PETRHead(BaseModule):
         if taps is not None:
             taps.update(score_topk=indexs, refine_hs=r_hs, refine_kpts=det_kpts.clone())
         dev = det_kpts.device
-        wh = torch.tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas],
-                          dtype=torch.float32, device=dev).view(B, 1, 1, 2)
+        wh, sf = self._meta_scales(img_metas, dev)
         det_kpts = torch.minimum((det_kpts * wh).clamp(min=0), wh)
         if rescale:
-            sf = torch.tensor([list(m['scale_factor'][:2]) for m in img_metas],
-                              dtype=torch.float32, device=dev).view(B, 1, 1, 2)
             det_kpts = det_kpts / sf
         x1 = det_kpts[..., 0].min(dim=2, keepdim=True)[0]
         y1 = det_kpts[..., 1].min(dim=2, keepdim=True)[0]

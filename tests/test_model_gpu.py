@@ -287,3 +287,19 @@ def test_videopose_hrnet_t7_runs_and_matches_structure():
                   scale_factor=(1., 1., 1., 1.))]
     res = m.forward_device(img, metas)
     assert res['kpts'].shape == (1, 10, 15, 3) and torch.isfinite(res['kpts']).all()
+
+
+def test_hipgraph_replay_equals_eager():
+    from pavenet_amd.graph import GraphedForward
+    m = _build(3, 12)
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    a = _t(seeded_array('graph.a', (1, 3, 3, 128, 160))).cuda()
+    b = _t(seeded_array('graph.b', (1, 3, 3, 128, 160))).cuda()
+    g = GraphedForward(m, a, metas)
+    for img in (a, b, a):
+        got = {k: v.clone() for k, v in g(img).items()}
+        exp = m.forward_device(img, metas)
+        for k in ('bboxes', 'kpts', 'keep'):
+            np.testing.assert_allclose(got[k].float().cpu().numpy(),
+                                       exp[k].float().cpu().numpy(), rtol=1e-5, atol=1e-4)
