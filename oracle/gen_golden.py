@@ -180,6 +180,8 @@ E2E = {
                              '2025_5_11_res50_num_frames_3_posetrack17_layer_num_3.py', 3),
     'e2e_videopose_r50_t5': ('configs/videopose/2025-2-7/'
                              '2025_2_7_res50_num_frames_5_posetrack17.py', 5),
+    'e2e_videopose_swinl_t3': ('configs/videopose/2025-2-7/'
+                               '2025_2_7_swin_num_frames_3_posetrack17.py', 3),
 }
 
 
@@ -231,7 +233,7 @@ def gen_e2e(which=None):
         enc_topk = torch.topk(taps['enc_cls'][..., 0], Q, dim=1)[1]
         N = model.bbox_head.test_cfg['max_per_img']
         score_topk = taps['cls_all'][-1][0].sigmoid().view(-1).topk(N)[1]
-        full = (T == 3)  # T=5: keep the fixture small (centre-frame memory, no refine taps)
+        full = (name == 'e2e_videopose_r50_t3')  # others: keep the fixture small (centre-frame memory, no refine taps)
         extra = dict(memory=taps['memory'], neck3=feats[3], refine_hs=taps['refine_hs'][-1],
                      refine_refs=taps['refine_refs'], refine_init_ref=taps['refine_init_ref'],
                      kpt_last=taps['kpt_all'][-1]) if full else \

@@ -2,7 +2,7 @@
 reference's type names, and offers the re-stated model dicts (the reference's config files do
 not travel to the GPU box; the dicts below keep their type names and kwargs)."""
 from . import (backbones, bricks, deform_attn, detectors, heads, necks, petr,  # noqa: F401
-               transformer)
+               swin, transformer)
 from .registry import build_model  # noqa: F401
 
 
@@ -146,4 +146,18 @@ def with_hrnet_w48(model_cfg):
     cfg = copy.deepcopy(model_cfg)
     cfg['backbone'] = dict(type='HRNet', in_channels=3, extra=copy.deepcopy(HRNET_W48_EXTRA))
     cfg['neck']['in_channels'] = [96, 192, 384]
+    return cfg
+
+
+def with_swin_l(model_cfg, num_frames=None):
+    """Swin-L backbone / neck as in configs/videopose/2025-2-7/
+    2025_2_7_swin_num_frames_3_posetrack17.py:12-35."""
+    import copy
+    cfg = copy.deepcopy(model_cfg)
+    cfg['backbone'] = dict(type='mmdet.SwinTransformer', num_frames=num_frames, embed_dims=192,
+                           depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7,
+                           mlp_ratio=4, qkv_bias=True, qk_scale=None, drop_rate=0.,
+                           attn_drop_rate=0., drop_path_rate=0.3, patch_norm=True,
+                           out_indices=(1, 2, 3), with_cp=False)
+    cfg['neck']['in_channels'] = [384, 768, 1536]
     return cfg

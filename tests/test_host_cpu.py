@@ -142,6 +142,8 @@ def test_reference_config_files_build(golden_dir):
     for path, name in ((ref, 'videopose_r50_t3'),
                        ('/root/reference/configs/videopose/2025-2-7/'
                         '2025_2_7_res50_num_frames_5_posetrack17.py', 'videopose_r50_t5'),
+                       ('/root/reference/configs/videopose/2025-2-7/'
+                        '2025_2_7_swin_num_frames_3_posetrack17.py', 'videopose_swinl_t3'),
                        ('/root/reference/configs/petr/petr_r50_16x2_100e_coco.py', 'petr_r50'),
                        ('/root/reference/configs/petr/petr_hrnetw48_16x2_100e_coco.py',
                         'petr_hrnetw48'),

@@ -303,3 +303,28 @@ def test_hipgraph_replay_equals_eager():
         for k in ('bboxes', 'kpts', 'keep'):
             np.testing.assert_allclose(got[k].float().cpu().numpy(),
                                        exp[k].float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_swin_l_t3_vs_reference_golden(golden_dir):
+    """Swin-L T = 3 PAVE-Net (configs/videopose/2025-2-7/2025_2_7_swin_num_frames_3_posetrack17.py)
+    against the reference's outputs."""
+    from pavenet_amd.models import build_model, videopose_r50_cfg, with_swin_l
+    g = _g(golden_dir, 'e2e_videopose_swinl_t3')
+    N = int(g['score_topk'].shape[0])
+    m = build_model(with_swin_l(videopose_r50_cfg(num_frames=3, max_per_img=N), num_frames=3))
+    m = _seed(m, g).cuda().eval()
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    with torch.no_grad():
+        feat = m.extract_feat(_t(g['img']).cuda())
+        outs = m.bbox_head(feat, metas)
+        memory = outs['memory'].permute(1, 0, 2)
+        np.testing.assert_allclose(memory[1::3].cpu().numpy(), g['memory_center'],
+                                   rtol=2e-3, atol=1e-3)
+        outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
+        np.testing.assert_allclose(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
+                                   rtol=2e-3, atol=2e-3)
+        res = m.bbox_head.get_bboxes(outs, metas, force_score_topk=_t(g['score_topk'])[None].cuda())
+        (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
+    assert kpts.shape == g['det_kpts'].shape
+    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=2e-2)
