@@ -685,12 +685,12 @@ struct WinParams {
 
 // loads of one level's window rows (issued first, stored to LDS later so that every load of
 // the block is in flight before the first wait)
-template <int WW, int N>
+template <int WW, int N, int RPP>
 __device__ __forceinline__ void win_load(float4 (&v)[N], const char* vframe, int tid8, int ox,
                                          int oy, int H, int W, int st) {
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int r = tid8 + k * 32;
+    const int r = tid8 + k * RPP;
     const int wy = r / WW, wx = r - wy * WW;  // WW is a compile-time constant
     const int x = ox + wx, y = oy + wy;
     const bool ok = (r < WW * WW) && x >= 0 && x < W && y >= 0 && y < H;
@@ -700,24 +700,65 @@ __device__ __forceinline__ void win_load(float4 (&v)[N], const char* vframe, int
   }
 }
 
-template <int WW, int N>
+template <int WW, int N, int RPP>
 __device__ __forceinline__ void win_store(const float4 (&v)[N], float* win, int rbase, int tid8,
                                           int j) {
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int r = tid8 + k * 32;
+    const int r = tid8 + k * RPP;
     if (r < WW * WW) *reinterpret_cast<float4*>(win + (rbase + r) * 32 + j * 4) = v[k];
   }
 }
 
+// Broadcast of lane JJ's value to the 8 lanes of its group on the VALU (2 DPP moves + 1 select),
+// not through the LDS crossbar: ds_bpermute costs ~9 LDS cycles per wave instruction on the
+// pipe all four SIMDs share, which made the exchange 65 % of the LDS time.
+template <int JJ>
+__device__ __forceinline__ int bcast8(int x, bool hi) {
+  constexpr int q = JJ & 3;
+  const int t = __builtin_amdgcn_update_dpp(x, x, q * 0x55, 0xf, 0xf, false);  // quad_perm[q,q,q,q]
+  if constexpr (JJ < 4) {
+    const int u = __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xf, false);   // row_shr:4
+    return hi ? u : t;
+  } else {
+    const int u = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0xf, false);   // row_shl:4
+    return hi ? t : u;
+  }
+}
+
+template <int JJ>
+__device__ __forceinline__ void win_gather_pair(float4& acc, const char* wbytes,
+                                                const float (&dw)[2][4],
+                                                const unsigned (&pk)[2][2], bool hi) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float w0 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][0]), hi));
+    const float w1 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][1]), hi));
+    const float w2 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][2]), hi));
+    const float w3 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][3]), hi));
+    const unsigned p0 = (unsigned)bcast8<JJ>((int)pk[s][0], hi);
+    const unsigned p1 = (unsigned)bcast8<JJ>((int)pk[s][1], hi);
+    const float4 v0 = *reinterpret_cast<const float4*>(wbytes + (p0 & 0xffffu));
+    const float4 v1 = *reinterpret_cast<const float4*>(wbytes + (p0 >> 16));
+    const float4 v2 = *reinterpret_cast<const float4*>(wbytes + (p1 & 0xffffu));
+    const float4 v3 = *reinterpret_cast<const float4*>(wbytes + (p1 >> 16));
+    fma4(acc, w0, v0);
+    fma4(acc, w1, v1);
+    fma4(acc, w2, v2);
+    fma4(acc, w3, v3);
+  }
+}
+
+// 512 threads = 8 waves x (8 queries x 8 lanes); LDS holds only the window (61 KB), so two
+// workgroups (16 waves) share a CU.  Each lane prepares the corner descriptors of its 2 points
+// and the 8 lanes of a query exchange them with DPP moves (no LDS storage, no LDS traffic).
 template <int TILE, int W0, int W1, int W2, int W3>
-__global__ __launch_bounds__(256, 2) void enc_window_kernel(const WinParams p) {
+__global__ __launch_bounds__(512, 4) void enc_window_kernel(const WinParams p) {
+  static_assert(TILE * TILE == 64, "8 waves x 8 queries");
   constexpr int kR0 = W0 * W0, kR1 = W1 * W1, kR2 = W2 * W2, kR3 = W3 * W3;
   constexpr int kRows = kR0 + kR1 + kR2 + kR3;
-  constexpr int kGroupStride = 16 * 8 + 8;  // floats per (wave, group) descriptor block, padded
-  constexpr int kRounds = (TILE * TILE) / 32;
+  static_assert(kRows * 128 < 65536, "window byte offsets are packed into 16 bits");
   __shared__ __attribute__((aligned(16))) float win[kRows * 32];
-  __shared__ __attribute__((aligned(16))) float desc[4 * 8 * kGroupStride];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 3, j = lane & 7;
@@ -739,24 +780,17 @@ __global__ __launch_bounds__(256, 2) void enc_window_kernel(const WinParams p) {
   const int qx1 = min(qx0 + TILE, Ws[0]) - 1, qy1 = min(qy0 + TILE, Hs[0]) - 1;
   const long long ubase = (long long)frame * p.S;
 
-  // ---- prefetch this lane's projection rows / reference points for all rounds
+  // ---- this lane's query: projection row / reference point (issued before the staging loads)
   // lane j: points 2j, 2j+1 of this head -> both on level l = j >> 1
   const int l = j >> 1;
-  float4 off[kRounds];
-  float2 lgt[kRounds], rf[kRounds];
-  long long unit[kRounds];
-  bool valid[kRounds];
-#pragma unroll
-  for (int rd = 0; rd < kRounds; ++rd) {
-    const int qi = wave * (kRounds * 8) + rd * 8 + g;
-    const int qy = qy0 + qi / TILE, qx = qx0 + qi % TILE;
-    valid[rd] = (qy < Hs[0]) && (qx < Ws[0]);
-    unit[rd] = ubase + (valid[rd] ? (long long)qy * Ws[0] + qx : 0);
-    const float* row = p.proj + unit[rd] * p.proj_stride;
-    off[rd] = *reinterpret_cast<const float4*>(row + head * 32 + 4 * j);
-    lgt[rd] = *reinterpret_cast<const float2*>(row + 256 + head * 16 + 2 * j);
-    rf[rd] = *reinterpret_cast<const float2*>(p.ref + unit[rd] * 8 + 2 * l);
-  }
+  const int qi = wave * 8 + g;
+  const int qy = qy0 + qi / TILE, qx = qx0 + qi % TILE;
+  const bool valid = (qy < Hs[0]) && (qx < Ws[0]);
+  const long long unit = ubase + (valid ? (long long)qy * Ws[0] + qx : 0);
+  const float* row = p.proj + unit * p.proj_stride;
+  const float4 off = *reinterpret_cast<const float4*>(row + head * 32 + 4 * j);
+  const float2 lgt = *reinterpret_cast<const float2*>(row + 256 + head * 16 + 2 * j);
+  const float2 rf = *reinterpret_cast<const float2*>(p.ref + unit * 8 + 2 * l);
 
   // window origin per level, from the reference points of the tile's corner queries
   int ox[4], oy[4];
@@ -794,21 +828,21 @@ __global__ __launch_bounds__(256, 2) void enc_window_kernel(const WinParams p) {
   const char* vframe = reinterpret_cast<const char*>(p.value) + ubase * (kRowFloats * 4) +
                        head * (kDim * 4) + j * 16;
   {
-    const int tid8 = threadIdx.x >> 3;
-    constexpr int N0 = (kR0 + 31) / 32, N1 = (kR1 + 31) / 32, N2 = (kR2 + 31) / 32,
-                  N3 = (kR3 + 31) / 32;
+    const int tid8 = threadIdx.x >> 3;  // 0..63
+    constexpr int N0 = (kR0 + 63) / 64, N1 = (kR1 + 63) / 64, N2 = (kR2 + 63) / 64,
+                  N3 = (kR3 + 63) / 64;
     float4 v0[N0], v1[N1], v2[N2], v3[N3];
-    win_load<W0, N0>(v0, vframe, tid8, ox[0], oy[0], Hs[0], Ws[0], St[0]);
-    win_load<W1, N1>(v1, vframe, tid8, ox[1], oy[1], Hs[1], Ws[1], St[1]);
-    win_load<W2, N2>(v2, vframe, tid8, ox[2], oy[2], Hs[2], Ws[2], St[2]);
-    win_load<W3, N3>(v3, vframe, tid8, ox[3], oy[3], Hs[3], Ws[3], St[3]);
-    win_store<W0, N0>(v0, win, 0, tid8, j);
-    win_store<W1, N1>(v1, win, kR0, tid8, j);
-    win_store<W2, N2>(v2, win, kR0 + kR1, tid8, j);
-    win_store<W3, N3>(v3, win, kR0 + kR1 + kR2, tid8, j);
+    win_load<W0, N0, 64>(v0, vframe, tid8, ox[0], oy[0], Hs[0], Ws[0], St[0]);
+    win_load<W1, N1, 64>(v1, vframe, tid8, ox[1], oy[1], Hs[1], Ws[1], St[1]);
+    win_load<W2, N2, 64>(v2, vframe, tid8, ox[2], oy[2], Hs[2], Ws[2], St[2]);
+    win_load<W3, N3, 64>(v3, vframe, tid8, ox[3], oy[3], Hs[3], Ws[3], St[3]);
+    win_store<W0, N0, 64>(v0, win, 0, tid8, j);
+    win_store<W1, N1, 64>(v1, win, kR0, tid8, j);
+    win_store<W2, N2, 64>(v2, win, kR0 + kR1, tid8, j);
+    win_store<W3, N3, 64>(v3, win, kR0 + kR1 + kR2, tid8, j);
   }
-  __syncthreads();
 
+  // ---- descriptors of my two points (overlaps the staging loads' latency)
   const int H = l == 0 ? Hs[0] : l == 1 ? Hs[1] : l == 2 ? Hs[2] : Hs[3];
   const int W = l == 0 ? Ws[0] : l == 1 ? Ws[1] : l == 2 ? Ws[2] : Ws[3];
   const int st = l == 0 ? St[0] : l == 1 ? St[1] : l == 2 ? St[2] : St[3];
@@ -816,88 +850,83 @@ __global__ __launch_bounds__(256, 2) void enc_window_kernel(const WinParams p) {
   const int woy = l == 0 ? oy[0] : l == 1 ? oy[1] : l == 2 ? oy[2] : oy[3];
   const int ww = l == 0 ? W0 : l == 1 ? W1 : l == 2 ? W2 : W3;
   const int wbase = l == 0 ? 0 : l == 1 ? kR0 : l == 2 ? kR0 + kR1 : kR0 + kR1 + kR2;
-  float* my_desc = desc + (wave * 8 + g) * kGroupStride;
-  const char* wbytes = reinterpret_cast<const char*>(win) + j * 16;
-
-  // ---- queries: wave w owns tile queries [8*kRounds*w, ...), 8 at a time
+  const float mx = group8_max(fmaxf(lgt.x, lgt.y));
+  const float e0 = expf(lgt.x - mx), e1 = expf(lgt.y - mx);
+  const float inv = 1.f / group8_sum(e0 + e1);
+  float dw[2][4];
+  unsigned dofs[2][4];
+  bool my_fb = false;
 #pragma unroll
-  for (int rd = 0; rd < kRounds; ++rd) {
-    const float mx = group8_max(fmaxf(lgt[rd].x, lgt[rd].y));
-    const float e0 = expf(lgt[rd].x - mx), e1 = expf(lgt[rd].y - mx);
-    const float inv = 1.f / group8_sum(e0 + e1);
+  for (int s = 0; s < 2; ++s) {
+    const float ofx = s == 0 ? off.x : off.z, ofy = s == 0 ? off.y : off.w;
+    const float aw = (s == 0 ? e0 : e1) * inv;
+    const float px = (rf.x + ofx / (float)W) * (float)W - 0.5f;
+    const float py = (rf.y + ofy / (float)H) * (float)H - 0.5f;
+    const bool inside = (py > -1.f) && (px > -1.f) && (py < (float)H) && (px < (float)W);
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const bool y0ok = inside && (y0 >= 0), y1ok = inside && (y1 <= H - 1);
+    const bool x0ok = (x0 >= 0), x1ok = (x1 <= W - 1);
+    dw[s][0] = (y0ok && x0ok) ? hy * hx * aw : 0.f;
+    dw[s][1] = (y0ok && x1ok) ? hy * lx * aw : 0.f;
+    dw[s][2] = (y1ok && x0ok) ? ly * hx * aw : 0.f;
+    dw[s][3] = (y1ok && x1ok) ? ly * lx * aw : 0.f;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const float ofx = s == 0 ? off[rd].x : off[rd].z, ofy = s == 0 ? off[rd].y : off[rd].w;
-      const float aw = (s == 0 ? e0 : e1) * inv;
-      const float px = (rf[rd].x + ofx / (float)W) * (float)W - 0.5f;
-      const float py = (rf[rd].y + ofy / (float)H) * (float)H - 0.5f;
-      const bool inside = (py > -1.f) && (px > -1.f) && (py < (float)H) && (px < (float)W);
-      const float fy = floorf(py), fx = floorf(px);
-      const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-      const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-      const bool y0ok = inside && (y0 >= 0), y1ok = inside && (y1 <= H - 1);
-      const bool x0ok = (x0 >= 0), x1ok = (x1 <= W - 1);
-      const float wc[4] = {(y0ok && x0ok) ? hy * hx * aw : 0.f, (y0ok && x1ok) ? hy * lx * aw : 0.f,
-                           (y1ok && x0ok) ? ly * hx * aw : 0.f, (y1ok && x1ok) ? ly * lx * aw : 0.f};
-      unsigned o[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int cy = (c < 2) ? y0 : y1, cx = (c & 1) ? x1 : x0;
-        const int dy = cy - woy, dx = cx - wox;
-        if (wc[c] == 0.f) {
-          o[c] = 0u;  // masked corner: weight 0 on a staged (finite) row
-        } else if (dy >= 0 && dy < ww && dx >= 0 && dx < ww) {
-          o[c] = (unsigned)((wbase + dy * ww + dx) * 128);
-        } else {
-          o[c] = 0x80000000u | (unsigned)(st + cy * W + cx);  // global fallback: token index
-        }
-      }
-      float4* dst = reinterpret_cast<float4*>(my_desc + (2 * j + s) * 8);
-      dst[0] = make_float4(wc[0], wc[1], wc[2], wc[3]);
-      dst[1] = make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]),
-                           __uint_as_float(o[3]));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const float4 w = *reinterpret_cast<const float4*>(my_desc + i * 8);
-      const float4 of4 = *reinterpret_cast<const float4*>(my_desc + i * 8 + 4);
-      const unsigned o0 = __float_as_uint(of4.x), o1 = __float_as_uint(of4.y),
-                     o2 = __float_as_uint(of4.z), o3 = __float_as_uint(of4.w);
-      const bool fb = ((o0 | o1 | o2 | o3) & 0x80000000u) != 0u;
-      if (__builtin_amdgcn_ballot_w64(fb) == 0ull) {  // whole wave in-window: pure LDS gather
-        const float4 v0 = *reinterpret_cast<const float4*>(wbytes + o0);
-        const float4 v1 = *reinterpret_cast<const float4*>(wbytes + o1);
-        const float4 v2 = *reinterpret_cast<const float4*>(wbytes + o2);
-        const float4 v3 = *reinterpret_cast<const float4*>(wbytes + o3);
-        fma4(acc, w.x, v0);
-        fma4(acc, w.y, v1);
-        fma4(acc, w.z, v2);
-        fma4(acc, w.w, v3);
+    for (int c = 0; c < 4; ++c) {
+      const int cy = (c < 2) ? y0 : y1, cx = (c & 1) ? x1 : x0;
+      const int dy = cy - woy, dx = cx - wox;
+      if (dw[s][c] == 0.f) {
+        dofs[s][c] = 0u;  // masked corner: weight 0 on a staged (finite) row
+      } else if (dy >= 0 && dy < ww && dx >= 0 && dx < ww) {
+        dofs[s][c] = (unsigned)((wbase + dy * ww + dx) * 128);
       } else {
-        const unsigned oo[4] = {o0, o1, o2, o3};
-        const float wv[4] = {w.x, w.y, w.z, w.w};
+        dofs[s][c] = 0x80000000u | (unsigned)(st + cy * W + cx);  // global fallback: token
+        my_fb = true;
+      }
+    }
+  }
+  const bool wave_fb = __builtin_amdgcn_ballot_w64(my_fb) != 0ull;
+  // in-window offsets fit 16 bits: two per register on the common path
+  const unsigned pk[2][2] = {{dofs[0][0] | (dofs[0][1] << 16), dofs[0][2] | (dofs[0][3] << 16)},
+                             {dofs[1][0] | (dofs[1][1] << 16), dofs[1][2] | (dofs[1][3] << 16)}};
+  __syncthreads();  // windows staged
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const char* wbytes = reinterpret_cast<const char*>(win) + j * 16;
+  const int gbase = lane & 56;
+  if (!wave_fb) {
+    const bool hi = (lane & 4) != 0;
+    win_gather_pair<0>(acc, wbytes, dw, pk, hi);  // points 0, 1 (from lane 0 of the group)
+    win_gather_pair<1>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<2>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<3>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<4>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<5>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<6>(acc, wbytes, dw, pk, hi);
+    win_gather_pair<7>(acc, wbytes, dw, pk, hi);
+  } else {  // some corner of this wave lies outside its window: unpacked descriptors
+#pragma unroll 1
+    for (int jj = 0; jj < 8; ++jj) {
+      const int src = gbase | jj;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          const float wc = __shfl(dw[s][c], src);
+          const unsigned oc = (unsigned)__shfl((int)dofs[s][c], src);
           float4 v;
-          if (oo[c] & 0x80000000u) {
-            v = ld16(vframe, (oo[c] & 0x7fffffffu) * (unsigned)(kRowFloats * 4));
+          if (oc & 0x80000000u) {
+            v = ld16(vframe, (oc & 0x7fffffffu) * (unsigned)(kRowFloats * 4));
           } else {
-            v = *reinterpret_cast<const float4*>(wbytes + oo[c]);
+            v = *reinterpret_cast<const float4*>(wbytes + oc);
           }
-          fma4(acc, wv[c], v);
+          fma4(acc, wc, v);
         }
       }
     }
-    if (valid[rd])
-      *reinterpret_cast<float4*>(p.out + unit[rd] * kRowFloats + head * kDim + j * 4) = acc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  if (valid) *reinterpret_cast<float4*>(p.out + unit * kRowFloats + head * kDim + j * 4) = acc;
 }
 
 template <int MODE, int PPL, int WQ>
@@ -1177,7 +1206,7 @@ int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_s
   const long long nb = (long long)n_frames * w.tiles_x * w.tiles_y * kHeads;
   if (nb >= (1ll << 31)) return fail(PAVE_E_ARG, "enc_deform_attn_window: grid too large");
   w.n_blocks = (int)nb;
-  hipLaunchKernelGGL((enc_window_kernel<kTile, 15, 11, 9, 8>), dim3((unsigned)nb), dim3(256), 0,
+  hipLaunchKernelGGL((enc_window_kernel<kTile, 15, 11, 9, 8>), dim3((unsigned)nb), dim3(512), 0,
                      st, w);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
