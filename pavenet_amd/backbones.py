@@ -194,7 +194,7 @@ class ResNet(BaseModule):
         return self._as_map(out, onhw)
 
     def forward(self, x):
-        if self.input_type == 'mul_frames':
+        if self.input_type == 'mul_frames' and x.dim() == 5:
             x = x.flatten(0, 1)  # [B, T, C, H, W] -> [B*T, C, H, W]  (resnet.py:634-639)
         assert not self.training, 'pavenet_amd.ResNet is an inference (frozen BN) backbone'
         f = self._build_folded()

@@ -58,7 +58,8 @@ class VideoPoseV1(BaseModule):
         return x
 
     @torch.no_grad()
-    def forward_device(self, img, img_metas, rescale=False, **head_kwargs):
+    def forward_device(self, img, img_metas, rescale=False, force_score_topk=None,
+                       **head_kwargs):
         """img [B, T, 3, H, W] on the device; img_metas: one dict per clip.  Returns the
         head's fixed-shape device result dict (see VideoPoseHeadMulFrames.get_bboxes).
 
@@ -66,7 +67,8 @@ class VideoPoseV1(BaseModule):
         rank's frames, img [B, T_loc, 3, H, W] (frames t with t % world == rank, in order)."""
         feat = self.extract_feat(img)
         outs = self.bbox_head(feat, img_metas, **head_kwargs)
-        return self.bbox_head.get_bboxes(outs, img_metas, rescale=rescale)
+        return self.bbox_head.get_bboxes(outs, img_metas, rescale=rescale,
+                                         force_score_topk=force_score_topk)
 
     @torch.no_grad()
     def simple_test(self, img, img_metas, rescale=False):

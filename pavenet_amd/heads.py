@@ -208,14 +208,17 @@ class VideoPoseHeadMulFrames(BaseModule):
     def make_masks(self, mlvl_feats, img_metas, frames_per_clip=None):
         """Padding masks + sine encodings per level.  When no clip is padded they are built
         once for a single frame (they are identical for every frame) and broadcast."""
-        n = mlvl_feats[0].size(0)
+        return self.make_masks_from_shapes(mlvl_feats[0].size(0),
+                                           [tuple(f.shape[-2:]) for f in mlvl_feats],
+                                           mlvl_feats[0].device, img_metas, frames_per_clip)
+
+    def make_masks_from_shapes(self, n, level_hw, dev, img_metas, frames_per_clip=None):
         T = frames_per_clip or self.num_frames
         H, W = img_metas[0]['batch_input_shape']
         shapes = [tuple(int(v) for v in img_metas[i // T]['img_shape'][:2]) for i in range(n)]
         has_padding = any(s != (H, W) for s in shapes)
-        dev = mlvl_feats[0].device
         key = (H, W, tuple(shapes) if has_padding else None,
-               tuple(tuple(f.shape[-2:]) for f in mlvl_feats), str(dev))
+               tuple(tuple(int(v) for v in hw) for hw in level_hw), str(dev))
         if key not in self._consts:
             nm = n if has_padding else 1
             img_masks = torch.ones((nm, H, W), device=dev)
@@ -223,8 +226,8 @@ class VideoPoseHeadMulFrames(BaseModule):
                 h, w = shapes[i]
                 img_masks[i, :h, :w] = 0
             masks, pos = [], []
-            for feat in mlvl_feats:
-                m = F.interpolate(img_masks[None], size=feat.shape[-2:]).to(torch.bool).squeeze(0)
+            for hw in level_hw:
+                m = F.interpolate(img_masks[None], size=tuple(hw)).to(torch.bool).squeeze(0)
                 masks.append(m)
                 pos.append(self.positional_encoding(m))
             if len(self._consts) > 8:
@@ -238,8 +241,12 @@ class VideoPoseHeadMulFrames(BaseModule):
         T, Q = self.num_frames, self.num_query
         c = T // 2
         shard = tr_kwargs.get('frame_shard')
-        mlvl_masks, mlvl_pos, has_padding = self.make_masks(
-            mlvl_feats, img_metas, shard.n_local if shard is not None else None)
+        pre = tr_kwargs.pop('precomputed', None)
+        if pre is not None:  # streaming: encoder memory comes from the per-frame cache
+            mlvl_masks, mlvl_pos, has_padding, tr_kwargs['encoded'] = pre
+        else:
+            mlvl_masks, mlvl_pos, has_padding = self.make_masks(
+                mlvl_feats, img_metas, shard.n_local if shard is not None else None)
         hs, init_reference, inter_references, enc_outputs_class, enc_outputs_kpt, \
             enc_outputs_sigma, hm_proto, memory = self.transformer(
                 mlvl_feats, mlvl_masks, self.query_embedding.weight, mlvl_pos,
@@ -358,6 +365,13 @@ class VideoPoseHeadMulFrames(BaseModule):
         if force_score_topk is not None:
             indexs = force_score_topk
             scores = torch.gather(cls_score, 1, indexs)
+        shard = outs.get('frame_shard')
+        if shard is not None:
+            # a discrete choice made from replicated arithmetic: take rank 0's, so that a
+            # last-bit difference between ranks can never make them decode different poses
+            from . import dist as pdist
+            indexs = pdist.broadcast_from(indexs.contiguous(), 0, shard.group)
+            scores = torch.gather(cls_score, 1, indexs)
         det_labels = indexs % self.num_classes
         bbox_index = indexs // self.num_classes                     # [B, N]
         gidx = bbox_index.unsqueeze(-1).expand(-1, -1, 2 * K)
@@ -392,7 +406,7 @@ class VideoPoseHeadMulFrames(BaseModule):
         det_kpts = torch.cat((det_kpts, kpt_scores), dim=3).contiguous()
         keep, order = ops.oks_nms(det_kpts, scores.contiguous(), self._sigmas(dev), self.oks_thresh)
         return dict(bboxes=det_bboxes, labels=det_labels, kpts=det_kpts, keep=keep, order=order,
-                    scores=scores)
+                    scores=scores, score_index=indexs)
 
     def simple_test_bboxes(self, feats, img_metas, rescale=False):
         """HEAD:1507-1529 -> list (per clip) of (det_bboxes [n,5], det_labels [n], det_kpts [n,K,3])."""

@@ -242,6 +242,7 @@ class PETRHead(BaseModule):
         self._is_init = True
 
     make_masks = VideoPoseHeadMulFrames.make_masks
+    make_masks_from_shapes = VideoPoseHeadMulFrames.make_masks_from_shapes
     _meta_scales = VideoPoseHeadMulFrames._meta_scales
     get_p = staticmethod(VideoPoseHeadMulFrames.get_p)
     results_to_list = staticmethod(VideoPoseHeadMulFrames.results_to_list)

@@ -382,17 +382,11 @@ class VideoPoseTransformerMulFrames(Transformer):
         """Reference kwarg names -> per-frame list (or generic frame_<suffix>)."""
         return _collect_frame_branches(self.num_frames, kwargs, suffix)
 
-    # -- a4: forward (OT:21218-21456) ----------------------------------------
-    def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, cls_branches=None,
-                sigma_branches=None, has_padding=True, frame_shard=None, **kwargs):
-        """frame_shard (pavenet_amd.dist.FrameShard): mlvl_feats hold only this rank's frames
-        ([B*T_loc, C, h, w]); the encoder runs on them, the centre-frame proposals are broadcast
-        from their owner, and the T-frame attentions merge per-rank partial rows."""
-        assert self.as_two_stage or query_embed is not None
-        T = self.num_frames
-        Tl = T if frame_shard is None else frame_shard.n_local
-        branches = self._frame_branch_lists(kwargs, 'kpt_branches')
-        kpt_branches = branches[T // 2] if branches is not None else None
+    # -- encoder over independent frames (OT:21277-21322) ----------------------
+    def encode_frames(self, mlvl_feats, mlvl_masks, mlvl_pos_embeds, has_padding=True):
+        """Flatten levels and run the encoder.  Frames are independent here, so the result can
+        be cached per frame (pavenet_amd.streaming) or computed on another rank (frame sharding).
+        -> (memory [n_frames, S, C], mask_flatten, valid_ratios [n_frames, L, 2], geometry)."""
         dev = mlvl_feats[0].device
         geom = self.geometry([f.shape[-2:] for f in mlvl_feats], dev)
         feat_flatten, mask_flatten, lvl_pos_embed_flatten = [], [], []
@@ -401,7 +395,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             mask_flatten.append(mask.flatten(1))
             pos_embed = pos_embed.flatten(2).transpose(1, 2)
             lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
-        feat_flatten = torch.cat(feat_flatten, 1)                      # [B*T, S, C] contiguous
+        feat_flatten = torch.cat(feat_flatten, 1)                      # [n, S, C] contiguous
         mask_flatten = torch.cat(mask_flatten, 1)
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
         if lvl_pos_embed_flatten.shape[0] != feat_flatten.shape[0]:    # shared across frames
@@ -428,7 +422,29 @@ class VideoPoseTransformerMulFrames(Transformer):
             query_pos=seq_first_view(lvl_pos_embed_flatten), query_key_padding_mask=attn_mask,
             spatial_shapes=spatial_shapes, reference_points=reference_points,
             level_start_index=level_start_index, valid_ratios=valid_ratios, **extra)
-        memory = batch_first(memory)                                   # [B*T, S, C]
+        return batch_first(memory), mask_flatten, valid_ratios, geom
+
+    # -- a4: forward (OT:21218-21456) ----------------------------------------
+    def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, cls_branches=None,
+                sigma_branches=None, has_padding=True, frame_shard=None, **kwargs):
+        """frame_shard (pavenet_amd.dist.FrameShard): mlvl_feats hold only this rank's frames
+        ([B*T_loc, C, h, w]); the encoder runs on them, the centre-frame proposals are broadcast
+        from their owner, and the T-frame attentions merge per-rank partial rows."""
+        assert self.as_two_stage or query_embed is not None
+        T = self.num_frames
+        Tl = T if frame_shard is None else frame_shard.n_local
+        branches = self._frame_branch_lists(kwargs, 'kpt_branches')
+        kpt_branches = branches[T // 2] if branches is not None else None
+        encoded = kwargs.pop('encoded', None)
+        if encoded is None:
+            encoded = self.encode_frames(mlvl_feats, mlvl_masks, mlvl_pos_embeds, has_padding)
+        memory, mask_flatten, valid_ratios, geom = encoded
+        dev = memory.device
+        bs = memory.shape[0]
+        spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
+        attn_mask = mask_flatten if has_padding else None
+        if attn_mask is not None and attn_mask.shape[0] != bs:
+            attn_mask = attn_mask.expand(bs, -1)
         c = memory.shape[-1]
         n_clips = bs // Tl
         if frame_shard is None:

@@ -210,8 +210,11 @@ def test_frame_sharded_two_ranks(T):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'tests', 'sharded_worker.py'), str(T)]
+    torch.cuda.empty_cache()  # the two workers share this process's GPU
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    if r.returncode != 0 and 'MISMATCH' not in r.stdout:  # rendezvous hiccup: one retry
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:] + '\n---\n' + r.stderr[-6000:])
     assert 'sharded == unsharded: True' in r.stdout
 
 
@@ -328,3 +331,22 @@ def test_swin_l_t3_vs_reference_golden(golden_dir):
         (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
     assert kpts.shape == g['det_kpts'].shape
     np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=2e-2)
+
+
+def test_streaming_video_equals_per_window_simple_test():
+    """Per-frame encoder-memory cache: every frame of a 6-frame video, decoded from
+    cached slabs, equals simple_test on its edge-replicated T = 3 window."""
+    from pavenet_amd.streaming import VideoPoseStream
+    m = _build(3, 12)
+    meta = dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3), scale_factor=(1., 1., 1., 1.))
+    video = _t(seeded_array('stream.video', (6, 3, 128, 160))).cuda()
+    stream = VideoPoseStream(m, meta, encode_chunk=4, decode_chunk=4)
+    got = stream.infer_video(video)
+    wins = stream.window_indices(6, 3)
+    assert wins[0] == [0, 0, 1] and wins[5] == [4, 5, 5] and wins[2] == [1, 2, 3]
+    for c, w in enumerate(wins):
+        clip = video[w][None]  # [1, T, 3, H, W]
+        exp = m.bbox_head.results_to_list(m.forward_device(clip, [meta]))[0]
+        assert got[c][2].shape == exp[2].shape
+        np.testing.assert_allclose(got[c][2].cpu().numpy(), exp[2].cpu().numpy(),
+                                   rtol=1e-4, atol=1e-2)

@@ -69,7 +69,8 @@ def test_sampler_errors():
     assert ms_deform_attn_forward(v, sd, ld, loc, aw, 3).shape == (3, 5, 256)
 
 
-@pytest.mark.parametrize('T,U,clips', [(1, 321, 1), (1, 643, 2), (3, 75, 2), (5, 45, 1), (7, 30, 2)])
+@pytest.mark.parametrize('T,U,clips', [(1, 321, 1), (1, 643, 2), (2, 75, 2), (3, 75, 2), (4, 33, 1),
+                                       (5, 45, 1), (7, 30, 2)])
 def test_grid_fused_vs_oracle(T, U, clips):
     from pavenet_amd.ops import deform_attn_grid_fused
     shapes, lsi, sd, ld = _levels(LEVELS)
@@ -93,7 +94,8 @@ def test_grid_fused_vs_oracle(T, U, clips):
                                rtol=1e-5)
 
 
-@pytest.mark.parametrize('T,clips,Q,K', [(1, 2, 9, 17), (3, 2, 10, 15), (5, 1, 7, 15), (7, 1, 5, 15)])
+@pytest.mark.parametrize('T,clips,Q,K', [(1, 2, 9, 17), (2, 2, 10, 15), (3, 2, 10, 15), (5, 1, 7, 15),
+                                         (7, 1, 5, 15)])
 def test_pose_fused_vs_oracle(T, clips, Q, K):
     from pavenet_amd.ops import deform_attn_pose_fused
     shapes, lsi, sd, ld = _levels(LEVELS)
