@@ -149,6 +149,28 @@ int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_s
                                     int n_frames, int S, const int* levels_hw, int grid_ref,
                                     int n_rest, int proj_stride, void* stream);
 
+/*
+ * [R1] backward: void ms_deform_attn_backward(value, spatial_shapes, level_start_index,
+ * sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc, grad_attn_weight,
+ * im2col_step)  (pybind.cpp:167-173, 743-748; ms_deform_attn_cuda.cu:279-351;
+ * kernels ms_deform_attn_cuda_kernel.cuh:66-198, 256-801).
+ *   grad_output [bs, Lq, M*D];  grad_value [bs, S, M, D] is ACCUMULATED into (caller zeroes it,
+ *   as MO:72 does);  grad_sampling_loc [bs, Lq, M, L, P, 2] and grad_attn_weight
+ *   [bs, Lq, M, L, P] are fully overwritten.
+ */
+int pave_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start, const float* sampling_loc,
+                                     const float* attn_weight, const float* grad_output,
+                                     float* grad_value, float* grad_sampling_loc,
+                                     float* grad_attn_weight, int bs, int S, int M, int D, int L,
+                                     int Lq, int P, int im2col_step, void* stream);
+int pave_ms_deform_attn_backward_f64(const double* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start, const double* sampling_loc,
+                                     const double* attn_weight, const double* grad_output,
+                                     double* grad_value, double* grad_sampling_loc,
+                                     double* grad_attn_weight, int bs, int S, int M, int D, int L,
+                                     int Lq, int P, int im2col_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -998,6 +998,127 @@ int msda_forward_impl(const scalar_t* value, const int64_t* shapes, const int64_
   return PAVE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// [R1] backward (ms_deform_attn_backward): restates the col2im family of
+// ms_deform_attn_cuda_kernel.cuh:66-198, 256-801 with one decomposition for every D:
+// a group of G lanes (fp32, D % 4 == 0: G = D/4 lanes x 4 channels; otherwise G = 1 lane looping
+// over the channels) owns one (b, q, m).  grad_value is scattered with float atomics (the only
+// cross-group sum); the channel sums of grad_sampling_loc / grad_attn_weight are reduced with
+// xor-shuffles inside the group and written once, so those two outputs need no atomics and no
+// shared-memory variants per D.
+// ---------------------------------------------------------------------------
+template <typename scalar_t, int G, int CPL>  // CPL channels per lane per step (4 or 1)
+__global__ __launch_bounds__(256) void msda_bwd_kernel(
+    const long long ngroups, const scalar_t* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const scalar_t* __restrict__ loc,
+    const scalar_t* __restrict__ attw, const scalar_t* __restrict__ gout, const int S,
+    const int M, const int D, const int L, const int Lq, const int P,
+    scalar_t* __restrict__ gvalue, scalar_t* __restrict__ gloc, scalar_t* __restrict__ gattw) {
+  constexpr int kGroupsPerBlock = 256 / G;
+  const int sub = threadIdx.x % G;
+  const long long row = (long long)M * D;
+  for (long long g = (long long)blockIdx.x * kGroupsPerBlock + threadIdx.x / G; g < ngroups;
+       g += (long long)gridDim.x * kGroupsPerBlock) {
+    const int m = (int)(g % M);
+    const long long b = g / ((long long)M * Lq);
+    const scalar_t* vb = value + b * S * row + (long long)m * D;
+    scalar_t* gvb = gvalue + b * S * row + (long long)m * D;
+    const scalar_t* go = gout + g * D;
+    for (int l = 0; l < L; ++l) {
+      const long long start = lsi[l];
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      for (int p = 0; p < P; ++p) {
+        const long long pi = (g * L + l) * P + p;
+        const scalar_t loc_w = loc[2 * pi], loc_h = loc[2 * pi + 1];
+        const scalar_t weight = attw[pi];
+        const scalar_t h_im = loc_h * H - (scalar_t)0.5, w_im = loc_w * W - (scalar_t)0.5;
+        scalar_t g_w = 0, g_x = 0, g_y = 0;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+          const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const scalar_t lh = h_im - h_low, lw = w_im - w_low, hh = 1 - lh, hw = 1 - lw;
+          const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= W - 1;
+          const bool ok3 = h_high <= H - 1 && w_low >= 0, ok4 = h_high <= H - 1 && w_high <= W - 1;
+          const long long o1 = (start + (long long)h_low * W + w_low) * row;
+          const long long o2 = (start + (long long)h_low * W + w_high) * row;
+          const long long o3 = (start + (long long)h_high * W + w_low) * row;
+          const long long o4 = (start + (long long)h_high * W + w_high) * row;
+          const scalar_t w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          for (int c0 = sub * CPL; c0 < D; c0 += G * CPL) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+              const int c = c0 + k;
+              const scalar_t top = go[c];
+              const scalar_t tgv = top * weight;  // d out / d bilinear
+              const scalar_t v1 = ok1 ? vb[o1 + c] : (scalar_t)0, v2 = ok2 ? vb[o2 + c] : (scalar_t)0;
+              const scalar_t v3 = ok3 ? vb[o3 + c] : (scalar_t)0, v4 = ok4 ? vb[o4 + c] : (scalar_t)0;
+              if (ok1) atomicAdd(gvb + o1 + c, w1 * tgv);
+              if (ok2) atomicAdd(gvb + o2 + c, w2 * tgv);
+              if (ok3) atomicAdd(gvb + o3 + c, w3 * tgv);
+              if (ok4) atomicAdd(gvb + o4 + c, w4 * tgv);
+              g_w += top * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+              g_x += tgv * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);  // d/dw of the bilinear form
+              g_y += tgv * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+            }
+          }
+        }
+#pragma unroll
+        for (int o = G >> 1; o > 0; o >>= 1) {
+          g_w += __shfl_xor(g_w, o);
+          g_x += __shfl_xor(g_x, o);
+          g_y += __shfl_xor(g_y, o);
+        }
+        if (sub == 0) {
+          gattw[pi] = g_w;
+          gloc[2 * pi] = g_x * W;
+          gloc[2 * pi + 1] = g_y * H;
+        }
+      }
+    }
+  }
+}
+
+template <typename scalar_t>
+int msda_backward_impl(const scalar_t* value, const int64_t* shapes, const int64_t* lsi,
+                       const scalar_t* loc, const scalar_t* attw, const scalar_t* gout,
+                       scalar_t* gvalue, scalar_t* gloc, scalar_t* gattw, int bs, int S, int M,
+                       int D, int L, int Lq, int P, int im2col_step, void* stream) {
+  if (!value || !shapes || !lsi || !loc || !attw || !gout || !gvalue || !gloc || !gattw)
+    return fail(PAVE_E_ARG, "ms_deform_attn_backward: null pointer");
+  if (bs <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0 || im2col_step <= 0)
+    return fail(PAVE_E_ARG, "ms_deform_attn_backward: sizes must be positive");
+  const int step = bs < im2col_step ? bs : im2col_step;
+  if (bs % step != 0)
+    return fail(PAVE_E_STEP, "ms_deform_attn_backward: batch must be divisible by im2col_step");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long ngroups = (long long)bs * Lq * M;
+  bool done = false;
+#define PAVE_BWD(T_, G_, C_)                                                                     \
+  {                                                                                               \
+    long long nb = (ngroups + (256 / G_) - 1) / (256 / G_);                                       \
+    if (nb > 65536 * 4) nb = 65536 * 4;                                                           \
+    hipLaunchKernelGGL((msda_bwd_kernel<T_, G_, C_>), dim3((unsigned)nb), dim3(256), 0, st,      \
+                       ngroups, value, shapes, lsi, loc, attw, gout, S, M, D, L, Lq, P, gvalue,   \
+                       gloc, gattw);                                                              \
+    done = true;                                                                                  \
+  }
+  if constexpr (sizeof(scalar_t) == 4) {
+    if (D % 4 == 0) {
+      const int G = D / 4;
+      if (G == 8) PAVE_BWD(float, 8, 4)
+      else if (G == 16) PAVE_BWD(float, 16, 4)
+      else if (G == 4) PAVE_BWD(float, 4, 4)
+      else if (G == 2) PAVE_BWD(float, 2, 4)
+      else if (G == 1) PAVE_BWD(float, 1, 4)
+    }
+  }
+  if (!done) PAVE_BWD(scalar_t, 1, 1)
+#undef PAVE_BWD
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1229,6 +1350,28 @@ int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_s
     return launch_fused<kGrid, 2, 1>(p, st);
   }
   return PAVE_OK;
+}
+
+int pave_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start, const float* sampling_loc,
+                                     const float* attn_weight, const float* grad_output,
+                                     float* grad_value, float* grad_sampling_loc,
+                                     float* grad_attn_weight, int bs, int S, int M, int D, int L,
+                                     int Lq, int P, int im2col_step, void* stream) {
+  return msda_backward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                                   grad_output, grad_value, grad_sampling_loc, grad_attn_weight,
+                                   bs, S, M, D, L, Lq, P, im2col_step, stream);
+}
+
+int pave_ms_deform_attn_backward_f64(const double* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start, const double* sampling_loc,
+                                     const double* attn_weight, const double* grad_output,
+                                     double* grad_value, double* grad_sampling_loc,
+                                     double* grad_attn_weight, int bs, int S, int M, int D, int L,
+                                     int Lq, int P, int im2col_step, void* stream) {
+  return msda_backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                                    grad_output, grad_value, grad_sampling_loc, grad_attn_weight,
+                                    bs, S, M, D, L, Lq, P, im2col_step, stream);
 }
 
 }  // extern "C"

@@ -95,23 +95,62 @@ def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
     return out
 
 
-class MultiScaleDeformableAttnFunction(torch.autograd.Function):
-    """Same ``apply(value, shapes, lsi, loc, weights, im2col_step)`` as MO:20-57.
+def ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index,
+                            sampling_locations, attention_weights, grad_output, grad_value,
+                            grad_sampling_loc, grad_attn_weight, im2col_step=64):
+    """Same positional / keyword surface as ``mmcv._ext.ms_deform_attn_backward``
+    (pybind.cpp:743-748): grad_value is accumulated into, the other two are overwritten."""
+    lib = native.load()
+    dt = value.dtype
+    _require(dt in (torch.float32, torch.float64), 'ms_deform_attn_backward: fp32 / fp64 only')
+    for t, n in ((value, 'value'), (sampling_locations, 'sampling_loc'),
+                 (attention_weights, 'attn_weight'), (grad_output, 'grad_output'),
+                 (grad_value, 'grad_value'), (grad_sampling_loc, 'grad_sampling_loc'),
+                 (grad_attn_weight, 'grad_attn_weight')):
+        _dev(t, n, dt)
+    _dev(value_spatial_shapes, 'spatial_shapes', torch.int64)
+    _dev(value_level_start_index, 'level_start_index', torch.int64)
+    bs, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    _require(grad_output.numel() == bs * Lq * M * D and grad_value.shape == value.shape and
+             grad_sampling_loc.shape == sampling_locations.shape and
+             grad_attn_weight.shape == attention_weights.shape,
+             'ms_deform_attn_backward: gradient shapes mismatch')
+    fn = (lib.pave_ms_deform_attn_backward_f32 if dt == torch.float32
+          else lib.pave_ms_deform_attn_backward_f64)
+    with torch.cuda.device(value.device):
+        st = fn(value.data_ptr(), value_spatial_shapes.data_ptr(),
+                value_level_start_index.data_ptr(), sampling_locations.data_ptr(),
+                attention_weights.data_ptr(), grad_output.data_ptr(), grad_value.data_ptr(),
+                grad_sampling_loc.data_ptr(), grad_attn_weight.data_ptr(), bs, S, M, D, L, Lq, P,
+                int(im2col_step), _stream_ptr())
+    native.check(st, 'ms_deform_attn_backward')
 
-    Forward only this round (backward is "next").
-    """
+
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """Same ``apply(value, shapes, lsi, loc, weights, im2col_step)`` and gradients as MO:20-89."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
                 sampling_locations, attention_weights, im2col_step):
-        return ms_deform_attn_forward(
+        ctx.im2col_step = im2col_step
+        out = ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index,
             sampling_locations, attention_weights, im2col_step=im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
-        raise NotImplementedError(
-            'pavenet_amd: ms_deform_attn_backward is not built yet (forward-only path)')
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        grad_value = torch.zeros_like(value)
+        grad_loc = torch.zeros_like(loc)
+        grad_aw = torch.zeros_like(aw)
+        ms_deform_attn_backward(value, shapes, lsi, loc, aw, grad_output.contiguous(), grad_value,
+                                grad_loc, grad_aw, im2col_step=ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_aw, None
 
 
 def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,

@@ -230,3 +230,31 @@ def test_enc_window_kernel_equals_direct_and_oracle(levels, sigma, gr):
     idx = torch.arange(0, F * S, 7)
     exp = grid_expected(value, shapes, lsi, proj[idx], ref[:, idx], 1, idx // S)
     np.testing.assert_allclose(a.cpu()[idx].numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('D', [4, 30, 32, 64, 71])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_backward_vs_autograd_of_reference_formulation(D, dtype):
+    """ms_deform_attn_backward against autograd through the reference's own PyTorch formulation
+    (MO:92-149, restated in the oracle) -- the comparison mmcv's gradcheck makes for
+    D in {4, 30, 32, 64, 71, 1025} (test_ms_deformable_attn.py:138-182)."""
+    from pavenet_amd.ops import MultiScaleDeformableAttnFunction
+    N, M, Lq, L, P = 2, 3, 5, 2, 2
+    shapes = torch.as_tensor([(3, 2), (2, 1)], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(D)
+    value = (torch.rand(N, S, M, D, generator=g) * 0.01).to(dtype)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g).to(dtype) * 1.2 - 0.1  # some outside
+    aw = torch.rand(N, Lq, M, L, P, generator=g).to(dtype) + 1e-5
+    aw = aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.rand(N, Lq, M * D, generator=g).to(dtype)
+    ref_in = [t.double().clone().requires_grad_(True) for t in (value, loc, aw)]
+    R.msda_forward_torch(ref_in[0], shapes, ref_in[1], ref_in[2]).backward(gout.double())
+    dev_in = [t.cuda().clone().requires_grad_(True) for t in (value, loc, aw)]
+    out = MultiScaleDeformableAttnFunction.apply(dev_in[0], shapes.cuda(), lsi.cuda(), dev_in[1],
+                                                 dev_in[2], 2)
+    out.backward(gout.cuda())
+    tol = dict(rtol=1e-9, atol=1e-12) if dtype == torch.float64 else dict(rtol=2e-4, atol=1e-6)
+    for a, b in zip(dev_in, ref_in):
+        np.testing.assert_allclose(a.grad.double().cpu().numpy(), b.grad.numpy(), **tol)
