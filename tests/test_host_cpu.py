@@ -157,3 +157,46 @@ def test_reference_config_files_build(golden_dir):
         m = build_model(model)
         want = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))[name]
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == want
+
+
+def test_kpt2json_and_checkpoint_roundtrip(tmp_path):
+    from pavenet_amd.formats import kpt2json, load_checkpoint, results2json
+    det = [np.array([[10., 20., 50., 80., 0.9], [1., 2., 3., 5., 0.4]], dtype=np.float32)]
+    kpt = [np.arange(2 * 15 * 3, dtype=np.float32).reshape(2, 15, 3)]
+    res = [(det, kpt), ([np.zeros((0, 5), np.float32)], [np.zeros((0, 15, 3), np.float32)])]
+    bj, kj = kpt2json(res, img_ids=[7, 8])
+    assert len(bj) == 2 and len(kj) == 2
+    assert bj[0] == dict(image_id=7, bbox=[10.0, 20.0, 40.0, 60.0], score=float(np.float32(0.9)),
+                         category_id=1)
+    assert kj[1]['keypoints'] == list(map(float, range(45, 90))) and kj[1]['image_id'] == 7
+    files = results2json(res, [7, 8], str(tmp_path / 'out'))
+    assert json.load(open(files['keypoints'])) == kj
+    ref = '/root/reference/opera/datasets/posetrack_video_pose.py'
+    if os.path.exists(ref):  # container only: the reference's own method gives the same lists
+        # (in a child process: the import shim patches torch globally)
+        import pickle
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        pickle.dump((res, bj, kj), open(tmp_path / 'io.pkl', 'wb'))
+        code = (
+            "import sys, pickle; sys.path.insert(0, %r); import ref_shim; ref_shim.install()\n"
+            "from opera.datasets.posetrack_video_pose import PosetrackVideoPoseDataset as D\n"
+            "res, bj, kj = pickle.load(open(%r, 'rb'))\n"
+            "class Fake:\n"
+            "    img_ids, cat_ids = [7, 8], [1]\n"
+            "    xyxy2xywh = staticmethod(lambda b: [float(b[0]), float(b[1]), float(b[2]-b[0]), float(b[3]-b[1])])\n"
+            "    def __len__(self): return 2\n"
+            "rb, rk = D._kpt2json(Fake(), res)\n"
+            "assert rk == kj and rb == bj\n"
+            "print('reference agrees')\n") % (os.path.join(root, 'oracle'), str(tmp_path / 'io.pkl'))
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), timeout=300)
+        assert 'reference agrees' in r.stdout, r.stderr[-2000:]
+    # checkpoint helper: 'state_dict' wrapper + DDP 'module.' prefix
+    m = torch.nn.Linear(3, 2)
+    torch.save(dict(state_dict={'module.' + k: v + 1 for k, v in m.state_dict().items()},
+                    meta=dict(epoch=3)), tmp_path / 'c.pth')
+    m2 = torch.nn.Linear(3, 2)
+    ck = load_checkpoint(m2, str(tmp_path / 'c.pth'), strict=True)
+    assert ck['meta']['epoch'] == 3 and torch.equal(m2.weight, m.weight + 1)
