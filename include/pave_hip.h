@@ -171,6 +171,17 @@ int pave_ms_deform_attn_backward_f64(const double* value, const int64_t* spatial
                                      double* grad_attn_weight, int bs, int S, int M, int D, int L,
                                      int Lq, int P, int im2col_step, void* stream);
 
+/*
+ * Device input pipeline for T frames of one clip (mmdet Resize(keep_ratio) -> Normalize(to_rgb)
+ * -> Pad -> MulImageToTensor; configs/_base_/datasets/posetrack17_video_keypoint.py:71-84).
+ *   src   [T, H0, W0, 3] HWC, BGR, uint8 (src_is_u8 = 1) or float32, DEVICE
+ *   dst   [T, 3, Hp, Wp] float32: the (Hn, Wn) resized + normalised image top-left, zeros elsewhere
+ *   mean, std  HOST float[3] (in the order of the channels AFTER the optional BGR->RGB swap)
+ */
+int pave_preprocess_frames(const void* src, int src_is_u8, float* dst, int T, int H0, int W0,
+                           int Hn, int Wn, int Hp, int Wp, const float* mean, const float* std,
+                           int to_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

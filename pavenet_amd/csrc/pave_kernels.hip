@@ -1119,6 +1119,65 @@ int msda_backward_impl(const scalar_t* value, const int64_t* shapes, const int64
   return PAVE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Input pipeline on the device: for T frames at once,
+// keep-ratio bilinear resize (cv2.INTER_LINEAR float semantics: half-pixel centres, edge
+// clamp), BGR->RGB, (x - mean) / std, zero pad to the batch canvas, HWC -> CHW.
+// Restates mmdet Resize / Normalize / Pad / MulImageToTensor
+// (configs/_base_/datasets/posetrack17_video_keypoint.py:71-84, mmcv/image/geometric.py
+// imresize + photometric.py imnormalize).  One thread per output pixel (3 channels).
+// ---------------------------------------------------------------------------
+template <typename src_t>
+__global__ __launch_bounds__(256) void preprocess_frames_kernel(
+    const src_t* __restrict__ src, float* __restrict__ dst, const int T, const int H0,
+    const int W0, const int Hn, const int Wn, const int Hp, const int Wp, const float m0,
+    const float m1, const float m2, const float s0, const float s1, const float s2,
+    const int to_rgb) {
+  const long long n = (long long)T * Hp * Wp;
+  const float sx = (float)W0 / (float)Wn, sy = (float)H0 / (float)Hn;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const int y = (int)((i / Wp) % Hp);
+    const int t = (int)(i / ((long long)Wp * Hp));
+    float c[3] = {0.f, 0.f, 0.f};
+    if (x < Wn && y < Hn) {
+      float fx = ((float)x + 0.5f) * sx - 0.5f, fy = ((float)y + 0.5f) * sy - 0.5f;
+      int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+      fx -= (float)x0;
+      fy -= (float)y0;
+      if (x0 < 0) { x0 = 0; fx = 0.f; }
+      if (x0 >= W0 - 1) { x0 = W0 - 1; fx = 0.f; }
+      if (y0 < 0) { y0 = 0; fy = 0.f; }
+      if (y0 >= H0 - 1) { y0 = H0 - 1; fy = 0.f; }
+      const int x1 = min(x0 + 1, W0 - 1), y1 = min(y0 + 1, H0 - 1);
+      const src_t* f = src + (long long)t * H0 * W0 * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float a = (float)f[((long long)y0 * W0 + x0) * 3 + k];
+        const float b = (float)f[((long long)y0 * W0 + x1) * 3 + k];
+        const float cc = (float)f[((long long)y1 * W0 + x0) * 3 + k];
+        const float d = (float)f[((long long)y1 * W0 + x1) * 3 + k];
+        const float top = a * (1.f - fx) + b * fx, bot = cc * (1.f - fx) + d * fx;
+        c[k] = top * (1.f - fy) + bot * fy;
+      }
+      if (to_rgb) {
+        const float tmp = c[0];
+        c[0] = c[2];
+        c[2] = tmp;
+      }
+      c[0] = (c[0] - m0) * s0;
+      c[1] = (c[1] - m1) * s1;
+      c[2] = (c[2] - m2) * s2;
+    }
+    const long long plane = (long long)Hp * Wp;
+    float* o = dst + (long long)t * 3 * plane + (long long)y * Wp + x;
+    o[0] = c[0];
+    o[plane] = c[1];
+    o[2 * plane] = c[2];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1372,6 +1431,31 @@ int pave_ms_deform_attn_backward_f64(const double* value, const int64_t* spatial
   return msda_backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight,
                                     grad_output, grad_value, grad_sampling_loc, grad_attn_weight,
                                     bs, S, M, D, L, Lq, P, im2col_step, stream);
+}
+
+int pave_preprocess_frames(const void* src, int src_is_u8, float* dst, int T, int H0, int W0,
+                           int Hn, int Wn, int Hp, int Wp, const float* mean, const float* std,
+                           int to_rgb, void* stream) {
+  if (!src || !dst || !mean || !std) return fail(PAVE_E_ARG, "preprocess_frames: null pointer");
+  if (T <= 0 || H0 <= 0 || W0 <= 0 || Hn <= 0 || Wn <= 0 || Hp < Hn || Wp < Wn)
+    return fail(PAVE_E_ARG, "preprocess_frames: bad sizes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long n = (long long)T * Hp * Wp;
+  long long nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  const float s0 = (float)(1.0 / (double)std[0]), s1 = (float)(1.0 / (double)std[1]),
+              s2 = (float)(1.0 / (double)std[2]);
+  if (src_is_u8)
+    hipLaunchKernelGGL((preprocess_frames_kernel<unsigned char>), dim3((unsigned)nb), dim3(256), 0,
+                       st, static_cast<const unsigned char*>(src), dst, T, H0, W0, Hn, Wn, Hp, Wp,
+                       mean[0], mean[1], mean[2], s0, s1, s2, to_rgb);
+  else
+    hipLaunchKernelGGL((preprocess_frames_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st,
+                       static_cast<const float*>(src), dst, T, H0, W0, Hn, Wn, Hp, Wp, mean[0],
+                       mean[1], mean[2], s0, s1, s2, to_rgb);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
 }
 
 }  // extern "C"

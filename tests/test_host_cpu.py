@@ -200,3 +200,14 @@ def test_kpt2json_and_checkpoint_roundtrip(tmp_path):
     m2 = torch.nn.Linear(3, 2)
     ck = load_checkpoint(m2, str(tmp_path / 'c.pth'), strict=True)
     assert ck['meta']['epoch'] == 3 and torch.equal(m2.weight, m.weight + 1)
+
+
+def test_rescale_size_matches_reference_pipeline_shapes():
+    """1080p -> 750 x 1333 (posetrack17_video_keypoint.py:75,81 with size_divisor=1) and
+    640 x 480 COCO -> 800 x 1067 padded to 800 x 1088 (coco_keypoint.py:73,79)."""
+    from oracle import preprocess_ref as PR
+    from pavenet_amd.preprocess import rescale_size
+    assert rescale_size((1920, 1080), (1333, 800)) == (1333, 750)
+    assert rescale_size((640, 480), (1333, 800)) == (1067, 800)
+    for wh in ((1920, 1080), (640, 480), (333, 500), (1333, 800)):
+        assert rescale_size(wh, (1333, 800)) == PR.rescale_size(wh, (1333, 800))

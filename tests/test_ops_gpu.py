@@ -258,3 +258,22 @@ def test_backward_vs_autograd_of_reference_formulation(D, dtype):
     tol = dict(rtol=1e-9, atol=1e-12) if dtype == torch.float64 else dict(rtol=2e-4, atol=1e-6)
     for a, b in zip(dev_in, ref_in):
         np.testing.assert_allclose(a.grad.double().cpu().numpy(), b.grad.numpy(), **tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.float32])
+@pytest.mark.parametrize('hw,div', [((270, 480), 1), ((97, 61), 32), ((120, 160), 32)])
+def test_preprocess_clip_vs_oracle(dtype, hw, div):
+    """Device input pipeline (resize keep-ratio, BGR->RGB, normalise, pad, stack) against the
+    NumPy restatement of the reference's test pipeline."""
+    from oracle import preprocess_ref as PR
+    from pavenet_amd.preprocess import preprocess_clip
+    rng = np.random.default_rng(hw[0] + div)
+    frames = rng.integers(0, 256, size=(3, hw[0], hw[1], 3)).astype(np.uint8)
+    src = _t(frames) if dtype == torch.uint8 else _t(frames.astype(np.float32))
+    scale = (200, 120)
+    out, meta = preprocess_clip(src.cuda(), img_scale=scale, size_divisor=div)
+    exp, emeta = PR.preprocess_clip(frames, img_scale=scale, size_divisor=div)
+    assert tuple(out.shape) == exp.shape and meta['img_shape'] == emeta['img_shape']
+    assert meta['batch_input_shape'] == emeta['batch_input_shape']
+    np.testing.assert_allclose(meta['scale_factor'], emeta['scale_factor'])
+    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=1e-4)  # fma contraction
