@@ -182,6 +182,16 @@ int pave_preprocess_frames(const void* src, int src_is_u8, float* dst, int T, in
                            int Hn, int Wn, int Hp, int Wp, const float* mean, const float* std,
                            int to_rgb, void* stream);
 
+/*
+ * 3x3 convolution, NHWC fp32, pad 1, stride 1 or 2, bias (+ReLU) fused: implicit GEMM on the
+ * exact-fp32 MFMA.  Used for the ResNet / HRNet 3x3 convolutions with BatchNorm folded in
+ * (mmdet resnet.py Bottleneck.conv2 / BasicBlock, hrnet.py).
+ *   x [N, H, W, Cin];  w [3, 3, Cin, Cout] (tap-major, Cout innermost);  bias [Cout] or NULL;
+ *   y [N, Ho, Wo, Cout], Ho = (H - 1)/stride + 1.  Cin %% 32 == 0, Cout %% 64 == 0.
+ */
+int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
+                          int H, int W, int Cin, int Cout, int stride, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

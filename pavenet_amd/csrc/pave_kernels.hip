@@ -1178,6 +1178,141 @@ __global__ __launch_bounds__(256) void preprocess_frames_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 convolution, NHWC fp32, pad 1, stride 1|2, as an implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD) with bias (+ReLU) in the epilogue.
+//   C[M, Cout] = A[M, 9*Cin] * B[9*Cin, Cout],  M = N*Ho*Wo;  A is gathered on the fly: for
+//   tap (ky, kx) and channel slab c0 the 32-channel segment of input pixel
+//   (oy*s + ky - 1, ox*s + kx - 1) is 128 contiguous bytes (zero outside the image).
+// Block = 256 threads, tile 128 (pixels) x BN (64 | 128 output channels), K-slab 32.
+// LDS: A[128][33] (row stride 33 floats: the 32 lanes of an MFMA operand read 32 different
+// rows at one k -> conflict-free) and B[32][BN].  Wave tile: 64x64 (BN=128: 2x2 waves) or
+// 32x64 (BN=64: 4x1 waves) as 32x32 accumulator tiles.
+// Replaces MIOpen's fp32 igemm / CK grouped conv (48 TFLOP/s on the bench workload) plus the
+// separate bias / ReLU passes for the ResNet / HRNet 3x3 convolutions.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, const int N, const int H, const int W, const int Cin, const int Cout,
+    const int Ho, const int Wo, const int stride, const int relu) {
+  constexpr int BM = 128, BK = 32, AST = 33;
+  constexpr int TM = (BN == 128) ? 2 : 1, TN = 2;
+  constexpr int WM = TM * 32, WN = TN * 32;
+  __shared__ float As[BM * AST];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (BN == 128) ? (wave >> 1) * WM : wave * WM;
+  const int wn0 = (BN == 128) ? (wave & 1) * WN : 0;
+  const long long M = (long long)N * Ho * Wo;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // the 4 pixels whose 16-byte segment `seg` this thread stages per K-slab
+  const int seg = tid & 7;
+  int iy0[4], ix0[4];
+  long long nbase[4];
+  bool pvalid[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long gm = m0 + (tid >> 3) + q * 32;
+    pvalid[q] = gm < M;
+    const long long g = pvalid[q] ? gm : 0;
+    const int ox = (int)(g % Wo);
+    const int oy = (int)((g / Wo) % Ho);
+    const int n = (int)(g / ((long long)Wo * Ho));
+    iy0[q] = oy * stride - 1;
+    ix0[q] = ox * stride - 1;
+    nbase[q] = (long long)n * H * W;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  constexpr int BV = (BK * BN) / (256 * 4);  // float4 per thread for B
+  const int cslabs = Cin / BK;
+  const int nslabs = 9 * cslabs;
+  float4 av[4], bv[BV];
+  // global -> registers for one K-slab (tap, 32 channels): issued one slab ahead so that the
+  // loads are in flight while the MFMAs of the current slab run
+  auto load_slab = [&](int slab) {
+    const int tap = slab / cslabs, c0 = (slab - tap * cslabs) * BK;
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+      const bool ok = pvalid[q] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      av[q] = ok ? *reinterpret_cast<const float4*>(
+                       x + (nbase[q] + (long long)iy * W + ix) * Cin + c0 + seg * 4)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* wrow = w + ((long long)tap * Cin + c0) * Cout + n0;
+#pragma unroll
+    for (int q = 0; q < BV; ++q) {
+      const int idx = tid + q * 256;          // float4 index in the [32][BN] tile
+      const int kr = idx / (BN / 4), nc = (idx - kr * (BN / 4)) * 4;
+      bv[q] = *reinterpret_cast<const float4*>(wrow + (long long)kr * Cout + nc);
+    }
+  };
+  load_slab(0);
+  for (int slab = 0; slab < nslabs; ++slab) {
+    __syncthreads();  // previous slab fully consumed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* d = As + ((tid >> 3) + q * 32) * AST + seg * 4;
+      d[0] = av[q].x;
+      d[1] = av[q].y;
+      d[2] = av[q].z;
+      d[3] = av[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < BV; ++q) *reinterpret_cast<float4*>(Bs + (tid + q * 256) * 4) = bv[q];
+    __syncthreads();
+    if (slab + 1 < nslabs) load_slab(slab + 1);
+    // ---- 16 k-steps of 2
+#pragma unroll 4
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(wm0 + i * 32 + lrow) * AST + kk * 2 + lk];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) b[jn] = Bs[(kk * 2 + lk) * BN + wn0 + jn * 32 + lrow];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: bias (+ReLU), C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int col = n0 + wn0 + jn * 32 + lrow;
+      const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowi = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const long long gm = m0 + rowi;
+        if (gm < M) {
+          float v = acc[i][jn][r] + bb;
+          if (relu) v = fmaxf(v, 0.f);
+          y[gm * Cout + col] = v;
+        }
+      }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1453,6 +1588,29 @@ int pave_preprocess_frames(const void* src, int src_is_u8, float* dst, int T, in
     hipLaunchKernelGGL((preprocess_frames_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st,
                        static_cast<const float*>(src), dst, T, H0, W0, Hn, Wn, Hp, Wp, mean[0],
                        mean[1], mean[2], s0, s1, s2, to_rgb);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
+                          int H, int W, int Cin, int Cout, int stride, int relu, void* stream) {
+  if (!x || !w || !y) return fail(PAVE_E_ARG, "conv3x3_nhwc: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2))
+    return fail(PAVE_E_ARG, "conv3x3_nhwc: bad sizes (stride 1 or 2)");
+  if (Cin % 32 != 0 || Cout % 64 != 0)
+    return fail(PAVE_E_ARG, "conv3x3_nhwc: Cin %% 32 == 0 and Cout %% 64 == 0 required");
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  const long long gx = (M + 127) / 128;
+  if (gx >= (1ll << 31)) return fail(PAVE_E_ARG, "conv3x3_nhwc: grid too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (Cout % 128 == 0)
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<128>), dim3((unsigned)gx, Cout / 128), dim3(256), 0, st,
+                       x, w, bias, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+  else
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<64>), dim3((unsigned)gx, Cout / 64), dim3(256), 0, st, x,
+                       w, bias, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

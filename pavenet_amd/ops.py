@@ -349,3 +349,25 @@ def deform_attn_enc_window(value, spatial_shapes, level_start_index, proj, ref, 
             _stream_ptr())
     native.check(st, 'deform_attn_enc_window')
     return out
+
+
+def conv3x3_nhwc(x, w_taps, bias, stride=1, relu=False):
+    """3x3 / pad 1 convolution of a channels_last map on the fp32 MFMA, bias (+ReLU) fused.
+    x [N, Cin, H, W] in channels_last storage; w_taps [3, 3, Cin, Cout] contiguous;
+    -> [N, Cout, Ho, Wo] channels_last."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv3x3_nhwc: fp32 4-D')
+    _require(x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_nhwc: channels_last input')
+    _dev(w_taps, 'w_taps', torch.float32)
+    N, Cin, H, W = x.shape
+    _require(tuple(w_taps.shape[:3]) == (3, 3, Cin), 'conv3x3_nhwc: weight must be [3,3,Cin,Cout]')
+    Cout = w_taps.shape[3]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _Timed('conv3x3'):
+        st = lib.pave_conv3x3_nhwc_f32(x.data_ptr(), w_taps.data_ptr(),
+                                       bias.data_ptr() if bias is not None else None,
+                                       y.data_ptr(), N, H, W, Cin, Cout, int(stride),
+                                       int(bool(relu)), _stream_ptr())
+    native.check(st, 'conv3x3_nhwc')
+    return y.permute(0, 3, 1, 2)

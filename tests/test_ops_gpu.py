@@ -277,3 +277,23 @@ def test_preprocess_clip_vs_oracle(dtype, hw, div):
     assert meta['batch_input_shape'] == emeta['batch_input_shape']
     np.testing.assert_allclose(meta['scale_factor'], emeta['scale_factor'])
     np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=1e-4)  # fma contraction
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 64, 64, 1), (1, 20, 9, 128, 128, 1),
+                                                   (3, 14, 22, 128, 256, 2), (1, 7, 5, 32, 192, 1),
+                                                   (2, 9, 9, 256, 64, 2)])
+def test_conv3x3_mfma_vs_torch(N, H, W, Cin, Cout, stride):
+    """Implicit-GEMM 3x3 convolution on the exact-fp32 MFMA (+bias, +ReLU) vs F.conv2d on the CPU."""
+    from pavenet_amd.ops import conv3x3_nhwc
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin**0.5)
+    b = torch.randn(Cout, generator=g)
+    for relu in (False, True):
+        exp = torch.nn.functional.conv2d(x, w, b, stride, 1)
+        exp = torch.relu(exp) if relu else exp
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        wt = w.permute(2, 3, 1, 0).contiguous().cuda()  # [3, 3, Cin, Cout]
+        out = conv3x3_nhwc(xd, wt, b.cuda(), stride=stride, relu=relu)
+        assert out.shape == exp.shape
+        np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
