@@ -192,6 +192,24 @@ int pave_preprocess_frames(const void* src, int src_is_u8, float* dst, int T, in
 int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
                           int H, int W, int Cin, int Cout, int stride, int relu, void* stream);
 
+/*
+ * Row GEMM with the whole Bottleneck tail in its epilogue:
+ *   out[M, N] = act(a[M, K] * w[K, N] + bias[N] + residual[M, N])      (fp32 MFMA, exact fp32)
+ * = mmdet resnet.py:264-283 `conv3 -> bn3 -> += identity -> relu` on the NHWC map (BatchNorm
+ * folded into w / bias).  `residual` may be NULL or alias `out` (every element is read before it
+ * is written by the same lane).  K %% 32 == 0, N %% 64 == 0, M < 2^31.
+ */
+int pave_rows_gemm_bias_res_act_f32(const float* a, const float* w, const float* bias,
+                                    const float* residual, float* out, long long M, int K, int N,
+                                    int relu, void* stream);
+
+/*
+ * ResNet stem tail in one pass (resnet.py:640-645 `norm1 -> relu -> maxpool` with BN folded):
+ *   y[N, Ho, Wo, C] = maxpool3x3/s2/p1(relu(x[N, H, W, C] + bias[C])),  Ho = (H - 1)/2 + 1.
+ */
+int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y, int N, int H,
+                                    int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,11 @@ class ResNet(BaseModule):
         self.feat_dim = inplanes
         self._folded = None
         self.channels_last = True
+        # Bottleneck tails (conv3 + bn3 + identity + ReLU) with K = planes up to this run as ONE
+        # hand-written MFMA kernel; above it hipBLASLt + a bias/ReLU pass is faster (measured,
+        # tools/bench_gemm_shapes.py: K=64 1.14 vs 1.84 ms, 128: 0.81 vs 1.04, 256: 0.68 vs 0.73,
+        # 512: 0.64 vs 0.58)
+        self.fused_tail_max_k = 256
 
     def init_weights(self):
         for m in self.modules():
@@ -145,6 +150,10 @@ class ResNet(BaseModule):
                     for cn, bn, _ in blk.pairs:
                         w, b = _fold(getattr(blk, cn), getattr(blk, bn))
                         f[(name, bi, cn)] = (w.contiguous(memory_format=mf), b)
+                        if cn == 'conv3' and w.shape[1] <= self.fused_tail_max_k \
+                                and w.shape[1] % 32 == 0:
+                            # [K, N] operand of pave_rows_gemm_bias_res_act_f32
+                            f[(name, bi, 'conv3_kn')] = w.flatten(1).t().contiguous()
                     if blk.downsample is not None:
                         w, b = _fold(blk.downsample[0], blk.downsample[1])
                         f[(name, bi, 'ds')] = (w.contiguous(memory_format=mf), b)
@@ -177,14 +186,23 @@ class ResNet(BaseModule):
         ops.bias_act_rows_(y, b2, None, relu=True)                        # bn2 + relu, one pass
         yrows, onhw = self._as_rows(y)
         w3, b3 = f[(name, bi, 'conv3')]
+        w3_kn = f.get((name, bi, 'conv3_kn'))
         if blk.downsample is not None:
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
             xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
             xrows, _ = self._as_rows(xs)
             idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())          # both biases here
-            out = torch.addmm(idt, yrows, w3.flatten(1).t())
-            ops.bias_act_rows_(out, None, None, relu=True)
+            if w3_kn is not None:                                         # += y @ W3, ReLU: one pass
+                out = ops.rows_gemm_bias_res_act(yrows, w3_kn, None, idt, relu=True, out=idt)
+            else:
+                out = torch.addmm(idt, yrows, w3.flatten(1).t())
+                ops.bias_act_rows_(out, None, None, relu=True)
+        elif w3_kn is not None:
+            # conv3 + bn3 + identity + ReLU as one MFMA kernel; a temporary identity is
+            # overwritten in place
+            out = ops.rows_gemm_bias_res_act(yrows, w3_kn, b3, rows, relu=True,
+                                             out=rows if inplace_identity else None)
         elif inplace_identity:
             out = rows.addmm_(yrows, w3.flatten(1).t())                   # identity += y @ W3
             ops.bias_act_rows_(out, b3, None, relu=True)
@@ -205,10 +223,10 @@ class ResNet(BaseModule):
         w, b = f['stem']
         if gemm_path:
             from . import ops
-            x = ops.bias_act_rows_(F.conv2d(x, w, None, 2, 3), b, None, relu=True)
+            # bn1 + relu + maxpool in one pass over the stem map
+            x = ops.bias_relu_maxpool_nhwc(F.conv2d(x, w, None, 2, 3), b)
         else:
-            x = F.relu_(F.conv2d(x, w, b, 2, 3))
-        x = self.maxpool(x)
+            x = self.maxpool(F.relu_(F.conv2d(x, w, b, 2, 3)))
         outs = []
         for i, name in enumerate(self.res_layers):
             for bi, blk in enumerate(getattr(self, name)):

@@ -1179,37 +1179,45 @@ __global__ __launch_bounds__(256) void preprocess_frames_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 convolution, NHWC fp32, pad 1, stride 1|2, as an implicit GEMM on the fp32 MFMA
-// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD) with bias (+ReLU) in the epilogue.
-//   C[M, Cout] = A[M, 9*Cin] * B[9*Cin, Cout],  M = N*Ho*Wo;  A is gathered on the fly: for
-//   tap (ky, kx) and channel slab c0 the 32-channel segment of input pixel
-//   (oy*s + ky - 1, ox*s + kx - 1) is 128 contiguous bytes (zero outside the image).
+// KSxKS convolution (KS = 3: pad 1, stride 1|2;  KS = 1: a row GEMM), NHWC fp32, as an implicit
+// GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD) with
+// bias (+residual) (+ReLU) in the epilogue.
+//   C[M, Cout] = A[M, KS*KS*Cin] * B[KS*KS*Cin, Cout],  M = N*Ho*Wo;  A is gathered on the fly:
+//   for tap (ky, kx) and channel slab c0 the 32-channel segment of input pixel
+//   (oy*s + ky - pad, ox*s + kx - pad) is 128 contiguous bytes (zero outside the image).
 // Block = 256 threads, tile 128 (pixels) x BN (64 | 128 output channels), K-slab 32.
 // LDS: A[128][33] (row stride 33 floats: the 32 lanes of an MFMA operand read 32 different
 // rows at one k -> conflict-free) and B[32][BN].  Wave tile: 64x64 (BN=128: 2x2 waves) or
 // 32x64 (BN=64: 4x1 waves) as 32x32 accumulator tiles.
-// Replaces MIOpen's fp32 igemm / CK grouped conv (48 TFLOP/s on the bench workload) plus the
-// separate bias / ReLU passes for the ResNet / HRNet 3x3 convolutions.
+// Grid is 1-D with the Cout tile fastest, so the blocks sharing an A tile run back to back.
+// Measured (tools/bench_conv.py, 28 frames): 87-100 TFLOP/s on the R-50 3x3 shapes, MIOpen's
+// searched fp32 kernels reach 110-128 there, so the model keeps MIOpen for 3x3; the KS = 1
+// instance with the residual epilogue replaces hipBLASLt GEMM + a separate bias/ReLU pass on the
+// bandwidth-bound 1x1 expansions of ResNet layer1/layer2 (K = 64 / 128).
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kConvSmemFloats = 128 * 68;  // >= operand tiles (128*33 + 32*128) and epilogue chunk
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
+template <int BN, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ y, const int N, const int H, const int W, const int Cin, const int Cout,
-    const int Ho, const int Wo, const int stride, const int relu) {
+    const float* residual, float* y, const int N, const int H, const int W, const int Cin,
+    const int Cout, const int Ho, const int Wo, const int stride, const int relu) {
+  constexpr int PAD = KS / 2, TAPS = KS * KS;
   constexpr int BM = 128, BK = 32, AST = 33;
   constexpr int TM = (BN == 128) ? 2 : 1, TN = 2;
   constexpr int WM = TM * 32, WN = TN * 32;
-  __shared__ float As[BM * AST];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  __shared__ __attribute__((aligned(16))) float smem[kConvSmemFloats];
+  float* As = smem;                  // [BM][AST]
+  float* Bs = smem + BM * AST;       // [BK][BN]   (BM*AST*4 is a multiple of 16)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (BN == 128) ? (wave >> 1) * WM : wave * WM;
   const int wn0 = (BN == 128) ? (wave & 1) * WN : 0;
   const long long M = (long long)N * Ho * Wo;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const int ntiles = Cout / BN;
+  const long long m0 = (long long)(blockIdx.x / ntiles) * BM;
+  const int n0 = (blockIdx.x % ntiles) * BN;
 
   // the 4 pixels whose 16-byte segment `seg` this thread stages per K-slab
   const int seg = tid & 7;
@@ -1220,12 +1228,13 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
   for (int q = 0; q < 4; ++q) {
     const long long gm = m0 + (tid >> 3) + q * 32;
     pvalid[q] = gm < M;
-    const long long g = pvalid[q] ? gm : 0;
-    const int ox = (int)(g % Wo);
-    const int oy = (int)((g / Wo) % Ho);
-    const int n = (int)(g / ((long long)Wo * Ho));
-    iy0[q] = oy * stride - 1;
-    ix0[q] = ox * stride - 1;
+    const unsigned g = pvalid[q] ? (unsigned)gm : 0u;  // host guarantees M < 2^31
+    const unsigned gy = g / (unsigned)Wo;
+    const int ox = (int)(g - gy * (unsigned)Wo);
+    const int n = (int)(gy / (unsigned)Ho);
+    const int oy = (int)(gy - (unsigned)n * (unsigned)Ho);
+    iy0[q] = oy * stride - PAD;
+    ix0[q] = ox * stride - PAD;
     nbase[q] = (long long)n * H * W;
   }
 
@@ -1240,30 +1249,29 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
   const int lrow = lane & 31, lk = lane >> 5;
   constexpr int BV = (BK * BN) / (256 * 4);  // float4 per thread for B
   const int cslabs = Cin / BK;
-  const int nslabs = 9 * cslabs;
+  const int nslabs = TAPS * cslabs;
   float4 av[4], bv[BV];
   // global -> registers for one K-slab (tap, 32 channels): issued one slab ahead so that the
   // loads are in flight while the MFMAs of the current slab run
-  auto load_slab = [&](int slab) {
-    const int tap = slab / cslabs, c0 = (slab - tap * cslabs) * BK;
-    const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int iy = iy0[q] + ky, ix = ix0[q] + kx;
-      const bool ok = pvalid[q] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      av[q] = ok ? *reinterpret_cast<const float4*>(
-                       x + (nbase[q] + (long long)iy * W + ix) * Cin + c0 + seg * 4)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float* wrow = w + ((long long)tap * Cin + c0) * Cout + n0;
-#pragma unroll
-    for (int q = 0; q < BV; ++q) {
-      const int idx = tid + q * 256;          // float4 index in the [32][BN] tile
-      const int kr = idx / (BN / 4), nc = (idx - kr * (BN / 4)) * 4;
-      bv[q] = *reinterpret_cast<const float4*>(wrow + (long long)kr * Cout + nc);
-    }
-  };
-  load_slab(0);
+#define PAVE_CONV_LOAD_SLAB(slab_)                                                              \
+  {                                                                                             \
+    const int tap_ = (slab_) / cslabs, c0_ = ((slab_) - tap_ * cslabs) * BK;                     \
+    const int ky_ = tap_ / KS, kx_ = tap_ - ky_ * KS;                                            \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+      const int iy = iy0[q] + ky_, ix = ix0[q] + kx_;                                            \
+      const bool ok = pvalid[q] && iy >= 0 && iy < H && ix >= 0 && ix < W;                       \
+      const float* src_ = ok ? x + (nbase[q] + (long long)iy * W + ix) * Cin + c0_ + seg * 4 : x; \
+      const float4 t_ = *reinterpret_cast<const float4*>(src_);                                  \
+      av[q] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);                                         \
+    }                                                                                           \
+    const float* wrow_ = w + ((long long)tap_ * Cin + c0_) * Cout + n0;                          \
+    _Pragma("unroll") for (int q = 0; q < BV; ++q) {                                            \
+      const int idx = tid + q * 256; /* float4 index in the [32][BN] tile */                     \
+      const int kr = idx / (BN / 4), nc = (idx - kr * (BN / 4)) * 4;                             \
+      bv[q] = *reinterpret_cast<const float4*>(wrow_ + (long long)kr * Cout + nc);               \
+    }                                                                                           \
+  }
+  PAVE_CONV_LOAD_SLAB(0)
   for (int slab = 0; slab < nslabs; ++slab) {
     __syncthreads();  // previous slab fully consumed
 #pragma unroll
@@ -1277,7 +1285,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
 #pragma unroll
     for (int q = 0; q < BV; ++q) *reinterpret_cast<float4*>(Bs + (tid + q * 256) * 4) = bv[q];
     __syncthreads();
-    if (slab + 1 < nslabs) load_slab(slab + 1);
+    if (slab + 1 < nslabs) PAVE_CONV_LOAD_SLAB(slab + 1)
     // ---- 16 k-steps of 2
 #pragma unroll 4
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -1293,24 +1301,112 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
     }
   }
-  // ---- epilogue: bias (+ReLU), C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) +
+  // 4*(lane>>5)) go through LDS in chunks of CR rows so that bias / residual / ReLU / store run
+  // on float4 with whole BN*4-byte row segments per wave (4-byte stores straight from the MFMA
+  // layout reach only half the HBM write rate).
+  constexpr int CST = BN + 4;             // chunk row stride (floats), keeps float4 alignment
+  constexpr int CR = (BN == 128) ? 64 : 128;
+  constexpr int RV = BN / 4;              // float4 per chunk row
+  constexpr int RPP = 256 / RV;           // rows per pass of the block
+  constexpr int NPASS = CR / RPP;         // = 8
+  static_assert(CR * CST <= kConvSmemFloats, "epilogue chunk must fit the staging buffer");
+  float* Cs = smem;
+  const int g = wm0 / WM;                 // wave row group
+  const int c4 = tid % RV;
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n0 + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();  // operand tiles (i = 0) / previous chunk (i > 0) fully consumed
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int col = n0 + wn0 + jn * 32 + lrow;
-      const float bb = bias ? bias[col] : 0.f;
+    for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rowi = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const long long gm = m0 + rowi;
-        if (gm < M) {
-          float v = acc[i][jn][r] + bb;
-          if (relu) v = fmaxf(v, 0.f);
-          y[gm * Cout + col] = v;
-        }
+        const int lr = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        Cs[lr * CST + wn0 + jn * 32 + lrow] = acc[i][jn][r];
+      }
+    __syncthreads();
+    float4 res[NPASS];
+    if (residual) {  // all loads in flight before the first store
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int lr = ps * RPP + tid / RV;
+        const long long gm = m0 + (lr >> 5) * WM + i * 32 + (lr & 31);
+        res[ps] = gm < M ? *reinterpret_cast<const float4*>(residual + gm * Cout + n0 + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int lr = ps * RPP + tid / RV;
+      const long long gm = m0 + (lr >> 5) * WM + i * 32 + (lr & 31);
+      if (gm < M) {
+        float4 v = *reinterpret_cast<const float4*>(Cs + lr * CST + c4 * 4);
+        v.x += b4.x;
+        v.y += b4.y;
+        v.z += b4.z;
+        v.w += b4.w;
+        if (residual) {
+          v.x += res[ps].x;
+          v.y += res[ps].y;
+          v.z += res[ps].z;
+          v.w += res[ps].w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + gm * Cout + n0 + c4 * 4) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ResNet stem tail in one pass: y = maxpool3x3/s2/p1(relu(x + bias)) on an NHWC map
+// (= relu(max(x) + bias): bias is per channel and ReLU is monotonic).  One thread = one
+// output pixel x 4 channels; the 16 lanes of a 64-channel pixel read 256 contiguous bytes.
+// Replaces a bias/ReLU pass (read + write of the 400x672 map) + MaxPool2d (resnet.py:640-645).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
+    const int N, const int H, const int W, const int C, const int Ho, const int Wo) {
+  const int c4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long long pix = i / c4;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long long n = pix / ((long long)Wo * Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v =
+            *reinterpret_cast<const float4*>(x + ((n * H + iy) * W + ix) * C + c);
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+      }
+    }
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    m.x = fmaxf(m.x + b.x, 0.f);
+    m.y = fmaxf(m.y + b.y, 0.f);
+    m.z = fmaxf(m.z + b.z, 0.f);
+    m.w = fmaxf(m.w + b.w, 0.f);
+    *reinterpret_cast<float4*>(y + pix * C + c) = m;
+  }
 }
 
 }  // namespace
@@ -1602,15 +1698,55 @@ int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, flo
     return fail(PAVE_E_ARG, "conv3x3_nhwc: Cin %% 32 == 0 and Cout %% 64 == 0 required");
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   const long long M = (long long)N * Ho * Wo;
-  const long long gx = (M + 127) / 128;
+  const int bn = Cout % 128 == 0 ? 128 : 64;
+  const long long gx = ((M + 127) / 128) * (Cout / bn);
   if (gx >= (1ll << 31)) return fail(PAVE_E_ARG, "conv3x3_nhwc: grid too large");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (Cout % 128 == 0)
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<128>), dim3((unsigned)gx, Cout / 128), dim3(256), 0, st,
-                       x, w, bias, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+  if (bn == 128)
+    hipLaunchKernelGGL((conv_nhwc_kernel<128, 3>), dim3((unsigned)gx), dim3(256), 0, st, x, w, bias,
+                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
   else
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<64>), dim3((unsigned)gx, Cout / 64), dim3(256), 0, st, x,
-                       w, bias, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+    hipLaunchKernelGGL((conv_nhwc_kernel<64, 3>), dim3((unsigned)gx), dim3(256), 0, st, x, w, bias,
+                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_rows_gemm_bias_res_act_f32(const float* a, const float* w, const float* bias,
+                                    const float* residual, float* out, long long M, int K, int Nc,
+                                    int relu, void* stream) {
+  if (!a || !w || !out) return fail(PAVE_E_ARG, "rows_gemm: null pointer");
+  if (M <= 0 || K <= 0 || Nc <= 0 || M >= (1ll << 31))
+    return fail(PAVE_E_ARG, "rows_gemm: bad sizes (0 < M < 2^31)");
+  if (K % 32 != 0 || Nc % 64 != 0)
+    return fail(PAVE_E_ARG, "rows_gemm: K %% 32 == 0 and N %% 64 == 0 required");
+  const int bn = Nc % 128 == 0 ? 128 : 64;
+  const long long gx = ((M + 127) / 128) * (Nc / bn);
+  if (gx >= (1ll << 31)) return fail(PAVE_E_ARG, "rows_gemm: grid too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // a 1x1 convolution over a 1 x M "image"
+  if (bn == 128)
+    hipLaunchKernelGGL((conv_nhwc_kernel<128, 1>), dim3((unsigned)gx), dim3(256), 0, st, a, w, bias,
+                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu);
+  else
+    hipLaunchKernelGGL((conv_nhwc_kernel<64, 1>), dim3((unsigned)gx), dim3(256), 0, st, a, w, bias,
+                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y, int N, int H,
+                                    int W, int C, void* stream) {
+  if (!x || !bias || !y) return fail(PAVE_E_ARG, "bias_relu_maxpool: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0)
+    return fail(PAVE_E_ARG, "bias_relu_maxpool: bad sizes (C %% 4 == 0)");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  const long long nb = std::min<long long>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)nb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, bias, y, N, H, W, C, Ho, Wo);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -371,3 +371,52 @@ def conv3x3_nhwc(x, w_taps, bias, stride=1, relu=False):
                                        int(bool(relu)), _stream_ptr())
     native.check(st, 'conv3x3_nhwc')
     return y.permute(0, 3, 1, 2)
+
+
+def rows_gemm_bias_res_act(a, w_kn, bias=None, residual=None, relu=False, out=None):
+    """out[M, N] = act(a[M, K] @ w_kn[K, N] + bias + residual) on the fp32 MFMA, one pass
+    (the Bottleneck tail `conv3 -> bn3 -> += identity -> relu`, resnet.py:264-283).
+    `residual` may be the tensor given as `out` (in-place accumulate into the identity)."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(w_kn, 'w_kn', torch.float32)
+    _require(a.dim() == 2 and w_kn.dim() == 2 and a.shape[1] == w_kn.shape[0],
+             'rows_gemm: a [M,K], w [K,N]')
+    M, K = a.shape
+    N = w_kn.shape[1]
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == N, 'rows_gemm: bias [N]')
+    if residual is not None:
+        _dev(residual, 'residual', torch.float32)
+        _require(tuple(residual.shape) == (M, N), 'rows_gemm: residual [M,N]')
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _dev(out, 'out', torch.float32)
+        _require(tuple(out.shape) == (M, N), 'rows_gemm: out [M,N]')
+    with torch.cuda.device(a.device), _Timed('rows_gemm'):
+        st = lib.pave_rows_gemm_bias_res_act_f32(
+            a.data_ptr(), w_kn.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None, out.data_ptr(), M, K, N,
+            int(bool(relu)), _stream_ptr())
+    native.check(st, 'rows_gemm_bias_res_act')
+    return out
+
+
+def bias_relu_maxpool_nhwc(x, bias):
+    """maxpool3x3/s2/p1(relu(x + bias)) of a channels_last map in one pass (ResNet stem tail)."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'bias_relu_maxpool: fp32 4-D')
+    _require(x.is_contiguous(memory_format=torch.channels_last),
+             'bias_relu_maxpool: channels_last input')
+    _dev(bias, 'bias', torch.float32)
+    N, C, H, W = x.shape
+    _require(bias.numel() == C, 'bias_relu_maxpool: bias [C]')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _Timed('stem_pool'):
+        st = lib.pave_bias_relu_maxpool_nhwc_f32(x.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                 N, H, W, C, _stream_ptr())
+    native.check(st, 'bias_relu_maxpool_nhwc')
+    return y.permute(0, 3, 1, 2)

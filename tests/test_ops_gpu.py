@@ -297,3 +297,40 @@ def test_conv3x3_mfma_vs_torch(N, H, W, Cin, Cout, stride):
         out = conv3x3_nhwc(xd, wt, b.cuda(), stride=stride, relu=relu)
         assert out.shape == exp.shape
         np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('M,K,N', [(1000, 64, 256), (129, 128, 512), (5, 32, 64), (4096, 256, 192)])
+def test_rows_gemm_bias_res_act_vs_torch(M, K, N):
+    """Bottleneck tail as one kernel: relu(a @ w + bias + identity), incl. in-place identity."""
+    from pavenet_amd.ops import rows_gemm_bias_res_act
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    exp = a.double() @ w.double() + b.double()
+    out = rows_gemm_bias_res_act(ad, wd, bd)
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+    out = rows_gemm_bias_res_act(ad, wd, None, r.cuda(), relu=True)
+    np.testing.assert_allclose(out.cpu().numpy(),
+                               torch.relu(a.double() @ w.double() + r.double()).numpy(),
+                               rtol=1e-4, atol=1e-4)
+    idt = r.cuda()
+    out = rows_gemm_bias_res_act(ad, wd, bd, idt, relu=True, out=idt)  # accumulate into identity
+    assert out.data_ptr() == idt.data_ptr()
+    np.testing.assert_allclose(out.cpu().numpy(), torch.relu(exp + r.double()).numpy(),
+                               rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('N,H,W,C', [(2, 16, 24, 64), (1, 15, 9, 64), (3, 7, 8, 32)])
+def test_bias_relu_maxpool_vs_torch(N, H, W, C):
+    """Stem tail: maxpool3x3/s2/p1(relu(x + b)) in one pass == torch's two ops (bit-exact)."""
+    from pavenet_amd.ops import bias_relu_maxpool_nhwc
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    b = torch.randn(C, generator=g)
+    exp = torch.nn.functional.max_pool2d(torch.relu(x + b[None, :, None, None]), 3, 2, 1)
+    out = bias_relu_maxpool_nhwc(x.cuda().contiguous(memory_format=torch.channels_last), b.cuda())
+    assert out.shape == exp.shape
+    assert torch.equal(out.cpu(), exp)
