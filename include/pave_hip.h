@@ -193,15 +193,19 @@ int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, flo
                           int H, int W, int Cin, int Cout, int stride, int relu, void* stream);
 
 /*
- * Row GEMM with the whole Bottleneck tail in its epilogue:
- *   out[M, N] = act(a[M, K] * w[K, N] + bias[N] + residual[M, N])      (fp32 MFMA, exact fp32)
- * = mmdet resnet.py:264-283 `conv3 -> bn3 -> += identity -> relu` on the NHWC map (BatchNorm
- * folded into w / bias).  `residual` may be NULL or alias `out` (every element is read before it
- * is written by the same lane).  K %% 32 == 0, N %% 64 == 0, M < 2^31.
+ * Row GEMM with the whole Bottleneck tail in its prologue / epilogue (fp32 MFMA, exact fp32):
+ *   A1 = a_bias ? relu(a[M, K] + a_bias[K]) : a            (conv2's folded bn2 + ReLU on load)
+ *   out[M, N] = act([A1 | a2[M, K2]] * w[K + K2, N] + bias[N] + residual[M, N])
+ * = mmdet resnet.py:264-283 `bn2 -> relu -> conv3 -> bn3 -> (+ downsample(x) | + identity) ->
+ * relu` on the NHWC map (BatchNorm folded into w / bias; the downsample 1x1 convolution is the
+ * second K range, w = [W3; Wd]).  a_bias, a2 (with K2 = 0), bias, residual may be NULL;
+ * `residual` may alias `out` (every element is read before it is written by the same lane).
+ * K %% 32 == 0, K2 %% 32 == 0, N %% 64 == 0, M < 2^31.
  */
-int pave_rows_gemm_bias_res_act_f32(const float* a, const float* w, const float* bias,
-                                    const float* residual, float* out, long long M, int K, int N,
-                                    int relu, void* stream);
+int pave_rows_gemm_bias_res_act_f32(const float* a, const float* a_bias, const float* a2,
+                                    const float* w, const float* bias, const float* residual,
+                                    float* out, long long M, int K, int K2, int N, int relu,
+                                    void* stream);
 
 /*
  * ResNet stem tail in one pass (resnet.py:640-645 `norm1 -> relu -> maxpool` with BN folded):

@@ -279,6 +279,9 @@ def gen_petr(which=None):
         def tapped_forward(*a, **k):
             out = head_forward(*a, **k)
             taps['cls_all'] = out[0].detach().clone()
+            # enc_outputs_class [B, S, 1]: out[2] for PETRHead, out[3] for VedPoseHeadV2
+            taps['enc_cls'] = next(o for o in out[2:4] if o.dim() == 3 and o.shape[-1] == 1
+                                   ).detach().clone()
             return out
 
         model.bbox_head.forward = tapped_forward
@@ -292,7 +295,8 @@ def gen_petr(which=None):
         det_bboxes, det_labels, det_kpts = res[0]
         N = model.bbox_head.test_cfg['max_per_img']
         score_topk = taps['cls_all'][-1][0].sigmoid().view(-1).topk(N)[1]
-        _save(name, keys=keys, img=img, img_shape=np.array([120, 150, 3]),
+        enc_topk = torch.topk(taps['enc_cls'][..., 0], model.bbox_head.num_query, dim=1)[1]
+        _save(name, keys=keys, img=img, img_shape=np.array([120, 150, 3]), enc_topk=enc_topk,
               memory=taps['memory'], hs=taps['hs'], inter_references=taps['inter_references'],
               cls_last=taps['cls_all'][-1], score_topk=score_topk, det_bboxes=det_bboxes,
               det_labels=det_labels, det_kpts=det_kpts)

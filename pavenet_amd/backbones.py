@@ -117,6 +117,12 @@ class ResNet(BaseModule):
         # tools/bench_gemm_shapes.py: K=64 1.14 vs 1.84 ms, 128: 0.81 vs 1.04, 256: 0.68 vs 0.73,
         # 512: 0.64 vs 0.58)
         self.fused_tail_max_k = 256
+        self.fused_ds_max_k = 384     # conv3 + downsample in one kernel up to this K1 + K2
+        # 3x3 convolutions: MIOpen's searched fp32 kernels are 10-30 % faster than the
+        # hand-written MFMA implicit GEMM (tools/bench_conv.py) but NOT run-to-run deterministic
+        # (tools/debug_determinism.py); True routes them through pave_conv3x3_nhwc_f32
+        # (bit-reproducible, bn2 + ReLU in its epilogue).
+        self.deterministic_conv3x3 = False
 
     def init_weights(self):
         for m in self.modules():
@@ -150,6 +156,9 @@ class ResNet(BaseModule):
                     for cn, bn, _ in blk.pairs:
                         w, b = _fold(getattr(blk, cn), getattr(blk, bn))
                         f[(name, bi, cn)] = (w.contiguous(memory_format=mf), b)
+                        if cn == 'conv2' and w.shape[2:] == (3, 3) and w.shape[1] % 32 == 0 \
+                                and w.shape[0] % 64 == 0:
+                            f[(name, bi, 'conv2_taps')] = w.permute(2, 3, 1, 0).contiguous()
                         if cn == 'conv3' and w.shape[1] <= self.fused_tail_max_k \
                                 and w.shape[1] % 32 == 0:
                             # [K, N] operand of pave_rows_gemm_bias_res_act_f32
@@ -157,6 +166,14 @@ class ResNet(BaseModule):
                     if blk.downsample is not None:
                         w, b = _fold(blk.downsample[0], blk.downsample[1])
                         f[(name, bi, 'ds')] = (w.contiguous(memory_format=mf), b)
+                        w3_kn = f.get((name, bi, 'conv3_kn'))
+                        if w3_kn is not None and w.shape[1] % 32 == 0 and \
+                                w3_kn.shape[0] + w.shape[1] <= self.fused_ds_max_k:
+                            # conv3 and the downsample convolution share one accumulator:
+                            # [y | x] @ [W3; Wd] + (b3 + bd)
+                            f[(name, bi, 'tail_ds_kn')] = (
+                                torch.cat([w3_kn, w.flatten(1).t()], 0).contiguous(),
+                                f[(name, bi, 'conv3')][1] + b)
         self._folded = (key, f)
         return f
 
@@ -172,9 +189,11 @@ class ResNet(BaseModule):
         return rows.view(n, h, w, rows.shape[-1]).permute(0, 3, 1, 2)  # channels_last 4-D
 
     def _bottleneck_gemm(self, blk, x, f, name, bi, inplace_identity=False):
-        """Bottleneck with its two 1x1 convolutions as row GEMMs on the NHWC map (hipBLASLt,
-        bias + ReLU / residual in the GEMM epilogue) and ONE fused bias+ReLU pass after each of
-        the 3x3 convolution and the residual GEMM (pave_bias_act_rows_f32)."""
+        """Bottleneck on the NHWC map: conv1 as a hipBLASLt row GEMM (bias + ReLU epilogue), the
+        3x3 through MIOpen, and the tail `bn2 -> relu -> conv3 -> bn3 -> + identity |
+        downsample(x) -> relu` as ONE hand-written MFMA kernel (pave_rows_gemm_bias_res_act_f32)
+        where that wins (K <= fused_tail_max_k); above it hipBLASLt GEMMs with the residual in
+        the epilogue plus one fused bias+ReLU pass each (pave_bias_act_rows_f32)."""
         from . import ops
         rows, nhw = self._as_rows(x)
         w1, b1 = f[(name, bi, 'conv1')]
@@ -182,27 +201,42 @@ class ResNet(BaseModule):
         y = self._as_map(y, nhw)
         w2, b2 = f[(name, bi, 'conv2')]
         c2 = blk.conv2
-        y = F.conv2d(y, w2, None, c2.stride, c2.padding, c2.dilation)     # MIOpen 3x3
-        ops.bias_act_rows_(y, b2, None, relu=True)                        # bn2 + relu, one pass
-        yrows, onhw = self._as_rows(y)
         w3, b3 = f[(name, bi, 'conv3')]
         w3_kn = f.get((name, bi, 'conv3_kn'))
+        taps = f.get((name, bi, 'conv2_taps')) if self.deterministic_conv3x3 else None
+        if taps is not None and c2.dilation[0] == 1 and c2.padding[0] == 1:
+            y = ops.conv3x3_nhwc(y, taps, b2, stride=c2.stride[0], relu=True)  # MFMA, bn2+relu fused
+            b2 = None
+        else:
+            y = F.conv2d(y, w2, None, c2.stride, c2.padding, c2.dilation)  # MIOpen 3x3
+            if w3_kn is None:
+                ops.bias_act_rows_(y, b2, None, relu=True)                # bn2 + relu, one pass
+                b2 = None
+        # else: bn2 + relu are applied by the tail kernel while it loads its A operand
+        yrows, onhw = self._as_rows(y)
         if blk.downsample is not None:
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
             xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
             xrows, _ = self._as_rows(xs)
-            idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())          # both biases here
-            if w3_kn is not None:                                         # += y @ W3, ReLU: one pass
-                out = ops.rows_gemm_bias_res_act(yrows, w3_kn, None, idt, relu=True, out=idt)
+            tail = f.get((name, bi, 'tail_ds_kn'))
+            if tail is not None:
+                # relu([relu(y + b2) | x] @ [W3; Wd] + b3 + bd): the whole tail in one kernel
+                out = ops.rows_gemm_bias_res_act(yrows, tail[0], tail[1], None, relu=True,
+                                                 a_bias=b2, a2=xrows)
             else:
-                out = torch.addmm(idt, yrows, w3.flatten(1).t())
-                ops.bias_act_rows_(out, None, None, relu=True)
+                idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())      # both biases here
+                if w3_kn is not None:                                     # += y @ W3, ReLU: one pass
+                    out = ops.rows_gemm_bias_res_act(yrows, w3_kn, None, idt, relu=True, out=idt,
+                                                     a_bias=b2)
+                else:
+                    out = torch.addmm(idt, yrows, w3.flatten(1).t())
+                    ops.bias_act_rows_(out, None, None, relu=True)
         elif w3_kn is not None:
-            # conv3 + bn3 + identity + ReLU as one MFMA kernel; a temporary identity is
-            # overwritten in place
+            # bn2 + relu + conv3 + bn3 + identity + ReLU as one MFMA kernel; a temporary identity
+            # is overwritten in place
             out = ops.rows_gemm_bias_res_act(yrows, w3_kn, b3, rows, relu=True,
-                                             out=rows if inplace_identity else None)
+                                             out=rows if inplace_identity else None, a_bias=b2)
         elif inplace_identity:
             out = rows.addmm_(yrows, w3.flatten(1).t())                   # identity += y @ W3
             ops.bias_act_rows_(out, b3, None, relu=True)

@@ -152,13 +152,50 @@ class ConvModule(nn.Module):
                 act_cfg.setdefault('inplace', inplace)
             self.activate = build_activation_layer(act_cfg)
 
+    # True: run-to-run bit-reproducible convolution (MIOpen's fp32 kernels are not, see
+    # tools/debug_determinism.py): 1x1 as a hipBLASLt row GEMM, 3x3 / pad 1 through the
+    # hand-written MFMA implicit GEMM.  Set per instance by `set_deterministic`.
+    deterministic = False
+
+    def _conv_deterministic(self, x):
+        c = self.conv
+        k, cin, cout = c.kernel_size, c.in_channels, c.out_channels
+        if not (x.is_cuda and x.dtype == torch.float32 and c.groups == 1 and c.dilation == (1, 1)):
+            return None
+        x = x.contiguous(memory_format=torch.channels_last)
+        if k == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0):
+            n, _, h, w = x.shape
+            rows = x.permute(0, 2, 3, 1).reshape(-1, cin)
+            wt = c.weight.flatten(1).t()
+            y = rows @ wt if c.bias is None else torch.addmm(c.bias, rows, wt)
+            return y.view(n, h, w, cout).permute(0, 3, 1, 2)
+        if k == (3, 3) and c.padding == (1, 1) and c.stride[0] == c.stride[1] and \
+                c.stride[0] in (1, 2) and cin % 32 == 0 and cout % 64 == 0:
+            from . import ops
+            return ops.conv3x3_nhwc(x, c.weight.permute(2, 3, 1, 0).contiguous(), c.bias,
+                                    stride=c.stride[0], relu=False)
+        return None
+
     def forward(self, x):
-        x = self.conv(x)
+        y = self._conv_deterministic(x) if self.deterministic and not self.training else None
+        x = self.conv(x) if y is None else y
         if self.with_norm:
             x = getattr(self, self.norm_name)(x)
         if self.with_activation:
             x = self.activate(x)
         return x
+
+
+def set_deterministic(model, flag=True):
+    """Bit-reproducible forward: every ConvModule and the ResNet 3x3 convolutions leave MIOpen
+    (whose searched fp32 kernels accumulate in a run-dependent order) for hipBLASLt row GEMMs /
+    the hand-written MFMA convolution.  ~5 % slower on the bench workload."""
+    for mod in model.modules():
+        if isinstance(mod, ConvModule):
+            mod.deterministic = bool(flag)
+        if hasattr(mod, 'deterministic_conv3x3'):
+            mod.deterministic_conv3x3 = bool(flag)
+    return model
 
 
 @MMCV_FEEDFORWARD_NETWORK.register_module()

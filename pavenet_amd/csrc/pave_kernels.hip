@@ -1202,7 +1202,11 @@ template <int BN, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_nhwc_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* residual, float* y, const int N, const int H, const int W, const int Cin,
-    const int Cout, const int Ho, const int Wo, const int stride, const int relu) {
+    const int Cout, const int Ho, const int Wo, const int stride, const int relu,
+    const float* __restrict__ a_bias, const float* __restrict__ x2, const int Cin2) {
+  // KS == 1 extras: the K axis may continue into a second row matrix x2 [M, Cin2] (the
+  // Bottleneck's downsample branch shares the accumulator), and the first source may get
+  // relu(x + a_bias[k]) applied on load (the producer's folded-BN bias + ReLU).
   constexpr int PAD = KS / 2, TAPS = KS * KS;
   constexpr int BM = 128, BK = 32, AST = 33;
   constexpr int TM = (BN == 128) ? 2 : 1, TN = 2;
@@ -1249,22 +1253,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lrow = lane & 31, lk = lane >> 5;
   constexpr int BV = (BK * BN) / (256 * 4);  // float4 per thread for B
   const int cslabs = Cin / BK;
-  const int nslabs = TAPS * cslabs;
+  const int nslabs = TAPS * cslabs + (KS == 1 ? Cin2 / BK : 0);
   float4 av[4], bv[BV];
   // global -> registers for one K-slab (tap, 32 channels): issued one slab ahead so that the
   // loads are in flight while the MFMAs of the current slab run
 #define PAVE_CONV_LOAD_SLAB(slab_)                                                              \
   {                                                                                             \
-    const int tap_ = (slab_) / cslabs, c0_ = ((slab_) - tap_ * cslabs) * BK;                     \
-    const int ky_ = tap_ / KS, kx_ = tap_ - ky_ * KS;                                            \
+    /* KS == 1: "tap" 0 = first source, 1 = second source (its slabs follow the first's) */      \
+    const int tap_ = (KS == 1) ? ((slab_) >= cslabs ? 1 : 0) : (slab_) / cslabs;                 \
+    const int c0_ = ((slab_) - tap_ * cslabs) * BK;                                              \
+    const int ky_ = (KS == 1) ? 0 : tap_ / KS, kx_ = (KS == 1) ? 0 : tap_ - ky_ * KS;            \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
       const int iy = iy0[q] + ky_, ix = ix0[q] + kx_;                                            \
       const bool ok = pvalid[q] && iy >= 0 && iy < H && ix >= 0 && ix < W;                       \
-      const float* src_ = ok ? x + (nbase[q] + (long long)iy * W + ix) * Cin + c0_ + seg * 4 : x; \
-      const float4 t_ = *reinterpret_cast<const float4*>(src_);                                  \
+      const long long pix_ = nbase[q] + (long long)iy * W + ix;                                  \
+      const float* src_ = !ok ? x                                                                \
+                          : (KS == 1 && tap_ > 0) ? x2 + pix_ * Cin2 + c0_ + seg * 4             \
+                                                  : x + pix_ * Cin + c0_ + seg * 4;              \
+      float4 t_ = *reinterpret_cast<const float4*>(src_);                                        \
+      if (KS == 1 && a_bias && tap_ == 0) {                                                      \
+        const float4 ab_ = *reinterpret_cast<const float4*>(a_bias + c0_ + seg * 4);             \
+        t_.x = fmaxf(t_.x + ab_.x, 0.f);                                                         \
+        t_.y = fmaxf(t_.y + ab_.y, 0.f);                                                         \
+        t_.z = fmaxf(t_.z + ab_.z, 0.f);                                                         \
+        t_.w = fmaxf(t_.w + ab_.w, 0.f);                                                         \
+      }                                                                                         \
       av[q] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);                                         \
     }                                                                                           \
-    const float* wrow_ = w + ((long long)tap_ * Cin + c0_) * Cout + n0;                          \
+    const float* wrow_ = w + ((long long)tap_ * Cin + c0_) * Cout + n0; /* rows of [K(+K2), N] */ \
     _Pragma("unroll") for (int q = 0; q < BV; ++q) {                                            \
       const int idx = tid + q * 256; /* float4 index in the [32][BN] tile */                     \
       const int kr = idx / (BN / 4), nc = (idx - kr * (BN / 4)) * 4;                             \
@@ -1704,23 +1720,27 @@ int pave_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (bn == 128)
     hipLaunchKernelGGL((conv_nhwc_kernel<128, 3>), dim3((unsigned)gx), dim3(256), 0, st, x, w, bias,
-                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu,
+                       (const float*)nullptr, (const float*)nullptr, 0);
   else
     hipLaunchKernelGGL((conv_nhwc_kernel<64, 3>), dim3((unsigned)gx), dim3(256), 0, st, x, w, bias,
-                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu);
+                       (const float*)nullptr, y, N, H, W, Cin, Cout, Ho, Wo, stride, relu,
+                       (const float*)nullptr, (const float*)nullptr, 0);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
 
-int pave_rows_gemm_bias_res_act_f32(const float* a, const float* w, const float* bias,
-                                    const float* residual, float* out, long long M, int K, int Nc,
-                                    int relu, void* stream) {
+int pave_rows_gemm_bias_res_act_f32(const float* a, const float* a_bias, const float* a2,
+                                    const float* w, const float* bias, const float* residual,
+                                    float* out, long long M, int K, int K2, int Nc, int relu,
+                                    void* stream) {
   if (!a || !w || !out) return fail(PAVE_E_ARG, "rows_gemm: null pointer");
-  if (M <= 0 || K <= 0 || Nc <= 0 || M >= (1ll << 31))
+  if (M <= 0 || K <= 0 || K2 < 0 || Nc <= 0 || M >= (1ll << 31))
     return fail(PAVE_E_ARG, "rows_gemm: bad sizes (0 < M < 2^31)");
-  if (K % 32 != 0 || Nc % 64 != 0)
-    return fail(PAVE_E_ARG, "rows_gemm: K %% 32 == 0 and N %% 64 == 0 required");
+  if ((K2 > 0) != (a2 != nullptr)) return fail(PAVE_E_ARG, "rows_gemm: a2 and K2 go together");
+  if (K % 32 != 0 || K2 % 32 != 0 || Nc % 64 != 0)
+    return fail(PAVE_E_ARG, "rows_gemm: K, K2 %% 32 == 0 and N %% 64 == 0 required");
   const int bn = Nc % 128 == 0 ? 128 : 64;
   const long long gx = ((M + 127) / 128) * (Nc / bn);
   if (gx >= (1ll << 31)) return fail(PAVE_E_ARG, "rows_gemm: grid too large");
@@ -1728,10 +1748,10 @@ int pave_rows_gemm_bias_res_act_f32(const float* a, const float* w, const float*
   // a 1x1 convolution over a 1 x M "image"
   if (bn == 128)
     hipLaunchKernelGGL((conv_nhwc_kernel<128, 1>), dim3((unsigned)gx), dim3(256), 0, st, a, w, bias,
-                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu);
+                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu, a_bias, a2, K2);
   else
     hipLaunchKernelGGL((conv_nhwc_kernel<64, 1>), dim3((unsigned)gx), dim3(256), 0, st, a, w, bias,
-                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu);
+                       residual, out, 1, 1, (int)M, K, Nc, 1, (int)M, 1, relu, a_bias, a2, K2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -26,7 +26,7 @@ SIGNATURES = {
     'pave_ms_deform_attn_backward_f64': [_vp] * 9 + [_c_int] * 8 + [_vp],
     'pave_preprocess_frames': [_vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp, _c_int, _vp],
     'pave_conv3x3_nhwc_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
-    'pave_rows_gemm_bias_res_act_f32': [_vp] * 5 + [ctypes.c_longlong] + [_c_int] * 3 + [_vp],
+    'pave_rows_gemm_bias_res_act_f32': [_vp] * 7 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
     'pave_bias_relu_maxpool_nhwc_f32': [_vp] * 3 + [_c_int] * 4 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }

@@ -373,20 +373,28 @@ def conv3x3_nhwc(x, w_taps, bias, stride=1, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def rows_gemm_bias_res_act(a, w_kn, bias=None, residual=None, relu=False, out=None):
-    """out[M, N] = act(a[M, K] @ w_kn[K, N] + bias + residual) on the fp32 MFMA, one pass
-    (the Bottleneck tail `conv3 -> bn3 -> += identity -> relu`, resnet.py:264-283).
+def rows_gemm_bias_res_act(a, w_kn, bias=None, residual=None, relu=False, out=None, a_bias=None,
+                           a2=None):
+    """out[M, N] = act([A1 | a2] @ w_kn + bias + residual) on the fp32 MFMA in one pass, with
+    A1 = relu(a + a_bias) if a_bias is given else a  (the Bottleneck tail `bn2 -> relu -> conv3 ->
+    bn3 -> += identity | downsample(x) -> relu`, resnet.py:264-283).  w_kn is [K (+ K2), N].
     `residual` may be the tensor given as `out` (in-place accumulate into the identity)."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
     _dev(w_kn, 'w_kn', torch.float32)
-    _require(a.dim() == 2 and w_kn.dim() == 2 and a.shape[1] == w_kn.shape[0],
-             'rows_gemm: a [M,K], w [K,N]')
+    _require(a.dim() == 2 and w_kn.dim() == 2, 'rows_gemm: a [M,K], w [K,N]')
     M, K = a.shape
+    K2 = 0
+    if a2 is not None:
+        _dev(a2, 'a2', torch.float32)
+        _require(a2.dim() == 2 and a2.shape[0] == M, 'rows_gemm: a2 [M,K2]')
+        K2 = a2.shape[1]
+    _require(w_kn.shape[0] == K + K2, 'rows_gemm: w must be [K + K2, N]')
     N = w_kn.shape[1]
-    if bias is not None:
-        _dev(bias, 'bias', torch.float32)
-        _require(bias.numel() == N, 'rows_gemm: bias [N]')
+    for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
+        if t is not None:
+            _dev(t, nm, torch.float32)
+            _require(t.numel() == n, f'rows_gemm: {nm} has {t.numel()} elements, expected {n}')
     if residual is not None:
         _dev(residual, 'residual', torch.float32)
         _require(tuple(residual.shape) == (M, N), 'rows_gemm: residual [M,N]')
@@ -395,11 +403,11 @@ def rows_gemm_bias_res_act(a, w_kn, bias=None, residual=None, relu=False, out=No
     else:
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'rows_gemm: out [M,N]')
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed('rows_gemm'):
         st = lib.pave_rows_gemm_bias_res_act_f32(
-            a.data_ptr(), w_kn.data_ptr(), bias.data_ptr() if bias is not None else None,
-            residual.data_ptr() if residual is not None else None, out.data_ptr(), M, K, N,
-            int(bool(relu)), _stream_ptr())
+            a.data_ptr(), ptr(a_bias), ptr(a2), w_kn.data_ptr(), ptr(bias), ptr(residual),
+            out.data_ptr(), M, K, K2, N, int(bool(relu)), _stream_ptr())
     native.check(st, 'rows_gemm_bias_res_act')
     return out
 

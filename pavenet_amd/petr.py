@@ -113,6 +113,7 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
             if forced is not None:
                 topk_proposals = forced
             self.last_topk_proposals = topk_proposals
+            self.last_enc_cls = enc_outputs_class  # [B, S, 1] (parity harness)
             rows = torch.gather(output_memory, 1,
                                 topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
             props = torch.gather(output_proposals, 1, topk_proposals.unsqueeze(-1).repeat(1, 1, 2))

@@ -49,8 +49,11 @@ class VideoPoseStream:
                 for c in range(n_frames)]
 
     @torch.no_grad()
-    def decode(self, slabs, windows, rescale=False):
-        """Run head + decoders + OKS-NMS on windows of cached slabs (B = len(windows))."""
+    def decode(self, slabs, windows, rescale=False, force_topk_proposals=None,
+               force_score_topk=None):
+        """Run head + decoders + OKS-NMS on windows of cached slabs (B = len(windows)).
+        The two `force_*` index tensors pin the proposal / score top-k selections (parity tests:
+        run-to-run rounding noise of the vendor GEMM / conv kernels can swap near-tied members)."""
         T = self.T
         B = len(windows)
         dev = slabs[0].device
@@ -62,8 +65,9 @@ class VideoPoseStream:
         if valid_ratios.shape[0] != B * T:
             valid_ratios = valid_ratios.expand(B * T, -1, -1)
         encoded = (memory, mask_flatten, valid_ratios, self._geom)
-        outs = self.head(None, metas, precomputed=(masks, pos, has_padding, encoded))
-        return self.head.get_bboxes(outs, metas, rescale=rescale)
+        kw = {} if force_topk_proposals is None else dict(force_topk_proposals=force_topk_proposals)
+        outs = self.head(None, metas, precomputed=(masks, pos, has_padding, encoded), **kw)
+        return self.head.get_bboxes(outs, metas, rescale=rescale, force_score_topk=force_score_topk)
 
     @torch.no_grad()
     def infer_video(self, frames, rescale=False):

@@ -466,6 +466,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             if forced is not None:  # parity harness: follow the reference's selection
                 topk_proposals = forced
             self.last_topk_proposals = topk_proposals
+            self.last_enc_cls = enc_outputs_class  # [B, S, 1] (parity harness)
             # The reference runs the keypoint / sigma branches on all S tokens and gathers the
             # top-k rows afterwards (OT:21372-21389); the branches are row-wise, so gathering
             # first is identical and 74x less work (300 of 22 323 rows).  The all-token

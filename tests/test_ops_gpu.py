@@ -334,3 +334,26 @@ def test_bias_relu_maxpool_vs_torch(N, H, W, C):
     out = bias_relu_maxpool_nhwc(x.cuda().contiguous(memory_format=torch.channels_last), b.cuda())
     assert out.shape == exp.shape
     assert torch.equal(out.cpu(), exp)
+
+
+def test_rows_gemm_prologue_and_second_source():
+    """Full Bottleneck tail: relu([relu(a + ab) | a2] @ w + bias) — A-side bias/ReLU on load and
+    the downsample branch as a second K range."""
+    from pavenet_amd.ops import rows_gemm_bias_res_act
+    g = torch.Generator().manual_seed(11)
+    M, K, K2, N = 777, 64, 96, 256
+    a, a2 = torch.randn(M, K, generator=g), torch.randn(M, K2, generator=g)
+    ab, b = torch.randn(K, generator=g), torch.randn(N, generator=g)
+    w = torch.randn(K + K2, N, generator=g) / (K + K2)**0.5
+    A = torch.cat([torch.relu(a + ab), a2], 1).double()
+    exp = torch.relu(A @ w.double() + b.double())
+    out = rows_gemm_bias_res_act(a.cuda(), w.cuda(), b.cuda(), None, relu=True, a_bias=ab.cuda(),
+                                 a2=a2.cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+    r = torch.randn(M, N, generator=g)
+    out = rows_gemm_bias_res_act(a.cuda(), w[:K].contiguous().cuda(), b.cuda(), r.cuda(),
+                                 relu=False, a_bias=ab.cuda())
+    exp = torch.relu(a + ab).double() @ w[:K].double() + b.double() + r.double()
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        rows_gemm_bias_res_act(a.cuda(), w.cuda(), b.cuda())          # w rows != K
