@@ -117,7 +117,7 @@ class ResNet(BaseModule):
         # tools/bench_gemm_shapes.py: K=64 1.14 vs 1.84 ms, 128: 0.81 vs 1.04, 256: 0.68 vs 0.73,
         # 512: 0.64 vs 0.58)
         self.fused_tail_max_k = 256
-        self.fused_ds_max_k = 384     # conv3 + downsample in one kernel up to this K1 + K2
+        self.fused_ds_max_k = 128     # conv3 + downsample in one kernel up to this K1 + K2 (layer1.0)
         # 3x3 convolutions: MIOpen's searched fp32 kernels are 10-30 % faster than the
         # hand-written MFMA implicit GEMM (tools/bench_conv.py) but NOT run-to-run deterministic
         # (tools/debug_determinism.py); True routes them through pave_conv3x3_nhwc_f32

@@ -1254,7 +1254,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int BV = (BK * BN) / (256 * 4);  // float4 per thread for B
   const int cslabs = Cin / BK;
   const int nslabs = TAPS * cslabs + (KS == 1 ? Cin2 / BK : 0);
-  float4 av[4], bv[BV];
+  float4 av[4], bv[BV], abv = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool abv_on = false;
   // global -> registers for one K-slab (tap, 32 channels): issued one slab ahead so that the
   // loads are in flight while the MFMAs of the current slab run
 #define PAVE_CONV_LOAD_SLAB(slab_)                                                              \
@@ -1270,16 +1271,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float* src_ = !ok ? x                                                                \
                           : (KS == 1 && tap_ > 0) ? x2 + pix_ * Cin2 + c0_ + seg * 4             \
                                                   : x + pix_ * Cin + c0_ + seg * 4;              \
-      float4 t_ = *reinterpret_cast<const float4*>(src_);                                        \
-      if (KS == 1 && a_bias && tap_ == 0) {                                                      \
-        const float4 ab_ = *reinterpret_cast<const float4*>(a_bias + c0_ + seg * 4);             \
-        t_.x = fmaxf(t_.x + ab_.x, 0.f);                                                         \
-        t_.y = fmaxf(t_.y + ab_.y, 0.f);                                                         \
-        t_.z = fmaxf(t_.z + ab_.z, 0.f);                                                         \
-        t_.w = fmaxf(t_.w + ab_.w, 0.f);                                                         \
-      }                                                                                         \
+      const float4 t_ = *reinterpret_cast<const float4*>(src_);                                  \
       av[q] = ok ? t_ : make_float4(0.f, 0.f, 0.f, 0.f);                                         \
     }                                                                                           \
+    /* A-side bias of this slab; applied when the slab is written to LDS, so that the loads */  \
+    /* above stay in flight across the MFMA loop (rows >= M get relu(bias): never stored)   */  \
+    abv_on = KS == 1 && a_bias && tap_ == 0;                                                     \
+    if (abv_on) abv = *reinterpret_cast<const float4*>(a_bias + c0_ + seg * 4);                  \
     const float* wrow_ = w + ((long long)tap_ * Cin + c0_) * Cout + n0; /* rows of [K(+K2), N] */ \
     _Pragma("unroll") for (int q = 0; q < BV; ++q) {                                            \
       const int idx = tid + q * 256; /* float4 index in the [32][BN] tile */                     \
@@ -1293,10 +1291,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float* d = As + ((tid >> 3) + q * 32) * AST + seg * 4;
-      d[0] = av[q].x;
-      d[1] = av[q].y;
-      d[2] = av[q].z;
-      d[3] = av[q].w;
+      float4 t = av[q];
+      if (abv_on) {
+        t.x = fmaxf(t.x + abv.x, 0.f);
+        t.y = fmaxf(t.y + abv.y, 0.f);
+        t.z = fmaxf(t.z + abv.z, 0.f);
+        t.w = fmaxf(t.w + abv.w, 0.f);
+      }
+      d[0] = t.x;
+      d[1] = t.y;
+      d[2] = t.z;
+      d[3] = t.w;
     }
 #pragma unroll
     for (int q = 0; q < BV; ++q) *reinterpret_cast<float4*>(Bs + (tid + q * 256) * 4) = bv[q];

@@ -69,8 +69,11 @@ def main():
             # library path = GEMM + the bias/ReLU pass;  own = one kernel
             ms_lib = timed(lambda: ops.bias_act_rows_(c.addmm_(a, wt.t()), bias, None, relu=True))
             own = timed(lambda: ops.rows_gemm_bias_res_act(a, wkn, bias, c, relu=True, out=c))
+            ab = torch.randn(K, device=dev)
+            own_ab = timed(lambda: ops.rows_gemm_bias_res_act(a, wkn, bias, c, relu=True, out=c,
+                                                              a_bias=ab))
             print(f'   {label}: hipBLASLt addmm_ + bias/relu pass {ms_lib:.3f} ms   '
-                  f'fused MFMA kernel {own:.3f} ms')
+                  f'fused MFMA kernel {own:.3f} ms   with bn2+relu on A load {own_ab:.3f} ms')
         seen[key] = ([label], ms)
         del a, wt
     tot = 0.0
