@@ -47,6 +47,10 @@ def parse():
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
     ap.add_argument('--cpu-baseline-frames', type=int, default=None)
+    ap.add_argument('--gemm', choices=('native', 'bf16x3'), default='native',
+                    help="dense projections: 'native' = hipBLASLt fp32 MFMA (the headline), "
+                         "'bf16x3' = hand-written exact-split GEMM on the bf16 MFMA (fp32-level "
+                         "accuracy; reported under config.gemm, see DESIGN.md)")
     return ap.parse_args()
 
 
@@ -100,6 +104,8 @@ def main():
     model = build_model(videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img))
     init_random_weights(model, seed=0)
     model = model.to(dev).eval()
+    from pavenet_amd.bricks import set_gemm_mode
+    set_gemm_mode(args.gemm)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
     metas = [dict(batch_input_shape=(args.height, args.width),
@@ -166,7 +172,7 @@ def main():
                     config=dict(workload=f'PAVE-Net R-50 T={T} frames, batch={B} clips/GPU, '
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
-                                parallelism=f'clip-parallel x{world}',
+                                parallelism=f'clip-parallel x{world}', gemm=args.gemm,
                                 detections_last_step=int(last[..., -N:].sum().item())),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:

@@ -195,21 +195,25 @@ class ResNet(BaseModule):
         where that wins (K <= fused_tail_max_k); above it hipBLASLt GEMMs with the residual in
         the epilogue plus one fused bias+ReLU pass each (pave_bias_act_rows_f32)."""
         from . import ops
+        from .bricks import linear_rows, split_gemm_ok
         rows, nhw = self._as_rows(x)
         w1, b1 = f[(name, bi, 'conv1')]
-        y = torch._addmm_activation(b1, rows, w1.flatten(1).t())          # conv1 + bn1 + relu
+        y = linear_rows(rows, w1.flatten(1), b1, relu=True)               # conv1 + bn1 + relu
         y = self._as_map(y, nhw)
         w2, b2 = f[(name, bi, 'conv2')]
         c2 = blk.conv2
         w3, b3 = f[(name, bi, 'conv3')]
         w3_kn = f.get((name, bi, 'conv3_kn'))
+        split3 = blk.downsample is None and split_gemm_ok(rows, w3.flatten(1))
+        if split3:
+            w3_kn = None  # the split GEMM takes the tail (same prologue / epilogue) for K >= 256
         taps = f.get((name, bi, 'conv2_taps')) if self.deterministic_conv3x3 else None
         if taps is not None and c2.dilation[0] == 1 and c2.padding[0] == 1:
             y = ops.conv3x3_nhwc(y, taps, b2, stride=c2.stride[0], relu=True)  # MFMA, bn2+relu fused
             b2 = None
         else:
             y = F.conv2d(y, w2, None, c2.stride, c2.padding, c2.dilation)  # MIOpen 3x3
-            if w3_kn is None:
+            if w3_kn is None and not split3:
                 ops.bias_act_rows_(y, b2, None, relu=True)                # bn2 + relu, one pass
                 b2 = None
         # else: bn2 + relu are applied by the tail kernel while it loads its A operand
@@ -232,6 +236,9 @@ class ResNet(BaseModule):
                 else:
                     out = torch.addmm(idt, yrows, w3.flatten(1).t())
                     ops.bias_act_rows_(out, None, None, relu=True)
+        elif split3:
+            out = linear_rows(yrows, w3.flatten(1), b3, relu=True, residual=rows,
+                              inplace_residual=inplace_identity, a_bias=b2)
         elif w3_kn is not None:
             # bn2 + relu + conv3 + bn3 + identity + ReLU as one MFMA kernel; a temporary identity
             # is overwritten in place

@@ -103,6 +103,71 @@ def _fusable(*tensors):
     return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
+# Dense projections (nn.Linear on [M, K] rows).  'native': hipBLASLt fp32 (v_mfma_f32_*_f32,
+# 157 TFLOP/s peak).  'bf16x3': the hand-written split GEMM (pave_gemm_bf16x3_f32): both operands
+# split EXACTLY into three bf16 terms, six bf16 MFMAs per product tile, fp32 accumulate -- fp32-level
+# accuracy (tests/test_ops_gpu.py::test_gemm_bf16x3_accuracy_vs_fp64) at 1.05-1.45x hipBLASLt's
+# fp32 rate on the K >= 256 shapes of this model.  Opt-in: the default bench number is 'native'.
+_GEMM = {'mode': 'native', 'min_rows': 8192}
+_SPLIT_CACHE = {}
+
+
+def set_gemm_mode(mode):
+    assert mode in ('native', 'bf16x3')
+    _GEMM['mode'] = mode
+
+
+def get_gemm_mode():
+    return _GEMM['mode']
+
+
+def _split_weight(weight):
+    """Weight [N, K] -> cached slab-major bf16x3 planes (re-split when the tensor changes)."""
+    from . import ops
+    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    hit = _SPLIT_CACHE.get(slot)
+    if hit is None or hit[0] != weight._version:
+        with torch.no_grad():
+            hit = (weight._version, ops.split_weight_bf16x3(weight.detach().contiguous()))
+        if len(_SPLIT_CACHE) > 1024:
+            _SPLIT_CACHE.clear()
+        _SPLIT_CACHE[slot] = hit
+    return hit[1]
+
+
+def split_gemm_ok(x2, weight):
+    """Shapes / dtypes the split GEMM takes (and where it beats the library)."""
+    return (_GEMM['mode'] == 'bf16x3' and x2.is_cuda and x2.dtype == torch.float32
+            and x2.dim() == 2 and x2.is_contiguous() and weight.dtype == torch.float32
+            and weight.shape[1] % 64 == 0 and weight.shape[1] >= 256
+            and weight.shape[0] % 128 == 0 and x2.shape[0] >= _GEMM['min_rows']
+            and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
+
+
+def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residual=False,
+                a_bias=None):
+    """act(A' @ weight^T + bias + residual) on rows [M, K]: the split GEMM when enabled and
+    applicable, else hipBLASLt with the same fusions (bias / ReLU / residual in the epilogue).
+    A' = relu(x2 + a_bias) when a_bias is given."""
+    if split_gemm_ok(x2, weight):
+        from . import ops
+        out = residual if (residual is not None and inplace_residual) else None
+        return ops.gemm_bf16x3(x2, _split_weight(weight), bias, residual, relu=relu, out=out,
+                               a_bias=a_bias)
+    if a_bias is not None:
+        x2 = torch.relu(x2 + a_bias)
+    if residual is not None:
+        t = residual.addmm_(x2, weight.t()) if inplace_residual else \
+            torch.addmm(residual, x2, weight.t())
+        if bias is not None:
+            t = t + bias if not inplace_residual else t.add_(bias)
+        return torch.relu_(t) if relu else t
+    if relu and bias is not None and x2.is_cuda:
+        return torch._addmm_activation(bias, x2, weight.t())
+    y = F.linear(x2, weight, bias)
+    return torch.relu_(y) if relu else y
+
+
 def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False):
     """(x @ W^T + b + identity) [-> LayerNorm], batch-first tensors [..., C].
 
@@ -114,7 +179,9 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
         from . import ops
         idt2 = identity_bf.reshape(-1, C_out)
         x2 = x_bf.reshape(-1, x_bf.shape[-1])
-        if inplace:  # caller guarantees nobody else reads identity: no copy of C into D
+        if split_gemm_ok(x2, linear.weight):
+            t = linear_rows(x2, linear.weight, None, residual=idt2, inplace_residual=inplace)
+        elif inplace:  # caller guarantees nobody else reads identity: no copy of C into D
             t = idt2.addmm_(x2, linear.weight.t())
         else:
             t = torch.addmm(idt2, x2, linear.weight.t())
@@ -236,7 +303,7 @@ class FFN(BaseModule):
         if self._fast_ok(x):
             xb, ib = batch_first(x), batch_first(identity)
             fc1, fc2 = self.layers[0][0], self.layers[1]
-            h = torch._addmm_activation(fc1.bias, xb.reshape(-1, xb.shape[-1]), fc1.weight.t())
+            h = linear_rows(xb.reshape(-1, xb.shape[-1]), fc1.weight, fc1.bias, relu=True)
             out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm,
                                        inplace=inplace_residual)
             return seq_first_view(out)

@@ -5,14 +5,16 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip')]
+SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
+           os.path.join(_HERE, 'csrc', 'pave_gemm_split.hip')]
+HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
 
 
 def build_native(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(
-            os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SOURCES):
+            os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SOURCES + HEADERS):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',

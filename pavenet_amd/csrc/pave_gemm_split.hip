@@ -1,0 +1,378 @@
+// libpave_hip.so -- fp32 row GEMM on the bf16 matrix cores by 3-way operand splitting.
+//
+// gfx950 multiplies fp32 on the MFMA at 157 TFLOP/s (v_mfma_f32_32x32x2_f32) but bf16 at
+// 2.5 PFLOP/s (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  An fp32 value splits EXACTLY into
+// three bf16 values by truncation (8 + 8 + 8 significand bits):
+//     a0 = hi16(a), r1 = a - a0, a1 = hi16(r1), a2 = r1 - a1            a = a0 + a1 + a2
+// (the subtractions are exact in fp32), products of bf16 pairs are exact in the MFMA's fp32
+// datapath, and
+//     a*b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + [a1b2 + a2b1 + a2b2]
+// where the bracket is <= 2^-23 |ab| -- below fp32's own rounding of the product sum.  Six bf16
+// MFMAs therefore give a GEMM with fp32-level accuracy (tests/test_ops_gpu.py measures it
+// against fp64 next to the native fp32 MFMA) at 2.5 PF / 6 = 417 TFLOP/s peak, 2.7x the fp32
+// MFMA rate.  Weights are split once on the host side (pave_split_bf16x3_f32); activations are
+// split while they are staged into LDS, so HBM traffic is that of an fp32 GEMM.
+//
+//   out[M, N] = act(A'[M, K] * W[N, K]^T + bias[N] + residual[M, N]),
+//   A' = a_bias ? relu(A + a_bias[K]) : A
+//
+// Block = 256 threads = 2 x 2 waves, block tile (2*TM*32) x (2*TN*32), K slab 16 (one MFMA
+// k-step).  LDS holds the three bf16 planes of the A and W slabs, double buffered, rows padded to
+// 48 bytes so that the ds_read_b128 of an MFMA operand (lane -> row l&31, k half l>>5) is
+// bank-conflict free.  The epilogue goes through LDS so that bias / residual / ReLU / store run
+// on float4 with whole row segments per wave.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pave_hip.h"
+#include "pave_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;          // K slab = one MFMA k-step
+constexpr int RST = 48;         // LDS row stride in bytes: 32 B of bf16 + 16 B pad (the 16 lanes
+                                // of a ds_read_b128 phase then fall on 16 distinct bank quads)
+
+__device__ __forceinline__ unsigned hi16(float x) { return __float_as_uint(x) & 0xffff0000u; }
+// pack the bf16 (= high halves) of two fp32 bit patterns: lo -> bits 0..15, hi -> bits 16..31
+__device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// exact 3-way bf16 split of 4 consecutive fp32 -> 3 x (4 bf16 = 8 bytes)
+__device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned h0[4], h1[4], h2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h0[i] = hi16(x[i]);
+    const float r1 = x[i] - __uint_as_float(h0[i]);
+    h1[i] = hi16(r1);
+    const float r2 = r1 - __uint_as_float(h1[i]);
+    h2[i] = __float_as_uint(r2);  // <= 8 significant bits: its high half is exact
+  }
+  p0 = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
+  p1 = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
+  p2 = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
+}
+
+// Software pipeline (one wave per SIMD, so nothing else hides latency):
+//   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
+//   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
+//   slab s's MFMAs, into a second fragment register set.
+template <int TM, int TN, bool ABIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
+  constexpr int BUF = 3 * (A_PLANE + W_PLANE);                 // one LDS buffer
+  constexpr int SMEM = 2 * BUF;
+  constexpr int APASS = BM / 64;   // float4 loads of A per thread per slab (4 threads per row)
+  constexpr int WV = (3 * BN * 2) / 256;  // uint4 loads of W per thread per slab (2 per row-plane)
+  static_assert((3 * BN * 2) % 256 == 0, "W slab must divide over the block");
+  static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, kh = lane >> 5;
+  const int ntiles = N / BN;
+  // XCD-aware bijective remap: the hardware deals workgroups round-robin over the 8 XCDs; give
+  // each XCD a contiguous run of logical tiles (column tile fastest) so that the column tiles of
+  // one row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once.
+  const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  const long long m0 = (long long)(lb / ntiles) * BM;
+  const int n0 = (lb % ntiles) * BN;
+
+  // ---- staging roles
+  // A: thread -> (row = tid>>2 + 64*q, 16-byte segment seg = tid&3 of the row's 64-byte slab)
+  const int a_seg = tid & 3;
+  const float* a_ptr[APASS];
+#pragma unroll
+  for (int q = 0; q < APASS; ++q) {
+    long long r = m0 + (tid >> 2) + 64 * q;
+    if (r >= M) r = M - 1;  // clamp: rows past M are computed on stand-in data, never stored
+    a_ptr[q] = A + r * K + a_seg * 4;
+  }
+  // W operand, slab-major [K/16][3][N][16] bf16 (host layout: one slab of a column tile is 3
+  // contiguous 4-KiB runs): uint4 index v = tid + 256*q -> plane, row, 16-byte half
+  const uint16_t* w_ptr[WV];
+  int w_dst[WV];
+#pragma unroll
+  for (int q = 0; q < WV; ++q) {
+    const int v = tid + 256 * q;
+    const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);
+    w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * 3*N*16
+    w_dst[q] = 3 * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
+  }
+  const long long w_slab = 3ll * N * 16;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // global -> register sets.  A set holds a PAIR of slabs (32 k): the two float4 a thread loads
+  // per row are the halves of one 128-byte line, so every line crosses L2 -> L1 once.  Two sets
+  // alternate; a pair is loaded 3 slabs before its first use.
+  f32x4 ra0[2][APASS], ra1[2][APASS];
+  u32x4 rw0[2][WV], rw1[2][WV];
+  f32x4 rb0[2], rb1[2];
+  const int nslabs = K / BK;
+  const int npairs = nslabs / 2;
+  auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rw)[2][WV], f32x4 (&rb)[2]) {
+    const int pp = pair < npairs ? pair : npairs - 1;  // past the end: repeat (never consumed)
+    const int k0 = pp * 2 * BK;
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      ra[0][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0);
+      ra[1][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0 + BK);
+    }
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+      rw[0][q] = *reinterpret_cast<const u32x4*>(w_ptr[q] + (long long)(2 * pp) * w_slab);
+      rw[1][q] = *reinterpret_cast<const u32x4*>(w_ptr[q] + (long long)(2 * pp + 1) * w_slab);
+    }
+    if (ABIAS) {
+      rb[0] = *reinterpret_cast<const f32x4*>(a_bias + k0 + a_seg * 4);
+      rb[1] = *reinterpret_cast<const f32x4*>(a_bias + k0 + BK + a_seg * 4);
+    }
+  };
+  auto stage = [&](unsigned char* buf, const f32x4 (&av)[APASS], const u32x4 (&wv)[WV],
+                   const f32x4 abv) {  // registers -> LDS (A split on the way)
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      float4 t = make_float4(av[q].x, av[q].y, av[q].z, av[q].w);
+      if (ABIAS) {
+        t.x = fmaxf(t.x + abv.x, 0.f);
+        t.y = fmaxf(t.y + abv.y, 0.f);
+        t.z = fmaxf(t.z + abv.z, 0.f);
+        t.w = fmaxf(t.w + abv.w, 0.f);
+      }
+      uint2 p0, p1, p2;
+      split4(t, p0, p1, p2);
+      const int d = ((tid >> 2) + 64 * q) * RST + a_seg * 8;
+      *reinterpret_cast<uint2*>(buf + d) = p0;
+      *reinterpret_cast<uint2*>(buf + A_PLANE + d) = p1;
+      *reinterpret_cast<uint2*>(buf + 2 * A_PLANE + d) = p2;
+    }
+#pragma unroll
+    for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(buf + w_dst[q]) = wv[q];
+  };
+  const int a_rd = (wm * TM * 32 + lr) * RST + kh * 16;
+  const int w_rd = 3 * A_PLANE + (wn * TN * 32 + lr) * RST + kh * 16;
+  constexpr int TH = TM / 2;  // row tiles per MFMA half-phase
+  // fragment reads: A row tiles [i0, i0 + TH) of a buffer, and all W column tiles
+  auto fread_a = [&](const unsigned char* buf, u32x4 (&fa)[3][TH], int i0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < TH; ++i)
+        fa[p][i] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + a_rd + (i0 + i) * 32 * RST);
+  };
+  auto fread_w = [&](const unsigned char* buf, u32x4 (&fb)[3][TN]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[p][j] = *reinterpret_cast<const u32x4*>(buf + p * W_PLANE + w_rd + j * 32 * RST);
+  };
+  auto mma = [&](const u32x4 (&fa)[3][TH], const u32x4 (&fb)[3][TN], int i0) {
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[0][i]), a1 = __builtin_bit_cast(bf16x8, fa[1][i]),
+                     a2 = __builtin_bit_cast(bf16x8, fa[2][i]);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[0][j]), b1 = __builtin_bit_cast(bf16x8, fb[1][j]),
+                     b2 = __builtin_bit_cast(bf16x8, fb[2][j]);
+        f32x16 c = acc[i0 + i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+        acc[i0 + i][j] = c;
+      }
+  };
+
+  // fragment registers: the two A halves of the current slab, the current and the next W set
+  u32x4 faL[3][TH], faH[3][TH], fbA[3][TN], fbB[3][TN];
+  unsigned char* buf0 = smem;
+  unsigned char* buf1 = smem + BUF;
+  // prologue: pairs 0 and 1 in registers, slab 0 staged, its first fragments read
+  gload(0, ra0, rw0, rb0);
+  gload(1, ra1, rw1, rb1);
+  stage(buf0, ra0[0], rw0[0], rb0[0]);
+  __syncthreads();
+  fread_a(buf0, faL, 0);
+  fread_w(buf0, fbA);
+
+  // One slab = two half-phases of TH*TN*6 MFMAs.  Phase 1 (low row tiles) covers the LDS reads
+  // of the high tiles' fragments and the staging of slab s+1 (STAGE_); phase 2 (high tiles)
+  // covers the reads of slab s+1's first fragments.  No branch in the body.
+#define PAVE_SLAB(bufc, bufn, fbc, fbn, STAGE_, LOAD_) \
+  {                                                    \
+    fread_a(bufc, faH, TH);                            \
+    STAGE_;                                            \
+    LOAD_;                                             \
+    mma(faL, fbc, 0);                                  \
+    __syncthreads(); /* bufn complete everywhere */    \
+    fread_a(bufn, faL, 0);                             \
+    fread_w(bufn, fbn);                                \
+    mma(faH, fbc, TH);                                 \
+  }
+  // 4 slabs per trip (K % 64 == 0): pair P = 2t in set 0, pair P+1 in set 1.  A set is
+  // reloaded with the pair two ahead right after its second slab has been staged.
+  for (int s = 0; s < nslabs; s += 4) {
+    const int P = s >> 1;
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rw0[1], rb0[1]), gload(P + 2, ra0, rw0, rb0))
+    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra1[0], rw1[0], rb1[0]), (void)0)
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rw1[1], rb1[1]), gload(P + 3, ra1, rw1, rb1))
+    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra0[0], rw0[0], rb0[0]), (void)0)
+  }
+#undef PAVE_SLAB
+
+  // ---- epilogue: per wave, 32-row chunks of its (TM*32) x (TN*32) tile through LDS
+  constexpr int CW = TN * 32;            // chunk width (floats)
+  constexpr int CST = CW + 4;            // row stride, keeps float4 alignment
+  constexpr int RV = CW / 4;             // float4 per chunk row
+  constexpr int RPP = 64 / RV;           // rows per pass of the wave
+  constexpr int NPASS = 32 / RPP;
+  static_assert(4 * 32 * CST * 4 <= SMEM, "epilogue chunks must fit the operand buffers");
+  __syncthreads();  // operand tiles fully consumed by every wave
+  float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * CST;
+  const int c4 = lane % RV;
+  const int ncol = n0 + wn * CW + c4 * 4;
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CST + j * 32 + lr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 res[NPASS];
+    if (residual) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const long long gm = m0 + wm * TM * 32 + i * 32 + ps * RPP + lane / RV;
+        res[ps] = gm < M ? *reinterpret_cast<const float4*>(residual + gm * N + ncol)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int lrow = ps * RPP + lane / RV;
+      const long long gm = m0 + wm * TM * 32 + i * 32 + lrow;
+      if (gm < M) {
+        float4 v = *reinterpret_cast<const float4*>(Cs + lrow * CST + c4 * 4);
+        v.x += b4.x;
+        v.y += b4.y;
+        v.z += b4.z;
+        v.w += b4.w;
+        if (residual) {
+          v.x += res[ps].x;
+          v.y += res[ps].y;
+          v.z += res[ps].z;
+          v.w += res[ps].w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(out + gm * N + ncol) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// fp32 [n] -> three bf16 planes [3][n] (exact truncation split)
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x,
+                                                           uint16_t* __restrict__ planes,
+                                                           const long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    const unsigned h0 = hi16(v);
+    const float r1 = v - __uint_as_float(h0);
+    const unsigned h1 = hi16(r1);
+    const float r2 = r1 - __uint_as_float(h1);
+    planes[i] = (uint16_t)(h0 >> 16);
+    planes[n + i] = (uint16_t)(h1 >> 16);
+    planes[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
+template <int TM, int TN, bool ABIAS>
+int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
+                float* out, long long M, int K, int N, int relu, const float* a_bias,
+                hipStream_t st) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  constexpr int SMEM = 2 * 3 * (BM + BN) * RST;
+  const long long gx = ((M + BM - 1) / BM) * (N / BN);
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<TM, TN, ABIAS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_bf16x3: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<TM, TN, ABIAS>), dim3((unsigned)gx), dim3(256), SMEM, st, a, w,
+                     bias, residual, out, (int)M, K, N, relu, a_bias);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pave_split_bf16x3_f32(const float* x, void* planes, long long n, void* stream) {
+  if (!x || !planes || n <= 0) return pave_internal_fail(PAVE_E_ARG, "split_bf16x3: bad argument");
+  const long long nb = (n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)nb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint16_t*>(planes), n);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
+                         const float* bias, const float* residual, float* out, long long M, int K,
+                         int N, int relu, void* stream) {
+  if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
+  if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
+  if (K % 64 != 0 || N % 128 != 0)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 required");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint16_t* w = static_cast<const uint16_t*>(w_planes);
+  if (a_bias) return launch_gemm<4, 2, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+  return launch_gemm<4, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "pave_hip.h"
+#include "pave_internal.h"
 
 namespace {
 
@@ -1431,6 +1432,8 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(
 }
 
 }  // namespace
+
+int pave_internal_fail(int code, const char* msg) { return fail(code, msg); }
 
 extern "C" {
 

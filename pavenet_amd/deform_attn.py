@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .bricks import (BaseModule, batch_first, constant_init, linear_residual_norm,
+from .bricks import (BaseModule, batch_first, constant_init, linear_residual_norm, linear_rows,
                      seq_first_view, xavier_init)
 from .registry import ATTENTION, MMCV_ATTENTION
 
@@ -70,6 +70,14 @@ class _CatProj:
                 self._cat_b = torch.cat([m.bias for m in offs + logits], 0).contiguous()
             self._cat_key = key
         return self._cat_w, self._cat_b
+
+
+def _proj(linear, x):
+    """nn.Linear on [..., K] through bricks.linear_rows (split GEMM when enabled)."""
+    if x.is_cuda and x.is_contiguous():
+        y = linear_rows(x.reshape(-1, x.shape[-1]), linear.weight, linear.bias)
+        return y.view(x.shape[:-1] + (y.shape[-1],))
+    return linear(x)
 
 
 def _fused_ok(mod, *tensors):
@@ -144,7 +152,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             q, v = query, value
         bs, num_query, _ = q.shape
         num_value = v.shape[1]
-        v = self.value_proj(v)
+        v = _proj(self.value_proj, v)
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
         v = v.view(v.shape[0], num_value, self.num_heads, -1)
@@ -152,7 +160,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                  and reference_points.shape[-1] == 2)
         if fused:
             w, b = self._cat_proj()
-            proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+            proj = linear_rows(q.reshape(bs * num_query, self.embed_dims), w, b)
             ref = reference_points.reshape(1, bs * num_query, self.num_levels, 2)
             if not ref.is_contiguous():
                 ref = ref.contiguous()
@@ -245,7 +253,7 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         """value_bf [B*T, S, C] -> [B*T, S, 8, 32]: padding mask, then value_proj."""
         if key_padding_mask is not None:
             value_bf = value_bf.masked_fill(key_padding_mask[..., None], 0.0)
-        v = self.value_proj(value_bf)
+        v = _proj(self.value_proj, value_bf)
         return v.view(v.shape[0], v.shape[1], self.num_heads, -1)
 
     supports_post_norm = True
@@ -281,7 +289,7 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
             return out if self.batch_first else seq_first_view(out)
         assert v.shape[0] == bs * T, 'value must hold num_frames slabs per clip'
         w, b = self._cat_proj()
-        proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+        proj = linear_rows(q.reshape(bs * num_query, self.embed_dims), w, b)
         if _fused_ok(self, q, v) and L <= 4 and K <= 24:
             ref = reference_points if reference_points.is_contiguous() \
                 else reference_points.contiguous()
@@ -312,7 +320,7 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         if Tl > 0:
             assert v.shape[0] == bs * Tl
             w, b = self._cat_proj(frames=tuple(shard.local))
-            proj = F.linear(q.reshape(bs * num_query, self.embed_dims), w, b)
+            proj = linear_rows(q.reshape(bs * num_query, self.embed_dims), w, b)
             ref = reference_points.view(bs, T, num_query, L, 2 * K)[:, shard.local].reshape(
                 bs, Tl * num_query, L, 2 * K).contiguous()
             row, smax, ssum = ops.deform_attn_pose_fused(
@@ -387,7 +395,7 @@ class MultiScaleDeformablePoseAttention(MulFramesMultiScaleDeformablePoseAttenti
                          batch_first=batch_first)
 
     def project_value(self, value_bf, key_padding_mask=None):
-        v = self.value_proj(value_bf)
+        v = _proj(self.value_proj, value_bf)
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
         return v.view(v.shape[0], v.shape[1], self.num_heads, -1)
@@ -454,7 +462,7 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         """memory_bt [B, T, S, C] (+ mask [B, T, S]) -> [B*T, S, 8, 32]."""
         if key_padding_mask is not None:
             memory_bt = memory_bt.masked_fill(key_padding_mask[..., None], 0.0)
-        v = self.value_proj(memory_bt)
+        v = _proj(self.value_proj, memory_bt)
         B, T, S, _ = v.shape
         return v.view(B * T, S, self.num_heads, -1)
 
@@ -508,7 +516,7 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
             assert _fused_ok(self, q, v) and L == 4 and P == 4
             if Tl > 0:
                 w, b = self._cat_proj(frames=tuple(shard.local))
-                proj = F.linear(q.reshape(N * num_query, self.embed_dims), w, b)
+                proj = linear_rows(q.reshape(N * num_query, self.embed_dims), w, b)
                 ref = reference_points.reshape(T, N * num_query, L, 2)[shard.local].contiguous()
                 unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
                 row, smax, ssum = ops.deform_attn_grid_fused(
@@ -525,7 +533,7 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
             out = linear_residual_norm(out, self.output_proj, idt, post_norm)
             return out if self.batch_first else seq_first_view(out)
         w, b = self._cat_proj()
-        proj = F.linear(q.reshape(N * num_query, self.embed_dims), w, b)
+        proj = linear_rows(q.reshape(N * num_query, self.embed_dims), w, b)
         ref = reference_points.reshape(T, N * num_query, L, 2)
         if _fused_ok(self, q, v) and L == 4 and P == 4:
             unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)

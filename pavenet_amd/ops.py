@@ -428,3 +428,60 @@ def bias_relu_maxpool_nhwc(x, bias):
                                                  N, H, W, C, _stream_ptr())
     native.check(st, 'bias_relu_maxpool_nhwc')
     return y.permute(0, 3, 1, 2)
+
+
+def split_bf16x3(x):
+    """fp32 tensor -> int16 tensor [3, *x.shape]: three bf16 planes with x == p0 + p1 + p2 exactly
+    (truncation split)."""
+    lib = native.load()
+    _dev(x, 'x', torch.float32)
+    planes = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.pave_split_bf16x3_f32(x.data_ptr(), planes.data_ptr(), x.numel(), _stream_ptr())
+    native.check(st, 'split_bf16x3')
+    return planes
+
+
+def split_weight_bf16x3(weight):
+    """nn.Linear weight [N, K] -> the W operand of `gemm_bf16x3`: int16 [K/16, 3, N, 16], i.e.
+    the three bf16 planes cut into 16-wide K slabs, slab-major, so that one slab of a column
+    tile is contiguous in memory (every 128-byte line is fetched once)."""
+    _require(weight.dim() == 2 and weight.shape[1] % 64 == 0 and weight.shape[0] % 128 == 0,
+             'split_weight_bf16x3: weight [N % 128 == 0, K % 64 == 0]')
+    N, K = weight.shape
+    planes = split_bf16x3(weight.contiguous())
+    return planes.view(3, N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
+
+
+def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None):
+    """out[M, N] = act(A' @ W^T + bias + residual), A' = relu(a + a_bias) if a_bias is given, on
+    the bf16 matrix cores with both operands split exactly into 3 bf16 terms (6 MFMA products,
+    fp32 accumulate: fp32-level accuracy at up to 2.7x the fp32 MFMA rate).
+    w_planes = split_weight_bf16x3(weight [N, K]).  `residual` may be the tensor given as `out`."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3
+             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+             'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
+    M, K = a.shape
+    N = w_planes.shape[2]
+    for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
+        if t is not None:
+            _dev(t, nm, torch.float32)
+            _require(t.numel() == n, f'gemm_bf16x3: {nm} has {t.numel()} elements, expected {n}')
+    if residual is not None:
+        _dev(residual, 'residual', torch.float32)
+        _require(tuple(residual.shape) == (M, N), 'gemm_bf16x3: residual [M,N]')
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _dev(out, 'out', torch.float32)
+        _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
+        st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
+                                      ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
+                                      _stream_ptr())
+    native.check(st, 'gemm_bf16x3')
+    return out

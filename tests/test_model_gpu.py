@@ -427,3 +427,35 @@ def test_streaming_video_equals_per_window_simple_test():
         assert got_c[2].shape == exp[2].shape
         np.testing.assert_allclose(got_c[2].cpu().numpy(), exp[2].cpu().numpy(),
                                    rtol=1e-4, atol=1e-2)
+
+
+def test_split_gemm_mode_matches_native():
+    """Opt-in bf16x3 split GEMM under the whole model: encoder memory and final keypoints agree
+    with the native fp32 path to fp32 rounding (selections pinned: near-tie robust)."""
+    from pavenet_amd import bricks
+    m = _build(3, 12)
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    img = _t(seeded_array('split.img', (1, 3, 3, 128, 160))).cuda()
+    old_rows = bricks._GEMM['min_rows']
+    try:
+        with torch.no_grad():
+            feat = m.extract_feat(img)
+            outs = m.bbox_head(feat, metas)
+            res = m.bbox_head.get_bboxes(outs, metas)
+            prop = m.bbox_head.transformer.last_topk_proposals
+            bricks.set_gemm_mode('bf16x3')
+            bricks._GEMM['min_rows'] = 1          # exercise it at test sizes
+            feat2 = m.extract_feat(img)
+            outs2 = m.bbox_head(feat2, metas, force_topk_proposals=prop)
+            res2 = m.bbox_head.get_bboxes(outs2, metas, force_score_topk=res['score_index'])
+    finally:
+        bricks.set_gemm_mode('native')
+        bricks._GEMM['min_rows'] = old_rows
+    assert len(bricks._SPLIT_CACHE) > 10, 'the split GEMM was not exercised'
+    for a, b in zip(feat, feat2):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(outs2['memory'].cpu().numpy(), outs['memory'].cpu().numpy(),
+                               rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(res2['kpts'].cpu().numpy(), res['kpts'].cpu().numpy(),
+                               rtol=1e-4, atol=1e-2)

@@ -63,6 +63,15 @@ def main():
             c = torch.randn(M, N, device=dev)
             fn = lambda: c.addmm_(a, wt.t())
         ms = timed(fn)
+        if N % 128 == 0 and K % 64 == 0:
+            wp = ops.split_weight_bf16x3(wt)
+            if kind == 'res':
+                f3 = lambda: ops.gemm_bf16x3(a, wp, bias, c, relu=False, out=c)
+            else:
+                f3 = lambda: ops.gemm_bf16x3(a, wp, bias, None, relu=(kind == 'act'))
+            ms3 = timed(f3)
+            print(f'   {label}: library {ms:.3f} ms ({2.0 * M * K * N / ms / 1e9:.0f} TF/s)   '
+                  f'bf16x3 split {ms3:.3f} ms ({2.0 * M * K * N / ms3 / 1e9:.0f} TF/s)')
         own = float('nan')
         if kind == 'res' and 'conv3' in label:
             wkn = wt.t().contiguous()
