@@ -131,6 +131,12 @@ int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, 
 int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* res,
                                 const float* gamma, const float* beta, float* y, long long rows,
                                 int C, float eps, void* stream);
+/* As above, plus y_plus[r,:] = y[r,:] + pos[r %% pos_rows, :] in the same pass: the next
+ * encoder layer's `query + query_pos` (mmcv multi_scale_deform_attn.py:353-354). */
+int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const float* res,
+                                    const float* gamma, const float* beta, float* y,
+                                    const float* pos, long long pos_rows, float* y_plus,
+                                    long long rows, int C, float eps, void* stream);
 
 /*
  * Encoder deformable attention ([R2], T = 1, L = 4, P = 4) with an LDS-staged value window for

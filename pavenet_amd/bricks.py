@@ -13,6 +13,7 @@ token-major ``[bs*n, C]`` matrices feed the GEMMs and HIP kernels without copies
 """
 import copy
 import math
+import os
 import warnings
 
 import torch
@@ -108,6 +109,10 @@ def _fusable(*tensors):
 # split EXACTLY into three bf16 terms, six bf16 MFMAs per product tile, fp32 accumulate -- fp32-level
 # accuracy (tests/test_ops_gpu.py::test_gemm_bf16x3_accuracy_vs_fp64) at 1.05-1.45x hipBLASLt's
 # fp32 rate on the K >= 256 shapes of this model.  Opt-in: the default bench number is 'native'.
+# Layer i's closing LayerNorm can also emit `out + query_pos` for layer i+1 (one pass less);
+# measured SLOWER on the bench workload (122.4 vs 121.1 ms/step: the extra 640 MB store costs more
+# than the broadcast add it saves), so it is off unless PAVE_POS_FUSION=1.
+FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
 _GEMM = {'mode': 'native', 'min_rows': 8192}
 _SPLIT_CACHE = {}
 
@@ -168,7 +173,7 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
     return torch.relu_(y) if relu else y
 
 
-def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False):
+def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False, pos_rows=None):
     """(x @ W^T + b + identity) [-> LayerNorm], batch-first tensors [..., C].
 
     Device fp32: the residual rides the GEMM (beta = 1, C = identity) and bias + LayerNorm are
@@ -185,6 +190,11 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
             t = idt2.addmm_(x2, linear.weight.t())
         else:
             t = torch.addmm(idt2, x2, linear.weight.t())
+        if post_norm is not None and pos_rows is not None:
+            # second output: LayerNorm(..) + pos, the next layer's `query + query_pos`
+            t, tp = ops.bias_add_layernorm(t, linear.bias, None, post_norm.weight, post_norm.bias,
+                                           post_norm.eps, pos=pos_rows)
+            return t.view(identity_bf.shape), tp.view(identity_bf.shape)
         if post_norm is not None:
             t = ops.bias_add_layernorm(t, linear.bias, None, post_norm.weight, post_norm.bias,
                                        post_norm.eps)
@@ -192,7 +202,8 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
             ops.bias_act_rows_(t, linear.bias, None, relu=False)
         return t.view(identity_bf.shape)
     out = linear(x_bf) + identity_bf
-    return post_norm(out) if post_norm is not None else out
+    out = post_norm(out) if post_norm is not None else out
+    return (out, None) if pos_rows is not None else out
 
 
 class ConvModule(nn.Module):
@@ -297,15 +308,32 @@ class FFN(BaseModule):
         return (self.num_fcs == 2 and self.add_identity and isinstance(self.activate, nn.ReLU)
                 and _fusable(x) and x.dim() == 3)
 
-    def forward(self, x, identity=None, post_norm=None, inplace_residual=False):
+    def forward(self, x, identity=None, post_norm=None, inplace_residual=False, carry=None,
+                query_pos=None):
+        """carry (dict with carry['emit'] = True) + query_pos: also produce out + query_pos in the
+        LayerNorm pass and leave it in carry['q_plus'] for the next layer's attention."""
         if identity is None:
             identity = x
         if self._fast_ok(x):
             xb, ib = batch_first(x), batch_first(identity)
             fc1, fc2 = self.layers[0][0], self.layers[1]
             h = linear_rows(xb.reshape(-1, xb.shape[-1]), fc1.weight, fc1.bias, relu=True)
+            pos_rows = None
+            if carry is not None and carry.get('emit') and post_norm is not None \
+                    and query_pos is not None and query_pos.dtype == torch.float32:
+                pb = batch_first(query_pos)
+                if pb.dim() == 3 and pb.stride(0) == 0 and pb[0].is_contiguous():
+                    pos_rows = pb[0]                      # one [S, C] table shared by all frames
+                elif pb.is_contiguous() and pb.shape == xb.shape:
+                    pos_rows = pb.reshape(-1, pb.shape[-1])
             out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm,
-                                       inplace=inplace_residual)
+                                       inplace=inplace_residual, pos_rows=pos_rows)
+            if pos_rows is not None:
+                out, plus = out
+                out = seq_first_view(out)
+                if plus is not None:
+                    carry['q_plus'], carry['q_for'] = seq_first_view(plus), out
+                return out
             return seq_first_view(out)
         if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
             out = self.layers(x.transpose(0, 1)).transpose(0, 1)  # keep the token-major storage
@@ -433,6 +461,7 @@ class BaseTransformerLayer(BaseModule):
             assert len(attn_masks) == self.num_attn
         order = self.operation_order
         skip_norm = False
+        carry = kwargs.pop('fusion_carry', None)
         for pos, layer in enumerate(order):
             # post-norm layers: hand the following LayerNorm to a module that can fuse it with
             # its own bias + residual epilogue (one pass instead of three)
@@ -444,10 +473,15 @@ class BaseTransformerLayer(BaseModule):
                     fuse = dict(post_norm=self.norms[norm_index])
             if layer == 'self_attn':
                 temp_key = temp_value = query
+                plus = {}
+                if carry is not None and carry.get('q_for') is query and \
+                        getattr(self.attentions[attn_index], 'supports_query_plus_pos', False):
+                    plus = dict(query_plus_pos=carry.pop('q_plus'))  # made by the previous LayerNorm
+                    carry.pop('q_for')
                 query = self.attentions[attn_index](
                     query, temp_key, temp_value, identity if self.pre_norm else None,
                     query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=query_key_padding_mask, **fuse, **kwargs)
+                    key_padding_mask=query_key_padding_mask, **plus, **fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
@@ -468,6 +502,9 @@ class BaseTransformerLayer(BaseModule):
             elif layer == 'ffn':
                 if kwargs.get('inplace_residual', False):
                     fuse = dict(fuse, inplace_residual=True)
+                if carry is not None and fuse.get('post_norm') is not None and \
+                        pos + 2 == len(order) and isinstance(self.ffns[ffn_index], FFN):
+                    fuse = dict(fuse, carry=carry, query_pos=query_pos)
                 query = self.ffns[ffn_index](query, identity if self.pre_norm else None, **fuse)
                 ffn_index += 1
             skip_norm = bool(fuse)
@@ -507,7 +544,14 @@ class TransformerLayerSequence(BaseModule):
 
     def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None,
                 query_key_padding_mask=None, key_padding_mask=None, **kwargs):
-        for layer in self.layers:
+        # layer i's closing LayerNorm can also write `out + query_pos`, which layer i+1's
+        # self-attention starts with (one elementwise pass less per layer)
+        carry = {} if (query.is_cuda and query_pos is not None and key is None
+                       and not torch.is_grad_enabled() and FUSE_QUERY_POS) else None
+        for i, layer in enumerate(self.layers):
+            if carry is not None:
+                carry['emit'] = i + 1 < len(self.layers)
+                kwargs['fusion_carry'] = carry
             query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos,
                           attn_masks=attn_masks, query_key_padding_mask=query_key_padding_mask,
                           key_padding_mask=key_padding_mask, **kwargs)

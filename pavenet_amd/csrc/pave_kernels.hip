@@ -589,7 +589,10 @@ template <int VPL>  // float4 vectors per lane: C = 256 * VPL
 __global__ __launch_bounds__(256) void bias_add_layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-    const long long rows, const int C, const float eps) {
+    const long long rows, const int C, const float eps, const float* __restrict__ pos,
+    const long long pos_rows, float* __restrict__ y_plus) {
+  // optional second output y_plus[r] = y[r] + pos[r % pos_rows]: the next layer's
+  // `query + query_pos` (MO:353-354) written in the same pass
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -637,6 +640,8 @@ __global__ __launch_bounds__(256) void bias_add_layernorm_kernel(
     }
     const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
     float4* y4 = reinterpret_cast<float4*>(y + r * C);
+    const float4* p4 = y_plus ? reinterpret_cast<const float4*>(pos + (r % pos_rows) * C) : nullptr;
+    float4* yp4 = y_plus ? reinterpret_cast<float4*>(y_plus + r * C) : nullptr;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
       const int i = lane + k * 64;
@@ -649,6 +654,10 @@ __global__ __launch_bounds__(256) void bias_add_layernorm_kernel(
         o.z = (v[k].z - mean) * rstd * g.z + b.z;
         o.w = (v[k].w - mean) * rstd * g.w + b.w;
         y4[i] = o;
+        if (yp4) {
+          const float4 pp = p4[i];
+          yp4[i] = make_float4(o.x + pp.x, o.y + pp.y, o.z + pp.z, o.w + pp.w);
+        }
       }
     }
   }
@@ -1572,7 +1581,17 @@ int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, 
 int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* res,
                                 const float* gamma, const float* beta, float* y, long long rows,
                                 int C, float eps, void* stream) {
+  return pave_bias_add_layernorm_pos_f32(x, bias, res, gamma, beta, y, nullptr, 0, nullptr, rows, C,
+                                         eps, stream);
+}
+
+int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const float* res,
+                                    const float* gamma, const float* beta, float* y,
+                                    const float* pos, long long pos_rows, float* y_plus,
+                                    long long rows, int C, float eps, void* stream) {
   if (!x || !y || !gamma || !beta) return fail(PAVE_E_ARG, "bias_add_layernorm: null pointer");
+  if ((y_plus != nullptr) != (pos != nullptr) || (pos && pos_rows <= 0))
+    return fail(PAVE_E_ARG, "bias_add_layernorm: pos, pos_rows > 0 and y_plus go together");
   if (rows <= 0 || C <= 0 || (C & 3) || C > 1024)
     return fail(PAVE_E_ARG, "bias_add_layernorm: C must be a multiple of 4, <= 1024");
   long long nb = (rows + 3) / 4;
@@ -1581,7 +1600,7 @@ int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* 
   const int vpl = ((C >> 2) + 63) / 64;
 #define PAVE_LN(V)                                                                              \
   hipLaunchKernelGGL((bias_add_layernorm_kernel<V>), dim3((unsigned)nb), dim3(256), 0, st, x,   \
-                     bias, res, gamma, beta, y, rows, C, eps)
+                     bias, res, gamma, beta, y, rows, C, eps, pos, pos_rows, y_plus)
   switch (vpl) {
     case 1: PAVE_LN(1); break;
     case 2: PAVE_LN(2); break;

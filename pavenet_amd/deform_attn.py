@@ -136,15 +136,18 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         return [self.sampling_offsets], [self.attention_weights]
 
     supports_post_norm = True
+    supports_query_plus_pos = True
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, post_norm=None, **kwargs):
+                level_start_index=None, post_norm=None, query_plus_pos=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
             identity = query
-        if query_pos is not None:
+        if query_plus_pos is not None:   # `query + query_pos`, already made by the producer
+            query = query_plus_pos
+        elif query_pos is not None:
             query = query + query_pos
         if not self.batch_first:
             q, v = batch_first(query), batch_first(value)

@@ -292,8 +292,10 @@ def bias_act_rows_(x, bias=None, res=None, relu=True):
     return x
 
 
-def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5):
-    """LayerNorm(x + bias + res) over the last dim; x / res dense row-major [..., C]."""
+def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5, pos=None):
+    """LayerNorm(x + bias + res) over the last dim; x / res dense row-major [..., C].
+    With pos ([P, C] rows, P dividing the row count pattern r % P): returns (y, y + pos) from the
+    same pass (the next layer's `query + query_pos`)."""
     lib = native.load()
     _dev(x, 'x', torch.float32)
     C = x.shape[-1]
@@ -301,13 +303,26 @@ def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5):
         _require(res.shape == x.shape and res.is_contiguous() and res.dtype == torch.float32,
                  'bias_add_layernorm: residual must match x')
     out = torch.empty_like(x)
+    rows = x.numel() // C
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    if pos is None:
+        with torch.cuda.device(x.device), _Timed('bias_add_layernorm'):
+            st = lib.pave_bias_add_layernorm_f32(x.data_ptr(), ptr(bias), ptr(res), gamma.data_ptr(),
+                                                 beta.data_ptr(), out.data_ptr(), rows, C,
+                                                 float(eps), _stream_ptr())
+        native.check(st, 'bias_add_layernorm')
+        return out
+    _dev(pos, 'pos', torch.float32)
+    _require(pos.shape[-1] == C and rows % (pos.numel() // C) == 0,
+             'bias_add_layernorm: pos [P, C] with P dividing the number of rows')
+    out_plus = torch.empty_like(x)
     with torch.cuda.device(x.device), _Timed('bias_add_layernorm'):
-        st = lib.pave_bias_add_layernorm_f32(
-            x.data_ptr(), bias.data_ptr() if bias is not None else None,
-            res.data_ptr() if res is not None else None, gamma.data_ptr(), beta.data_ptr(),
-            out.data_ptr(), x.numel() // C, C, float(eps), _stream_ptr())
+        st = lib.pave_bias_add_layernorm_pos_f32(
+            x.data_ptr(), ptr(bias), ptr(res), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+            pos.data_ptr(), pos.numel() // C, out_plus.data_ptr(), rows, C, float(eps),
+            _stream_ptr())
     native.check(st, 'bias_add_layernorm')
-    return out
+    return out, out_plus
 
 
 def deform_attn_enc_window(value, spatial_shapes, level_start_index, proj, ref, *, levels_hw,

@@ -181,6 +181,14 @@ def test_bias_add_layernorm_vs_torch(C):
     out = bias_add_layernorm(x.cuda(), None, None, gamma.cuda(), beta.cuda(), 1e-5)
     exp = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5)
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+    # second output: y + pos, with a pos table shared by the 37 leading rows ([5, C]) or full
+    for pos in (torch.randn(5, C, generator=g), torch.randn(37 * 5, C, generator=g)):
+        y, yp = bias_add_layernorm(x.cuda(), bias.cuda(), res.cuda(), gamma.cuda(), beta.cuda(),
+                                   1e-5, pos=pos.cuda())
+        exp = torch.nn.functional.layer_norm(x + bias + res, (C,), gamma, beta, 1e-5)
+        np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+        assert torch.equal(yp.cpu(), y.cpu() + pos.view(-1, 5, C).expand(37, 5, C)
+                           if pos.shape[0] == 5 else y.cpu() + pos.view(37, 5, C))
 
 
 def test_bias_act_rows_vs_torch():
