@@ -548,7 +548,13 @@ class TransformerLayerSequence(BaseModule):
         # self-attention starts with (one elementwise pass less per layer)
         carry = {} if (query.is_cuda and query_pos is not None and key is None
                        and not torch.is_grad_enabled() and FUSE_QUERY_POS) else None
+        # input_is_shared: the caller still needs `query` afterwards (it aliases the neck output),
+        # so the first attention must not accumulate its residual GEMM into it
+        shared = kwargs.pop('input_is_shared', False)
+        inplace = kwargs.get('inplace_residual', False)
         for i, layer in enumerate(self.layers):
+            if shared and inplace:
+                kwargs['inplace_residual'] = 'ffn_only' if i == 0 else inplace
             if carry is not None:
                 carry['emit'] = i + 1 < len(self.layers)
                 kwargs['fusion_carry'] = carry

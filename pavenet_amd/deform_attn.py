@@ -205,7 +205,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                 aw.contiguous(), self.im2col_step)
         idt = identity if self.batch_first else batch_first(identity)
         out = linear_residual_norm(out, self.output_proj, idt, post_norm,
-                                   inplace=kwargs.get('inplace_residual', False))
+                                   inplace=kwargs.get('inplace_residual', False) is True)
         return out if self.batch_first else seq_first_view(out)
 
 

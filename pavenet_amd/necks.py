@@ -1,5 +1,8 @@
 """``mmdet.ChannelMapper`` (a14), restated from
 third_party/mmdetection/mmdet/models/necks/channel_mapper.py:50-100."""
+import os
+
+import torch
 import torch.nn as nn
 
 from .bricks import BaseModule, ConvModule
@@ -14,6 +17,8 @@ class ChannelMapper(BaseModule):
                  init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')):
         super().__init__(init_cfg)
         assert isinstance(in_channels, (list, tuple))
+        # device eval: levels are written into one flattened buffer (PAVE_NO_FLAT_NECK=1: A/B switch)
+        self.flat_output = os.environ.get('PAVE_NO_FLAT_NECK', '0') != '1'
         self.extra_convs = None
         if num_outs is None:
             num_outs = len(in_channels)
@@ -38,8 +43,47 @@ class ChannelMapper(BaseModule):
                     nn.init.constant_(m.bias, 0)
         self._is_init = True
 
+    def _flat_ok(self, inputs):
+        mods = list(self.convs) + list(self.extra_convs or [])
+        return (not self.training and all(x.is_cuda and x.dtype == torch.float32 for x in inputs)
+                and (self.extra_convs is None or len(self.extra_convs) == 1)
+                and all(m.with_norm and not m.with_activation and m.conv.bias is None
+                        and isinstance(getattr(m, m.norm_name), nn.GroupNorm) for m in mods))
+
+    def _forward_flat(self, inputs):
+        """Same values as `forward`, but every level's GroupNorm writes straight into ONE
+        [n, sum(h*w), C] buffer -- the transformer's flattened multi-level feature
+        (OT:21312-21331) -- and the returned maps are views of it: no concatenation copy."""
+        mods = list(self.convs) + list(self.extra_convs or [])
+        xs = list(inputs) + ([inputs[-1]] if self.extra_convs else [])
+        ys = []
+        for m, x in zip(mods, xs):
+            y = m._conv_deterministic(x) if m.deterministic else None
+            y = m.conv(x) if y is None else y
+            ys.append(y.contiguous(memory_format=torch.channels_last))
+        n, C = ys[0].shape[0], ys[0].shape[1]
+        S = sum(y.shape[2] * y.shape[3] for y in ys)
+        buf = torch.empty((n, S, C), dtype=torch.float32, device=ys[0].device)
+        outs, st = [], 0
+        for m, y in zip(mods, ys):
+            gn = getattr(m, m.norm_name)
+            G = gn.num_groups
+            h, w = y.shape[2:]
+            rows = y.permute(0, 2, 3, 1).reshape(n, h * w, C)          # view of the NHWC storage
+            var, mean = torch.var_mean(rows.view(n, h * w, G, C // G), dim=(1, 3), unbiased=False)
+            rstd = torch.rsqrt(var + gn.eps)[:, :, None]                # [n, G, 1]
+            a = rstd * gn.weight.view(1, G, -1)
+            b = gn.bias.view(1, G, -1) - mean[:, :, None] * a
+            dst = buf[:, st:st + h * w]
+            torch.addcmul(b.reshape(n, 1, C), rows, a.reshape(n, 1, C), out=dst)
+            outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))
+            st += h * w
+        return tuple(outs)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.convs)
+        if self.flat_output and self._flat_ok(inputs):
+            return self._forward_flat(inputs)
         outs = [self.convs[i](inputs[i]) for i in range(len(inputs))]
         if self.extra_convs:
             for i in range(len(self.extra_convs)):

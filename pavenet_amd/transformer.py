@@ -383,6 +383,22 @@ class VideoPoseTransformerMulFrames(Transformer):
         return _collect_frame_branches(self.num_frames, kwargs, suffix)
 
     # -- encoder over independent frames (OT:21277-21322) ----------------------
+    @staticmethod
+    def _flat_view(mlvl_feats):
+        """[n, S, C] tensor aliasing the levels when they already are consecutive slices of one
+        token-major buffer (necks.ChannelMapper._forward_flat), else None."""
+        f0 = mlvl_feats[0]
+        n, C = f0.shape[:2]
+        S = sum(f.shape[2] * f.shape[3] for f in mlvl_feats)
+        off = 0
+        for f in mlvl_feats:
+            h, w = f.shape[2:]
+            if f.dtype != f0.dtype or f.stride() != (S * C, 1, w * C, C) or \
+                    f.data_ptr() != f0.data_ptr() + off * C * f0.element_size():
+                return None
+            off += h * w
+        return f0.as_strided((n, S, C), (S * C, C, 1))
+
     def encode_frames(self, mlvl_feats, mlvl_masks, mlvl_pos_embeds, has_padding=True):
         """Flatten levels and run the encoder.  Frames are independent here, so the result can
         be cached per frame (pavenet_amd.streaming) or computed on another rank (frame sharding).
@@ -395,7 +411,8 @@ class VideoPoseTransformerMulFrames(Transformer):
             mask_flatten.append(mask.flatten(1))
             pos_embed = pos_embed.flatten(2).transpose(1, 2)
             lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
-        feat_flatten = torch.cat(feat_flatten, 1)                      # [n, S, C] contiguous
+        flat = self._flat_view(mlvl_feats) if feat_flatten[0].is_cuda else None
+        feat_flatten = flat if flat is not None else torch.cat(feat_flatten, 1)  # [n, S, C]
         mask_flatten = torch.cat(mask_flatten, 1)
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
         if lvl_pos_embed_flatten.shape[0] != feat_flatten.shape[0]:    # shared across frames
@@ -417,6 +434,7 @@ class VideoPoseTransformerMulFrames(Transformer):
         # every encoder layer input is a temporary owned by this function, so the residual
         # GEMMs may accumulate into it (saves a copy of the 0.6 GB activation per GEMM)
         extra['inplace_residual'] = True
+        extra['input_is_shared'] = flat is not None   # aliases the neck output: keep it intact
         memory = self.encoder(
             query=seq_first_view(feat_flatten), key=None, value=None,
             query_pos=seq_first_view(lvl_pos_embed_flatten), query_key_padding_mask=attn_mask,
