@@ -47,10 +47,11 @@ def parse():
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
     ap.add_argument('--cpu-baseline-frames', type=int, default=None)
-    ap.add_argument('--gemm', choices=('native', 'bf16x3'), default='native',
+    ap.add_argument('--gemm', choices=('native', 'bf16x3', 'bf16x2', 'bf16', 'fp16'), default='native',
                     help="dense projections: 'native' = hipBLASLt fp32 MFMA (the headline), "
                          "'bf16x3' = hand-written exact-split GEMM on the bf16 MFMA (fp32-level "
-                         "accuracy; reported under config.gemm, see DESIGN.md)")
+                         "accuracy), 'bf16' = plain bf16 operands (BASELINE config 5's reduced-"
+                         "precision projections); reported under config.gemm, see DESIGN.md")
     return ap.parse_args()
 
 

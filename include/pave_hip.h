@@ -221,22 +221,27 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
                                     int W, int C, void* stream);
 
 /*
- * fp32 row GEMM on the bf16 matrix cores by exact 3-way operand splitting (6 bf16 MFMAs per
- * product tile, fp32 accumulate; error <= 2^-23 relative per product, i.e. fp32-level):
+ * fp32 row GEMM on the bf16 matrix cores by operand splitting into `nplanes` bf16 terms:
+ *   nplanes = 3: exact split, 6 bf16 MFMAs per product tile, error <= 2^-23 relative per product
+ *                (fp32-level);  2: 3 MFMAs, ~2^-16;  1: plain bf16 operands;  PAVE_PLANES_FP16:
+ *                plain fp16 operands (BASELINE config 5's "fp16 MFMA projections") -- always
+ *                with fp32 accumulation and fp32 in/out.
  *   out[M, N] = act(A'[M, K] * W[N, K]^T + bias[N] + residual[M, N]),
  *   A' = a_bias ? relu(a + a_bias[K]) : a
  * = nn.Linear (mmcv FFN / projections, bricks/transformer.py:1046-1120) with the residual and
  * activation of its caller in the epilogue.  `w_planes` = the weight [N, K] split once by
- * pave_split_bf16x3_f32 into three bf16 planes and re-laid slab-major [K/16][3][N][16] (one
- * 16-wide K slab of a column tile contiguous; pavenet_amd.ops.split_weight_bf16x3).
+ * pave_split_bf16x3_f32 into `nplanes` bf16 planes and re-laid slab-major [K/16][nplanes][N][16]
+ * (one 16-wide K slab of a column tile contiguous; pavenet_amd.ops.split_weight_bf16x3).
  * residual may alias out.  K %% 64 == 0, N %% 128 == 0, M < 2^31.
  */
+#define PAVE_PLANES_FP16 16 /* nplanes value: ONE plane of fp16 (not bf16) operands */
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
                          const float* bias, const float* residual, float* out, long long M, int K,
-                         int N, int relu, void* stream);
+                         int N, int relu, int nplanes, void* stream);
 
-/* x[n] fp32 -> planes[3][n] bf16 with x = p0 + p1 + p2 exactly (truncation split). */
-int pave_split_bf16x3_f32(const float* x, void* planes, long long n, void* stream);
+/* x[n] fp32 -> planes[nplanes][n] bf16: truncation terms, the last rounded to nearest even
+ * (nplanes = 3: x = p0 + p1 + p2 exactly). */
+int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -117,8 +117,15 @@ _GEMM = {'mode': 'native', 'min_rows': 8192}
 _SPLIT_CACHE = {}
 
 
+_PLANES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'fp16': 16}   # 16 = ops.PLANES_FP16
+
+
 def set_gemm_mode(mode):
-    assert mode in ('native', 'bf16x3')
+    """'native' (hipBLASLt fp32) | 'bf16x3' (exact 3-term split, fp32-level accuracy) |
+    'bf16x2' (2 terms, ~2^-16) | 'bf16' / 'fp16' (plain 16-bit operands, fp32 accumulate; 'fp16' is
+    BASELINE config 5's "fp16 MFMA projections": keypoints stay within 0.5 px of fp32 in the
+    parity test; fp16 operands overflow above 65504)."""
+    assert mode == 'native' or mode in _PLANES
     _GEMM['mode'] = mode
 
 
@@ -129,11 +136,13 @@ def get_gemm_mode():
 def _split_weight(weight):
     """Weight [N, K] -> cached slab-major bf16x3 planes (re-split when the tensor changes)."""
     from . import ops
-    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    planes = _PLANES[_GEMM['mode']]
+    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), planes)
     hit = _SPLIT_CACHE.get(slot)
     if hit is None or hit[0] != weight._version:
         with torch.no_grad():
-            hit = (weight._version, ops.split_weight_bf16x3(weight.detach().contiguous()))
+            hit = (weight._version,
+                   ops.split_weight_bf16x3(weight.detach().contiguous(), planes))
         if len(_SPLIT_CACHE) > 1024:
             _SPLIT_CACHE.clear()
         _SPLIT_CACHE[slot] = hit
@@ -142,9 +151,10 @@ def _split_weight(weight):
 
 def split_gemm_ok(x2, weight):
     """Shapes / dtypes the split GEMM takes (and where it beats the library)."""
-    return (_GEMM['mode'] == 'bf16x3' and x2.is_cuda and x2.dtype == torch.float32
+    return (_GEMM['mode'] in _PLANES and x2.is_cuda and x2.dtype == torch.float32
             and x2.dim() == 2 and x2.is_contiguous() and weight.dtype == torch.float32
-            and weight.shape[1] % 64 == 0 and weight.shape[1] >= 256
+            and weight.shape[1] % 64 == 0
+            and weight.shape[1] >= (256 if _GEMM['mode'] == 'bf16x3' else 64)
             and weight.shape[0] % 128 == 0 and x2.shape[0] >= _GEMM['min_rows']
             and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
 
@@ -158,7 +168,7 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
         from . import ops
         out = residual if (residual is not None and inplace_residual) else None
         return ops.gemm_bf16x3(x2, _split_weight(weight), bias, residual, relu=relu, out=out,
-                               a_bias=a_bias)
+                               a_bias=a_bias, fp16=_GEMM['mode'] == 'fp16')
     if a_bias is not None:
         x2 = torch.relu(x2 + a_bias)
     if residual is not None:

@@ -44,39 +44,54 @@ __device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) {
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
 
-// exact 3-way bf16 split of 4 consecutive fp32 -> 3 x (4 bf16 = 8 bytes)
-__device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned h0[4], h1[4], h2[4];
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// two fp32 -> two bf16 (or fp16), round to nearest even
+template <bool F16 = false>
+__device__ __forceinline__ unsigned pack_rne(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  if (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// P-term bf16 split of 4 consecutive fp32 -> P x (4 bf16 = 8 bytes).  All terms but the last
+// are truncations (exact residuals); the last is rounded to nearest (for P = 3 it is exact
+// either way: the residual has at most 8 significant bits).
+template <int P, bool F16>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&p)[P]) {
+  float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h0[i] = hi16(x[i]);
-    const float r1 = x[i] - __uint_as_float(h0[i]);
-    h1[i] = hi16(r1);
-    const float r2 = r1 - __uint_as_float(h1[i]);
-    h2[i] = __float_as_uint(r2);  // <= 8 significant bits: its high half is exact
+  for (int t = 0; t < P - 1; ++t) {
+    unsigned h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = hi16(x[i]);
+      x[i] -= __uint_as_float(h[i]);
+    }
+    p[t] = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
   }
-  p0 = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
-  p1 = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
-  p2 = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
+  p[P - 1] = make_uint2(pack_rne<F16>(x[0], x[1]), pack_rne<F16>(x[2], x[3]));
 }
 
 // Software pipeline (one wave per SIMD, so nothing else hides latency):
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
 //   slab s's MFMAs, into a second fragment register set.
-template <int TM, int TN, bool ABIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
+template <int TM, int TN, bool ABIAS, int P, bool F16>
+__device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
-  constexpr int BUF = 3 * (A_PLANE + W_PLANE);                 // one LDS buffer
-  constexpr int SMEM = 2 * BUF;
+  constexpr int BUF = P * (A_PLANE + W_PLANE);                 // one LDS buffer
+  constexpr int SMEM = (2 * BUF > 4 * 32 * (TN * 32 + 4) * 4) ? 2 * BUF : 4 * 32 * (TN * 32 + 4) * 4;
   constexpr int APASS = BM / 64;   // float4 loads of A per thread per slab (4 threads per row)
-  constexpr int WV = (3 * BN * 2) / 256;  // uint4 loads of W per thread per slab (2 per row-plane)
-  static_assert((3 * BN * 2) % 256 == 0, "W slab must divide over the block");
+  constexpr int WV = (P * BN * 2) / 256;  // uint4 loads of W per thread per slab (2 per row-plane)
+  static_assert((P * BN * 2) % 256 == 0, "W slab must divide over the block");
+  static_assert(!F16 || P == 1, "fp16 operands: single plane only");
   static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -112,9 +127,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int v = tid + 256 * q;
     const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);
     w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * 3*N*16
-    w_dst[q] = 3 * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
+    w_dst[q] = P * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
   }
-  const long long w_slab = 3ll * N * 16;
+  const long long w_slab = (long long)P * N * 16;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -161,56 +176,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         t.z = fmaxf(t.z + abv.z, 0.f);
         t.w = fmaxf(t.w + abv.w, 0.f);
       }
-      uint2 p0, p1, p2;
-      split4(t, p0, p1, p2);
+      uint2 pl[P];
+      split4<P, F16>(t, pl);
       const int d = ((tid >> 2) + 64 * q) * RST + a_seg * 8;
-      *reinterpret_cast<uint2*>(buf + d) = p0;
-      *reinterpret_cast<uint2*>(buf + A_PLANE + d) = p1;
-      *reinterpret_cast<uint2*>(buf + 2 * A_PLANE + d) = p2;
+#pragma unroll
+      for (int t2 = 0; t2 < P; ++t2) *reinterpret_cast<uint2*>(buf + t2 * A_PLANE + d) = pl[t2];
     }
 #pragma unroll
     for (int q = 0; q < WV; ++q) *reinterpret_cast<u32x4*>(buf + w_dst[q]) = wv[q];
   };
   const int a_rd = (wm * TM * 32 + lr) * RST + kh * 16;
-  const int w_rd = 3 * A_PLANE + (wn * TN * 32 + lr) * RST + kh * 16;
+  const int w_rd = P * A_PLANE + (wn * TN * 32 + lr) * RST + kh * 16;
   constexpr int TH = TM / 2;  // row tiles per MFMA half-phase
   // fragment reads: A row tiles [i0, i0 + TH) of a buffer, and all W column tiles
-  auto fread_a = [&](const unsigned char* buf, u32x4 (&fa)[3][TH], int i0) {
+  auto fread_a = [&](const unsigned char* buf, u32x4 (&fa)[P][TH], int i0) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int i = 0; i < TH; ++i)
         fa[p][i] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + a_rd + (i0 + i) * 32 * RST);
   };
-  auto fread_w = [&](const unsigned char* buf, u32x4 (&fb)[3][TN]) {
+  auto fread_w = [&](const unsigned char* buf, u32x4 (&fb)[P][TN]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         fb[p][j] = *reinterpret_cast<const u32x4*>(buf + p * W_PLANE + w_rd + j * 32 * RST);
   };
-  auto mma = [&](const u32x4 (&fa)[3][TH], const u32x4 (&fb)[3][TN], int i0) {
+  // products kept: all (pa, pb) with pa + pb < P  (P = 3: six, error <= 2^-23; P = 2: three,
+  // ~2^-16; P = 1: plain bf16), smallest terms first
+  auto mma = [&](const u32x4 (&fa)[P][TH], const u32x4 (&fb)[P][TN], int i0) {
 #pragma unroll
     for (int i = 0; i < TH; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[0][i]), a1 = __builtin_bit_cast(bf16x8, fa[1][i]),
-                     a2 = __builtin_bit_cast(bf16x8, fa[2][i]);
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[0][j]), b1 = __builtin_bit_cast(bf16x8, fb[1][j]),
-                     b2 = __builtin_bit_cast(bf16x8, fb[2][j]);
         f32x16 c = acc[i0 + i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+#pragma unroll
+        for (int o = P - 1; o >= 0; --o)       // order o = pa + pb
+#pragma unroll
+          for (int pa = 0; pa <= o; ++pa)
+            c = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                          __builtin_bit_cast(f16x8, fa[pa][i]),
+                          __builtin_bit_cast(f16x8, fb[o - pa][j]), c, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                          __builtin_bit_cast(bf16x8, fa[pa][i]),
+                          __builtin_bit_cast(bf16x8, fb[o - pa][j]), c, 0, 0, 0);
         acc[i0 + i][j] = c;
       }
   };
 
   // fragment registers: the two A halves of the current slab, the current and the next W set
-  u32x4 faL[3][TH], faH[3][TH], fbA[3][TN], fbB[3][TN];
+  u32x4 faL[P][TH], faH[P][TH], fbA[P][TN], fbB[P][TN];
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + BUF;
   // prologue: pairs 0 and 1 in registers, slab 0 staged, its first fragments read
@@ -238,10 +254,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // 4 slabs per trip (K % 64 == 0): pair P = 2t in set 0, pair P+1 in set 1.  A set is
   // reloaded with the pair two ahead right after its second slab has been staged.
   for (int s = 0; s < nslabs; s += 4) {
-    const int P = s >> 1;
-    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rw0[1], rb0[1]), gload(P + 2, ra0, rw0, rb0))
+    const int pr = s >> 1;
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rw0[1], rb0[1]), gload(pr + 2, ra0, rw0, rb0))
     PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra1[0], rw1[0], rb1[0]), (void)0)
-    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rw1[1], rb1[1]), gload(P + 3, ra1, rw1, rb1))
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rw1[1], rb1[1]), gload(pr + 3, ra1, rw1, rb1))
     PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra0[0], rw0[0], rb0[0]), (void)0)
   }
 #undef PAVE_SLAB
@@ -308,40 +324,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-// fp32 [n] -> three bf16 planes [3][n] (exact truncation split)
+// P = 3 needs the whole register file of a SIMD (one wave each); with fewer planes two workgroups
+// fit a CU, which the bandwidth-bound P = 1 form wants.
+template <int TM, int TN, bool ABIAS, int P, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias) {
+  gemm_split_body<TM, TN, ABIAS, P, F16>(A, Wp, bias, residual, out, M, K, N, relu, a_bias);
+}
+template <int TM, int TN, bool ABIAS, int P, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias) {
+  gemm_split_body<TM, TN, ABIAS, P, F16>(A, Wp, bias, residual, out, M, K, N, relu, a_bias);
+}
+
+// fp32 [n] -> nplanes bf16 planes [nplanes][n]: truncation terms, the last one rounded to
+// nearest even (nplanes = 3: x = p0 + p1 + p2 exactly)
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x,
                                                            uint16_t* __restrict__ planes,
-                                                           const long long n) {
+                                                           const long long n, const int nplanes,
+                                                           const int f16) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
        i += (long long)gridDim.x * 256) {
-    const float v = x[i];
-    const unsigned h0 = hi16(v);
-    const float r1 = v - __uint_as_float(h0);
-    const unsigned h1 = hi16(r1);
-    const float r2 = r1 - __uint_as_float(h1);
-    planes[i] = (uint16_t)(h0 >> 16);
-    planes[n + i] = (uint16_t)(h1 >> 16);
-    planes[2 * n + i] = (uint16_t)(__float_as_uint(r2) >> 16);
+    float v = x[i];
+    for (int t = 0; t < nplanes - 1; ++t) {
+      const unsigned h = hi16(v);
+      planes[t * n + i] = (uint16_t)(h >> 16);
+      v -= __uint_as_float(h);
+    }
+    planes[(nplanes - 1) * n + i] =
+        (uint16_t)((f16 ? pack_rne<true>(v, 0.f) : pack_rne<false>(v, 0.f)) & 0xffffu);
   }
 }
 
-template <int TM, int TN, bool ABIAS>
+template <int TM, int TN, bool ABIAS, int P, bool F16>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,
                 hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-  constexpr int SMEM = 2 * 3 * (BM + BN) * RST;
+  constexpr int SMEM = (2 * P * (BM + BN) * RST > 4 * 32 * (TN * 32 + 4) * 4)
+                           ? 2 * P * (BM + BN) * RST : 4 * 32 * (TN * 32 + 4) * 4;
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
+  auto* kern = (P == 1) ? gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16>
+                        : gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<TM, TN, ABIAS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_bf16x3: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<TM, TN, ABIAS>), dim3((unsigned)gx), dim3(256), SMEM, st, a, w,
-                     bias, residual, out, (int)M, K, N, relu, a_bias);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), SMEM, st, a, w, bias, residual, out,
+                     (int)M, K, N, relu, a_bias);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -351,11 +389,15 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
 
 extern "C" {
 
-int pave_split_bf16x3_f32(const float* x, void* planes, long long n, void* stream) {
-  if (!x || !planes || n <= 0) return pave_internal_fail(PAVE_E_ARG, "split_bf16x3: bad argument");
+int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes, void* stream) {
+  const int f16 = nplanes == PAVE_PLANES_FP16;
+  if (f16) nplanes = 1;
+  if (!x || !planes || n <= 0 || nplanes < 1 || nplanes > 3)
+    return pave_internal_fail(PAVE_E_ARG, "split_bf16x3: bad argument (1 <= nplanes <= 3)");
   const long long nb = (n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536;
   hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)nb), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint16_t*>(planes), n);
+                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint16_t*>(planes), n,
+                     nplanes, f16);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -363,16 +405,30 @@ int pave_split_bf16x3_f32(const float* x, void* planes, long long n, void* strea
 
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
                          const float* bias, const float* residual, float* out, long long M, int K,
-                         int N, int relu, void* stream) {
+                         int N, int relu, int nplanes, void* stream) {
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
   if (K % 64 != 0 || N % 128 != 0)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 required");
+  if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
-  if (a_bias) return launch_gemm<4, 2, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
-  return launch_gemm<4, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+#define PAVE_GO(AB, P) return launch_gemm<4, 2, AB, P, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st)
+  if (nplanes == PAVE_PLANES_FP16) {
+    if (a_bias) return launch_gemm<4, 2, true, 1, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+    return launch_gemm<4, 2, false, 1, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+  }
+  if (a_bias) {
+    if (nplanes == 3) PAVE_GO(true, 3);
+    if (nplanes == 2) PAVE_GO(true, 2);
+    PAVE_GO(true, 1);
+  }
+  if (nplanes == 3) PAVE_GO(false, 3);
+  if (nplanes == 2) PAVE_GO(false, 2);
+  PAVE_GO(false, 1);
+#undef PAVE_GO
 }
 
 }  // extern "C"

@@ -30,8 +30,8 @@ SIGNATURES = {
     'pave_conv3x3_nhwc_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_rows_gemm_bias_res_act_f32': [_vp] * 7 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
     'pave_bias_relu_maxpool_nhwc_f32': [_vp] * 3 + [_c_int] * 4 + [_vp],
-    'pave_gemm_bf16x3_f32': [_vp] * 6 + [ctypes.c_longlong] + [_c_int] * 3 + [_vp],
-    'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _vp],
+    'pave_gemm_bf16x3_f32': [_vp] * 6 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
+    'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
 # every symbol include/pave_hip.h declares

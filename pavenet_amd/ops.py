@@ -445,38 +445,49 @@ def bias_relu_maxpool_nhwc(x, bias):
     return y.permute(0, 3, 1, 2)
 
 
-def split_bf16x3(x):
-    """fp32 tensor -> int16 tensor [3, *x.shape]: three bf16 planes with x == p0 + p1 + p2 exactly
-    (truncation split)."""
+PLANES_FP16 = 16   # include/pave_hip.h PAVE_PLANES_FP16: one plane of fp16 operands
+
+
+def split_bf16x3(x, planes=3):
+    """fp32 tensor -> int16 tensor [planes, *x.shape] of bf16 bit patterns: truncation terms, the
+    last rounded to nearest (planes = 3: x == p0 + p1 + p2 exactly).  planes = PLANES_FP16: one
+    plane of fp16 bit patterns."""
     lib = native.load()
     _dev(x, 'x', torch.float32)
-    planes = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=x.device)
+    _require(planes in (1, 2, 3, PLANES_FP16), 'split_bf16x3: planes must be 1, 2, 3 or PLANES_FP16')
+    n_out = 1 if planes == PLANES_FP16 else planes
+    out = torch.empty((n_out,) + tuple(x.shape), dtype=torch.int16, device=x.device)
     with torch.cuda.device(x.device):
-        st = lib.pave_split_bf16x3_f32(x.data_ptr(), planes.data_ptr(), x.numel(), _stream_ptr())
+        st = lib.pave_split_bf16x3_f32(x.data_ptr(), out.data_ptr(), x.numel(), planes,
+                                       _stream_ptr())
     native.check(st, 'split_bf16x3')
-    return planes
+    return out
 
 
-def split_weight_bf16x3(weight):
-    """nn.Linear weight [N, K] -> the W operand of `gemm_bf16x3`: int16 [K/16, 3, N, 16], i.e.
-    the three bf16 planes cut into 16-wide K slabs, slab-major, so that one slab of a column
-    tile is contiguous in memory (every 128-byte line is fetched once)."""
+def split_weight_bf16x3(weight, planes=3):
+    """nn.Linear weight [N, K] -> the W operand of `gemm_bf16x3`: int16 [K/16, planes, N, 16],
+    i.e. the bf16 planes cut into 16-wide K slabs, slab-major, so that one slab of a column tile
+    is contiguous in memory (every 128-byte line is fetched once)."""
     _require(weight.dim() == 2 and weight.shape[1] % 64 == 0 and weight.shape[0] % 128 == 0,
              'split_weight_bf16x3: weight [N % 128 == 0, K % 64 == 0]')
     N, K = weight.shape
-    planes = split_bf16x3(weight.contiguous())
-    return planes.view(3, N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
+    pl = split_bf16x3(weight.contiguous(), planes)
+    return pl.view(pl.shape[0], N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
 
 
-def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None):
+def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None,
+                fp16=False):
     """out[M, N] = act(A' @ W^T + bias + residual), A' = relu(a + a_bias) if a_bias is given, on
-    the bf16 matrix cores with both operands split exactly into 3 bf16 terms (6 MFMA products,
-    fp32 accumulate: fp32-level accuracy at up to 2.7x the fp32 MFMA rate).
+    the bf16 matrix cores with both operands split into P = w_planes.shape[1] bf16 terms
+    (P = 3: exact split, 6 MFMA products, fp32-level accuracy;  2: 3 products, ~2^-16;
+    1: plain bf16 operands, or fp16 operands with fp16=True and a PLANES_FP16 weight), fp32
+    accumulate, fp32 in / out.
     w_planes = split_weight_bf16x3(weight [N, K]).  `residual` may be the tensor given as `out`."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
     _dev(w_planes, 'w_planes', torch.int16)
-    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3
+    _require(not fp16 or w_planes.shape[1] == 1, 'gemm_bf16x3: fp16 takes a single plane')
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
              and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
              'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
@@ -497,6 +508,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
+                                      PLANES_FP16 if fp16 else int(w_planes.shape[1]),
                                       _stream_ptr())
     native.check(st, 'gemm_bf16x3')
     return out

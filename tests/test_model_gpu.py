@@ -459,3 +459,28 @@ def test_split_gemm_mode_matches_native():
                                rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(res2['kpts'].cpu().numpy(), res['kpts'].cpu().numpy(),
                                rtol=1e-4, atol=1e-2)
+
+
+def test_fp16_projection_mode_within_half_pixel():
+    """BASELINE config 5's reduced-precision projections (`set_gemm_mode('fp16')`: fp16 operands,
+    fp32 accumulate, sampling / softmax / LayerNorm in fp32): keypoints within 0.5 px of the fp32
+    path (SURVEY 8c tolerance for fp16 projections), selections pinned."""
+    from pavenet_amd import bricks
+    m = _build(3, 12)
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    img = _t(seeded_array('fp16.img', (1, 3, 3, 128, 160))).cuda()
+    old_rows = bricks._GEMM['min_rows']
+    try:
+        with torch.no_grad():
+            res = m.forward_device(img, metas)
+            prop = m.bbox_head.transformer.last_topk_proposals
+            bricks.set_gemm_mode('fp16')
+            bricks._GEMM['min_rows'] = 1
+            res2 = m.forward_device(img, metas, force_topk_proposals=prop,
+                                    force_score_topk=res['score_index'])
+    finally:
+        bricks.set_gemm_mode('native')
+        bricks._GEMM['min_rows'] = old_rows
+    d = (res2['kpts'][..., :2] - res['kpts'][..., :2]).abs().max().item()
+    assert 0 < d < 0.5, d

@@ -406,3 +406,27 @@ def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
     exp = torch.relu(a + ab).double() @ w.double().t() + b.double() + r.double()
     assert out.data_ptr() == idt.data_ptr()
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('planes,rel', [(1, 6e-3), (2, 4e-5), (16, 8e-4)])
+def test_gemm_bf16_split_reduced_planes(planes, rel):
+    """1 plane = plain bf16 operands (round to nearest), 2 planes ~ 16 significand bits: the error
+    against fp64 sits at the expected level for each (and the 3-plane form is 100x below)."""
+    from pavenet_amd.ops import gemm_bf16x3, split_bf16x3, split_weight_bf16x3
+    g = torch.Generator().manual_seed(planes)
+    M, K, N = 777, 512, 256
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    exact = a.double() @ w.double().t() + b.double()
+    got = gemm_bf16x3(a.cuda(), split_weight_bf16x3(w.cuda(), planes), b.cuda(),
+                      fp16=planes == 16).cpu().double()
+    err = (got - exact).abs().max().item() / exact.abs().max().item()
+    assert err < rel, err
+    assert err > rel / 300, 'suspiciously exact: is the plane count honoured?'
+    if planes == 1:     # the single plane is the round-to-nearest bf16 of the value
+        p = split_bf16x3(w.cuda(), 1).cpu()[0]
+        assert torch.equal(p.view(torch.bfloat16), w.to(torch.bfloat16))
+    if planes == 16:    # PLANES_FP16: the round-to-nearest fp16 of the value
+        p = split_bf16x3(w.cuda(), 16).cpu()[0]
+        assert torch.equal(p.view(torch.float16), w.to(torch.float16))
