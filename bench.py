@@ -47,6 +47,8 @@ def parse():
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
     ap.add_argument('--cpu-baseline-frames', type=int, default=None)
+    ap.add_argument('--backbone', choices=('r50', 'hrnet_w48'), default='r50',
+                    help="'hrnet_w48' = BASELINE configs[3] (HRNet-w48 backbone under the MulFrames head)")
     ap.add_argument('--gemm', choices=('native', 'bf16x3', 'bf16x2', 'bf16', 'fp16'), default='native',
                     help="dense projections: 'native' = hipBLASLt fp32 MFMA (the headline), "
                          "'bf16x3' = hand-written exact-split GEMM on the bf16 MFMA (fp32-level "
@@ -102,7 +104,11 @@ def main():
     from pavenet_amd.weights import init_random_weights
 
     T, B = args.frames, args.clips
-    model = build_model(videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img))
+    mcfg = videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img)
+    if args.backbone == 'hrnet_w48':
+        from pavenet_amd.models import with_hrnet_w48
+        mcfg = with_hrnet_w48(mcfg)
+    model = build_model(mcfg)
     init_random_weights(model, seed=0)
     model = model.to(dev).eval()
     from pavenet_amd.bricks import set_gemm_mode
@@ -170,7 +176,7 @@ def main():
                     unit='clips/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                    config=dict(workload=f'PAVE-Net R-50 T={T} frames, batch={B} clips/GPU, '
+                    config=dict(workload=f'PAVE-Net {"R-50" if args.backbone == "r50" else "HRNet-w48"} T={T} frames, batch={B} clips/GPU, '
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
                                 parallelism=f'clip-parallel x{world}', gemm=args.gemm,

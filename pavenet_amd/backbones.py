@@ -297,8 +297,76 @@ class ResNet(BaseModule):
 # HRNet (a14): third_party/mmdetection/mmdet/models/backbones/hrnet.py, incl. the fork's
 # `return y_list[1:]` (:583).  Same ctor kwargs (`extra`) and state-dict keys.
 # ---------------------------------------------------------------------------
+class _Folded:
+    """Device inference path shared by the HRNet pieces: eval BatchNorm folded into its
+    convolution (cached until a parameter changes), channels-last maps, MIOpen convolution
+    without bias + ONE hand-written pass for bias / residual / ReLU (pave_bias_act_rows_f32)."""
+    cache = {}
+
+    @classmethod
+    def weights(cls, conv, bn):
+        key = tuple((t.data_ptr(), t._version) for t in
+                    (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        hit = cls.cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w, b = _fold(conv, bn)
+                hit = (key, w.contiguous(memory_format=torch.channels_last), b.contiguous())
+            cls.cache[id(conv)] = hit
+        return hit[1], hit[2]
+
+    @classmethod
+    def conv_bn(cls, x, conv, bn, relu=False, residual=None):
+        """act(bn(conv(x)) + residual); x, residual channels_last; the result is a fresh tensor."""
+        from . import ops
+        w, b = cls.weights(conv, bn)
+        y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return ops.bias_act_rows_(y, b, residual, relu=relu)
+
+    @staticmethod
+    def ok(x):
+        return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+    @classmethod
+    def seq(cls, mods, x):
+        """nn.Sequential of [Conv2d, BN, (ReLU)] (+ Upsample) groups (transitions, fuse layers)."""
+        mods = list(mods)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Sequential):
+                x = cls.seq(m, x)
+                i += 1
+            elif isinstance(m, nn.Conv2d):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = cls.conv_bn(x, m, mods[i + 1], relu=relu)
+                i += 3 if relu else 2
+            elif isinstance(m, nn.Upsample):
+                x = F.interpolate(x, scale_factor=m.scale_factor, mode=m.mode)
+                x = x.contiguous(memory_format=torch.channels_last)
+                i += 1
+            else:
+                raise TypeError(f'unexpected module in a folded sequence: {type(m).__name__}')
+        return x
+
+
 class _Block(nn.Module):
     """Runs a BasicBlock / Bottleneck parameter container (module forward, eval BN)."""
+
+    @staticmethod
+    def run_folded(blk, x):
+        identity = x
+        if blk.downsample is not None:
+            identity = _Folded.conv_bn(x, blk.downsample[0], blk.downsample[1])
+        y = x
+        n = len(blk.pairs)
+        for k, (cn, bn, act) in enumerate(blk.pairs):
+            last = k + 1 == n   # the last conv: + identity, then the block's final ReLU
+            y = _Folded.conv_bn(y, getattr(blk, cn), getattr(blk, bn), relu=act or last,
+                                residual=identity if last else None)
+        return y
 
     @staticmethod
     def run(blk, x):
@@ -316,8 +384,9 @@ class _Block(nn.Module):
 class _BlockSeq(nn.Sequential):
 
     def forward(self, x):
+        fast = _Folded.ok(x) and not self.training
         for blk in self:
-            x = _Block.run(blk, x)
+            x = _Block.run_folded(blk, x) if fast else _Block.run(blk, x)
         return x
 
 
@@ -383,6 +452,19 @@ class HRModule(nn.Module):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        if _Folded.ok(x[0]) and not self.training:
+            from . import ops
+            x_fuse = []
+            for i in range(len(self.fuse_layers)):
+                acc = None      # sum of the (fresh) cross-resolution terms
+                for j in range(self.num_branches):
+                    if j == i:
+                        continue
+                    t = _Folded.seq(self.fuse_layers[i][j], x[j])
+                    acc = t if acc is None else acc.add_(t)
+                # + the branch's own map, ReLU: one pass
+                x_fuse.append(ops.bias_act_rows_(acc, None, x[i], relu=True))
+            return x_fuse
         x_fuse = []
         for i in range(len(self.fuse_layers)):
             y = 0
@@ -486,8 +568,14 @@ class HRNet(BaseModule):
         if x.dim() == 5:  # [B, T, C, H, W]: the reference HRNet has no frame flatten
             x = x.flatten(0, 1)
         assert not self.training
-        x = F.relu(self.bn1(self.conv1(x)))
-        x = F.relu(self.bn2(self.conv2(x)))
+        fast = _Folded.ok(x)
+        if fast:
+            x = x.contiguous(memory_format=torch.channels_last)
+            x = _Folded.conv_bn(x, self.conv1, self.bn1, relu=True)
+            x = _Folded.conv_bn(x, self.conv2, self.bn2, relu=True)
+        else:
+            x = F.relu(self.bn1(self.conv1(x)))
+            x = F.relu(self.bn2(self.conv2(x)))
         x = self.layer1(x)
         y_list = [x]
         for s in (2, 3, 4):
@@ -495,7 +583,9 @@ class HRNet(BaseModule):
             tr = getattr(self, f'transition{s - 1}')
             x_list = []
             for i in range(cfg['num_branches']):
-                if tr[i] is not None:
+                if tr[i] is not None and fast:
+                    x_list.append(_Folded.seq(tr[i], y_list[-1] if s > 2 else x))
+                elif tr[i] is not None:
                     x_list.append(tr[i](y_list[-1] if s > 2 else x))
                 else:
                     x_list.append(y_list[i] if s > 2 else x)

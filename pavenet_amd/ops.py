@@ -272,8 +272,10 @@ def bias_act_rows_(x, bias=None, res=None, relu=True):
     `x` must be dense with channels innermost (token matrix, or an NHWC / channels_last map)."""
     lib = native.load()
     _require(x.is_cuda and x.dtype == torch.float32, 'bias_act_rows_: fp32 device tensor')
-    C = bias.numel() if bias is not None else x.shape[-1]
-    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+    nhwc = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) \
+        and not x.is_contiguous()
+    C = bias.numel() if bias is not None else (x.shape[1] if nhwc else x.shape[-1])
+    if nhwc:
         _require(x.shape[1] == C, 'bias_act_rows_: channel mismatch')
         if res is not None:
             _require(res.shape == x.shape and res.is_contiguous(memory_format=torch.channels_last),
