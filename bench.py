@@ -47,6 +47,10 @@ def parse():
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
     ap.add_argument('--cpu-baseline-frames', type=int, default=None)
+    ap.add_argument('--gemm-select', choices=('tuned', 'default', 'tune'), default='tuned',
+                    help="vendor GEMM kernel per shape: 'tuned' = the shipped TunableOp selections "
+                         "(pavenet_amd/data/tunableop_gfx950.csv, no tuning at run time), 'default' = "
+                         "library heuristic, 'tune' = measure now and write gpurun_out/tunableop_gfx950.csv")
     ap.add_argument('--backbone', choices=('r50', 'hrnet_w48'), default='r50',
                     help="'hrnet_w48' = BASELINE configs[3] (HRNet-w48 backbone under the MulFrames head)")
     ap.add_argument('--gemm', choices=('native', 'bf16x3', 'bf16x2', 'bf16', 'fp16'), default='native',
@@ -113,6 +117,13 @@ def main():
     model = model.to(dev).eval()
     from pavenet_amd.bricks import set_gemm_mode
     set_gemm_mode(args.gemm)
+    if args.gemm_select != 'default':
+        from pavenet_amd import tuning
+        if args.gemm_select == 'tune':
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            tuning.use_tuned_gemms(os.path.join(ROOT, 'gpurun_out', 'tunableop_gfx950.csv'), tune=True)
+        else:
+            tuning.use_tuned_gemms()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
     metas = [dict(batch_input_shape=(args.height, args.width),
@@ -180,6 +191,7 @@ def main():
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
                                 parallelism=f'clip-parallel x{world}', gemm=args.gemm,
+                                gemm_select=args.gemm_select,
                                 detections_last_step=int(last[..., -N:].sum().item())),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
