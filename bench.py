@@ -186,7 +186,11 @@ def main():
         line = dict(metric='clips/sec (T=7, 800x1344) fwd', value=round(clips / dt, 4),
                     unit='clips/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
-                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    scaling='weak', vs_baseline=None,
+                    dtype={'native': 'f32', 'bf16x3': 'f32 (exact 3-term bf16 split on the bf16 MFMA)',
+                           'bf16x2': 'bf16x2 operands, f32 accumulate', 'bf16': 'bf16 operands, f32 '
+                           'accumulate', 'fp16': 'f16 operands, f32 accumulate'}[args.gemm],
+                    data='synthetic',
                     config=dict(workload=f'PAVE-Net {"R-50" if args.backbone == "r50" else "HRNet-w48"} T={T} frames, batch={B} clips/GPU, '
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
@@ -194,6 +198,15 @@ def main():
                                 gemm_select=args.gemm_select,
                                 detections_last_step=int(last[..., -N:].sum().item())),
                     roofline=roofline)
+        if args.backbone == 'r50' and (args.height, args.width) == (800, 1344):
+            # SURVEY 8d dense (MFMA) work: per frame R-50 176 + neck 9 + encoder 201 GFLOP, per clip
+            # proposals 31 + T x (8.8 + 5.9) decoder value projections
+            flops = B * (T * (176 + 9 + 201) + 31 + T * 14.7) * 1e9
+            tf = flops * world * args.steps / dt / 1e12
+            line['dense_mfma'] = dict(tflop_per_step_per_gpu=round(flops / 1e12, 3),
+                                      achieved=round(tf / world, 1), peak=157.3, unit='TFLOP/s',
+                                      frac=round(tf / world / 157.3, 4),
+                                      note='whole step incl. the non-MFMA kernels; fp32 matrix peak')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(model, args, args.cpu_baseline_frames or T)
         print(json.dumps(line))

@@ -211,3 +211,38 @@ def test_rescale_size_matches_reference_pipeline_shapes():
     assert rescale_size((640, 480), (1333, 800)) == (1067, 800)
     for wh in ((1920, 1080), (640, 480), (333, 500), (1333, 800)):
         assert rescale_size(wh, (1333, 800)) == PR.rescale_size(wh, (1333, 800))
+
+
+def test_tuned_gemm_selection_file_is_well_formed():
+    """pavenet_amd/data/tunableop_gfx950.csv: the five validators PyTorch checks before it accepts
+    the file, then one `op,shape,solution,ms` row per GEMM shape (no duplicates)."""
+    from pavenet_amd import tuning
+    rows = [r.strip().split(',') for r in open(tuning.DEFAULT_FILE) if r.strip()]
+    val = {r[1]: r[2] for r in rows if r[0] == 'Validator'}
+    assert set(val) == {'PT_VERSION', 'HIP_VERSION', 'HIPBLASLT_VERSION', 'GCN_ARCH_NAME',
+                        'ROCBLAS_VERSION'}
+    assert val['GCN_ARCH_NAME'].startswith('gfx950')
+    ent = [r for r in rows if r[0] != 'Validator']
+    assert len(ent) > 30 and all(len(r) == 4 and float(r[3]) > 0 for r in ent)
+    assert len({(r[0], r[1]) for r in ent}) == len(ent)
+    # the bench workload's FFN shapes are covered
+    assert any(r[1].startswith('tn_256_625044_1024') for r in ent)
+
+
+def test_gemm_mode_switch_validates():
+    from pavenet_amd import bricks
+    assert bricks.get_gemm_mode() == 'native'
+    with pytest.raises(AssertionError):
+        bricks.set_gemm_mode('tf32')
+    for mode in ('bf16x3', 'bf16x2', 'bf16', 'fp16', 'native'):
+        bricks.set_gemm_mode(mode)
+        assert bricks.get_gemm_mode() == mode
+    # host tensors never take the device GEMM path
+    x, w = torch.randn(9000, 256), torch.randn(128, 256)
+    bricks.set_gemm_mode('bf16x3')
+    try:
+        assert not bricks.split_gemm_ok(x, w)
+        y = bricks.linear_rows(x, w, None, relu=True)
+        assert torch.equal(y, torch.relu(x @ w.t()))
+    finally:
+        bricks.set_gemm_mode('native')
