@@ -84,6 +84,8 @@ def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
              tuple(value_level_start_index.shape) == (L,),
              'ms_deform_attn_forward: spatial_shapes / level_start_index shape mismatch')
     out = torch.empty((bs, Lq, M * D), dtype=dt, device=value.device)
+    if out.numel() == 0:   # no queries (or empty batch): empty result, as the PyTorch formulation
+        return out         # (MO:92-149) gives; the C entry point rejects non-positive sizes
     fn = (lib.pave_ms_deform_attn_forward_f32 if dt == torch.float32
           else lib.pave_ms_deform_attn_forward_f64)
     with torch.cuda.device(value.device):
@@ -259,6 +261,8 @@ def oks_nms(kpts, scores, sigmas, thresh):
              'oks_nms: scores / sigmas shape mismatch')
     keep = torch.empty((n_clips, N), dtype=torch.int32, device=kpts.device)
     order = torch.empty((n_clips, N), dtype=torch.int32, device=kpts.device)
+    if keep.numel() == 0:  # nothing to suppress (the NumPy loop of HEAD:1624-1665 returns [])
+        return keep, order
     with torch.cuda.device(kpts.device):
         st = lib.pave_oks_nms_f32(kpts.data_ptr(), scores.data_ptr(), sigmas.data_ptr(),
                                   float(thresh), keep.data_ptr(), order.data_ptr(), n_clips, N,

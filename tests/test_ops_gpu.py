@@ -69,6 +69,37 @@ def test_sampler_errors():
     assert ms_deform_attn_forward(v, sd, ld, loc, aw, 3).shape == (3, 5, 256)
 
 
+def test_sampler_edge_cases():
+    """Empty query set, a single query / single point, and locations far outside the maps
+    (zero padding: every corner is out of range -> exact zeros), as the PyTorch formulation."""
+    from pavenet_amd.ops import ms_deform_attn_forward, oks_nms
+    shapes, lsi, sd, ld = _levels(LEVELS)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(2, S, 8, 32, generator=g).cuda()
+    out = ms_deform_attn_forward(v, sd, ld, torch.zeros(2, 0, 8, 4, 4, 2, device='cuda'),
+                                 torch.zeros(2, 0, 8, 4, 4, device='cuda'), 64)
+    assert out.shape == (2, 0, 256)
+    loc = torch.rand(2, 1, 8, 4, 1, 2, generator=g)
+    aw = torch.rand(2, 1, 8, 4, 1, generator=g)
+    got = ms_deform_attn_forward(v, sd, ld, loc.cuda(), aw.cuda(), 64)
+    exp = R.msda_forward_torch(v.cpu(), shapes, loc, aw)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    far = torch.full((2, 7, 8, 4, 4, 2), 7.5)
+    far[..., 1] = -3.25
+    z = ms_deform_attn_forward(v, sd, ld, far.cuda(), torch.ones(2, 7, 8, 4, 4, device='cuda'), 64)
+    assert torch.count_nonzero(z) == 0
+    # exactly on the border: pixel = loc * W - 0.5 in (-1, 0) keeps one row / column of corners
+    edge = torch.zeros(2, 3, 8, 4, 4, 2)
+    w1 = torch.rand(2, 3, 8, 4, 4, generator=g)
+    got = ms_deform_attn_forward(v, sd, ld, edge.cuda(), w1.cuda(), 64)
+    exp = R.msda_forward_torch(v.cpu(), shapes, edge, w1)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    keep, order = oks_nms(torch.zeros(2, 0, 15, 3, device='cuda'), torch.zeros(2, 0, device='cuda'),
+                          _t(R.OKS_SIGMAS_15).cuda(), 0.45)
+    assert keep.shape == (2, 0) and order.shape == (2, 0)
+
+
 @pytest.mark.parametrize('T,U,clips', [(1, 321, 1), (1, 643, 2), (2, 75, 2), (3, 75, 2), (4, 33, 1),
                                        (5, 45, 1), (7, 30, 2)])
 def test_grid_fused_vs_oracle(T, U, clips):
