@@ -239,6 +239,18 @@ int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_plan
                          const float* bias, const float* residual, float* out, long long M, int K,
                          int N, int relu, int nplanes, void* stream);
 
+/*
+ * 3x3 / pad 1 / stride 1|2 convolution, NHWC fp32 in and out, as an implicit GEMM through the same
+ * split-operand kernel (K axis = (ky, kx, cin)), bias (+ReLU) in the epilogue:
+ *   x [N, H, W, Cin];  w_planes = the weight [Cout, 3, 3, Cin] (i.e. [Cout, 9*Cin] rows) split and
+ *   re-laid like pave_gemm_bf16x3_f32's operand;  y [N, Ho, Wo, Cout], Ho = (H - 1)/stride + 1.
+ * Replaces a ResNet / HRNet 3x3 nn.Conv2d + folded BatchNorm (+ReLU) in the split / 16-bit GEMM
+ * modes.  Cin %% 64 == 0, Cout %% 64 == 0.
+ */
+int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                           int N, int H, int W, int Cin, int Cout, int stride, int relu,
+                           int nplanes, void* stream);
+
 /* x[n] fp32 -> planes[nplanes][n] bf16: truncation terms, the last rounded to nearest even
  * (nplanes = 3: x = p0 + p1 + p2 exactly). */
 int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes, void* stream);

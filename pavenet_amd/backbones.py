@@ -195,7 +195,7 @@ class ResNet(BaseModule):
         where that wins (K <= fused_tail_max_k); above it hipBLASLt GEMMs with the residual in
         the epilogue plus one fused bias+ReLU pass each (pave_bias_act_rows_f32)."""
         from . import ops
-        from .bricks import linear_rows, split_gemm_ok
+        from .bricks import linear_rows, split_conv_weight, split_gemm_ok
         rows, nhw = self._as_rows(x)
         w1, b1 = f[(name, bi, 'conv1')]
         y = linear_rows(rows, w1.flatten(1), b1, relu=True)               # conv1 + bn1 + relu
@@ -208,7 +208,16 @@ class ResNet(BaseModule):
         if split3:
             w3_kn = None  # the split GEMM takes the tail (same prologue / epilogue) for K >= 256
         taps = f.get((name, bi, 'conv2_taps')) if self.deterministic_conv3x3 else None
-        if taps is not None and c2.dilation[0] == 1 and c2.padding[0] == 1:
+        wsplit = None
+        if c2.dilation[0] == 1 and c2.padding[0] == 1 and c2.stride[0] == c2.stride[1] \
+                and not torch.is_grad_enabled():
+            wsplit = split_conv_weight(w2)     # split / 16-bit GEMM modes: same kernel family
+        if wsplit is not None:
+            from .bricks import get_gemm_mode
+            y = ops.conv3x3_split(y, wsplit, b2, stride=c2.stride[0], relu=True,
+                                  fp16=get_gemm_mode() == 'fp16')
+            b2 = None
+        elif taps is not None and c2.dilation[0] == 1 and c2.padding[0] == 1:
             y = ops.conv3x3_nhwc(y, taps, b2, stride=c2.stride[0], relu=True)  # MFMA, bn2+relu fused
             b2 = None
         else:

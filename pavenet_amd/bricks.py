@@ -149,6 +149,24 @@ def _split_weight(weight):
     return hit[1]
 
 
+def split_conv_weight(weight):
+    """Folded 3x3 conv weight [Cout, Cin, 3, 3] -> cached operand of ops.conv3x3_split for the
+    current GEMM mode, or None when the mode / shape does not take the split kernel."""
+    if _GEMM['mode'] not in _PLANES or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) \
+            or weight.shape[0] % 64 or weight.shape[1] % 64 or not weight.is_cuda \
+            or weight.dtype != torch.float32:
+        return None
+    from . import ops
+    planes = _PLANES[_GEMM['mode']]
+    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), planes, 'conv')
+    hit = _SPLIT_CACHE.get(slot)
+    if hit is None or hit[0] != weight._version:
+        with torch.no_grad():
+            hit = (weight._version, ops.split_conv3x3_weight(weight.detach(), planes))
+        _SPLIT_CACHE[slot] = hit
+    return hit[1]
+
+
 def split_gemm_ok(x2, weight):
     """Shapes / dtypes the split GEMM takes (and where it beats the library)."""
     return (_GEMM['mode'] in _PLANES and x2.is_cuda and x2.dtype == torch.float32

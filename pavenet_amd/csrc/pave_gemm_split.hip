@@ -75,22 +75,29 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&p)[P]) {
   p[P - 1] = make_uint2(pack_rne<F16>(x[0], x[1]), pack_rne<F16>(x[2], x[3]));
 }
 
+// 3x3 / pad 1 convolution as an implicit GEMM: row m = output pixel (n, oy, ox), K axis =
+// (tap, cin) with a 16-wide slab inside one tap; H == 0 means a plain row GEMM.
+struct ConvGeom {
+  int H, W, Cin, Ho, Wo, stride;
+};
+
 // Software pipeline (one wave per SIMD, so nothing else hides latency):
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
 //   slab s's MFMAs, into a second fragment register set.
-template <int TM, int TN, bool ABIAS, int P, bool F16>
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias) {
+    const float* __restrict__ a_bias, const ConvGeom g) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
   constexpr int BUF = P * (A_PLANE + W_PLANE);                 // one LDS buffer
   constexpr int SMEM = (2 * BUF > 4 * 32 * (TN * 32 + 4) * 4) ? 2 * BUF : 4 * 32 * (TN * 32 + 4) * 4;
   constexpr int APASS = BM / 64;   // float4 loads of A per thread per slab (4 threads per row)
-  constexpr int WV = (P * BN * 2) / 256;  // uint4 loads of W per thread per slab (2 per row-plane)
-  static_assert((P * BN * 2) % 256 == 0, "W slab must divide over the block");
+  constexpr int WN = P * BN * 2;          // uint4 loads of W per slab (2 per row-plane)
+  constexpr int WV = (WN + 255) / 256;    // per thread (the last round may be partial)
+  static_assert(!(CONV && ABIAS), "the convolution form has no A-side bias");
   static_assert(!F16 || P == 1, "fp16 operands: single plane only");
   static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -112,11 +119,22 @@ __device__ __forceinline__ void gemm_split_body(
   // A: thread -> (row = tid>>2 + 64*q, 16-byte segment seg = tid&3 of the row's 64-byte slab)
   const int a_seg = tid & 3;
   const float* a_ptr[APASS];
+  int iy0[APASS], ix0[APASS];   // CONV: top-left input pixel of the row's 3x3 window
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
     long long r = m0 + (tid >> 2) + 64 * q;
     if (r >= M) r = M - 1;  // clamp: rows past M are computed on stand-in data, never stored
-    a_ptr[q] = A + r * K + a_seg * 4;
+    if (CONV) {
+      const unsigned ur = (unsigned)r, gy = ur / (unsigned)g.Wo;
+      const int ox = (int)(ur - gy * (unsigned)g.Wo);
+      const int n = (int)(gy / (unsigned)g.Ho);
+      const int oy = (int)(gy - (unsigned)n * (unsigned)g.Ho);
+      iy0[q] = oy * g.stride - 1;
+      ix0[q] = ox * g.stride - 1;
+      a_ptr[q] = A + (long long)n * g.H * g.W * g.Cin + a_seg * 4;   // image base
+    } else {
+      a_ptr[q] = A + r * K + a_seg * 4;
+    }
   }
   // W operand, slab-major [K/16][3][N][16] bf16 (host layout: one slab of a column tile is 3
   // contiguous 4-KiB runs): uint4 index v = tid + 256*q -> plane, row, 16-byte half
@@ -124,9 +142,9 @@ __device__ __forceinline__ void gemm_split_body(
   int w_dst[WV];
 #pragma unroll
   for (int q = 0; q < WV; ++q) {
-    const int v = tid + 256 * q;
-    const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);
-    w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * 3*N*16
+    const int v = (tid + 256 * q) < WN ? tid + 256 * q : 0;   // spare threads of a partial round
+    const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);   // repeat item 0
+    w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * P*N*16
     w_dst[q] = P * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
   }
   const long long w_slab = (long long)P * N * 16;
@@ -150,10 +168,26 @@ __device__ __forceinline__ void gemm_split_body(
   auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rw)[2][WV], f32x4 (&rb)[2]) {
     const int pp = pair < npairs ? pair : npairs - 1;  // past the end: repeat (never consumed)
     const int k0 = pp * 2 * BK;
+    if (CONV) {
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // a pair (32 k) lies inside one tap
+      const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-    for (int q = 0; q < APASS; ++q) {
-      ra[0][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0);
-      ra[1][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0 + BK);
+      for (int q = 0; q < APASS; ++q) {
+        const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+        const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        const float* src = a_ptr[q] + (ok ? ((long long)iy * g.W + ix) * g.Cin + c0 : 0);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(src + BK);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[0][q] = ok ? t0 : z;   // zero padding
+        ra[1][q] = ok ? t1 : z;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < APASS; ++q) {
+        ra[0][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0);
+        ra[1][q] = *reinterpret_cast<const f32x4*>(a_ptr[q] + k0 + BK);
+      }
     }
 #pragma unroll
     for (int q = 0; q < WV; ++q) {
@@ -326,19 +360,19 @@ __device__ __forceinline__ void gemm_split_body(
 
 // P = 3 needs the whole register file of a SIMD (one wave each); with fewer planes two workgroups
 // fit a CU, which the bandwidth-bound P = 1 form wants.
-template <int TM, int TN, bool ABIAS, int P, bool F16>
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias) {
-  gemm_split_body<TM, TN, ABIAS, P, F16>(A, Wp, bias, residual, out, M, K, N, relu, a_bias);
+    const float* __restrict__ a_bias, const ConvGeom g) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g);
 }
-template <int TM, int TN, bool ABIAS, int P, bool F16>
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias) {
-  gemm_split_body<TM, TN, ABIAS, P, F16>(A, Wp, bias, residual, out, M, K, N, relu, a_bias);
+    const float* __restrict__ a_bias, const ConvGeom g) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g);
 }
 
 // fp32 [n] -> nplanes bf16 planes [nplanes][n]: truncation terms, the last one rounded to
@@ -360,17 +394,20 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   }
 }
 
-template <int TM, int TN, bool ABIAS, int P, bool F16>
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,
-                hipStream_t st) {
+                hipStream_t st, const ConvGeom g = ConvGeom{0, 0, 0, 0, 0, 0}) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int SMEM = (2 * P * (BM + BN) * RST > 4 * 32 * (TN * 32 + 4) * 4)
                            ? 2 * P * (BM + BN) * RST : 4 * 32 * (TN * 32 + 4) * 4;
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
-  auto* kern = (P == 1) ? gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16>
-                        : gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16>;
+  using kern_t = void (*)(const float*, const uint16_t*, const float*, const float*, float*, int, int,
+                          int, int, const float*, ConvGeom);
+  kern_t kern;
+  if constexpr (P == 1) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV>;
+  else kern = gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -379,7 +416,7 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), SMEM, st, a, w, bias, residual, out,
-                     (int)M, K, N, relu, a_bias);
+                     (int)M, K, N, relu, a_bias, g);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -415,10 +452,10 @@ int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_plan
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
-#define PAVE_GO(AB, P) return launch_gemm<4, 2, AB, P, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st)
+#define PAVE_GO(AB, P) return launch_gemm<4, 2, AB, P, false, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st)
   if (nplanes == PAVE_PLANES_FP16) {
-    if (a_bias) return launch_gemm<4, 2, true, 1, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
-    return launch_gemm<4, 2, false, 1, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+    if (a_bias) return launch_gemm<4, 2, true, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+    return launch_gemm<4, 2, false, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
   }
   if (a_bias) {
     if (nplanes == 3) PAVE_GO(true, 3);
@@ -429,6 +466,39 @@ int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_plan
   if (nplanes == 2) PAVE_GO(false, 2);
   PAVE_GO(false, 1);
 #undef PAVE_GO
+}
+
+int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                           int N, int H, int W, int Cin, int Cout, int stride, int relu,
+                           int nplanes, void* stream) {
+  if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: bad sizes (stride 1 or 2)");
+  if (Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: Cin %% 64 == 0 and Cout %% 64 == 0 required");
+  if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: tensor too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint16_t* w = static_cast<const uint16_t*>(w_planes);
+  const ConvGeom g{H, W, Cin, Ho, Wo, stride};
+  const int K = 9 * Cin;
+#define PAVE_CV(TN_, P_, F_) \
+  return launch_gemm<4, TN_, false, P_, F_, true>(x, w, bias, nullptr, y, M, K, Cout, relu, nullptr, st, g)
+  if (Cout % 128 == 0) {
+    if (nplanes == PAVE_PLANES_FP16) PAVE_CV(2, 1, true);
+    if (nplanes == 3) PAVE_CV(2, 3, false);
+    if (nplanes == 2) PAVE_CV(2, 2, false);
+    PAVE_CV(2, 1, false);
+  }
+  if (nplanes == PAVE_PLANES_FP16) PAVE_CV(1, 1, true);
+  if (nplanes == 3) PAVE_CV(1, 3, false);
+  if (nplanes == 2) PAVE_CV(1, 2, false);
+  PAVE_CV(1, 1, false);
+#undef PAVE_CV
 }
 
 }  // extern "C"

@@ -474,8 +474,8 @@ def split_weight_bf16x3(weight, planes=3):
     """nn.Linear weight [N, K] -> the W operand of `gemm_bf16x3`: int16 [K/16, planes, N, 16],
     i.e. the bf16 planes cut into 16-wide K slabs, slab-major, so that one slab of a column tile
     is contiguous in memory (every 128-byte line is fetched once)."""
-    _require(weight.dim() == 2 and weight.shape[1] % 64 == 0 and weight.shape[0] % 128 == 0,
-             'split_weight_bf16x3: weight [N % 128 == 0, K % 64 == 0]')
+    _require(weight.dim() == 2 and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0,
+             'split_weight_bf16x3: weight [N % 64 == 0, K % 64 == 0]')
     N, K = weight.shape
     pl = split_bf16x3(weight.contiguous(), planes)
     return pl.view(pl.shape[0], N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
@@ -498,6 +498,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
              'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
     N = w_planes.shape[2]
+    _require(N % 128 == 0, 'gemm_bf16x3: N % 128 == 0')
     for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
         if t is not None:
             _dev(t, nm, torch.float32)
@@ -518,3 +519,38 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
                                       _stream_ptr())
     native.check(st, 'gemm_bf16x3')
     return out
+
+
+def split_conv3x3_weight(weight, planes=3):
+    """Conv2d weight [Cout, Cin, 3, 3] -> the operand of `conv3x3_split`: rows [Cout, (ky, kx, cin)]
+    split and re-laid by `split_weight_bf16x3`."""
+    _require(weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3), 'split_conv3x3_weight: [Cout,Cin,3,3]')
+    cout, cin = weight.shape[:2]
+    return split_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous(), planes)
+
+
+def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False):
+    """3x3 / pad 1 convolution of a channels_last map through the split-operand GEMM kernel
+    (implicit GEMM), bias (+ReLU) fused.  x [N, Cin, H, W] channels_last; w_planes =
+    split_conv3x3_weight(weight) -> [N, Cout, Ho, Wo] channels_last."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv3x3_split: fp32 4-D')
+    _require(x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_split: channels_last input')
+    _dev(w_planes, 'w_planes', torch.int16)
+    N, Cin, H, W = x.shape
+    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == 9 * Cin and w_planes.shape[3] == 16,
+             'conv3x3_split: w_planes [9*Cin/16, P, Cout, 16] (split_conv3x3_weight)')
+    _require(not fp16 or w_planes.shape[1] == 1, 'conv3x3_split: fp16 takes a single plane')
+    Cout = w_planes.shape[2]
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == Cout, 'conv3x3_split: bias [Cout]')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _Timed('conv3x3_split'):
+        st = lib.pave_conv3x3_split_f32(
+            x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)),
+            PLANES_FP16 if fp16 else int(w_planes.shape[1]), _stream_ptr())
+    native.check(st, 'conv3x3_split')
+    return y.permute(0, 3, 1, 2)

@@ -462,3 +462,26 @@ def test_gemm_bf16_split_reduced_planes(planes, rel):
     if planes == 16:    # PLANES_FP16: the round-to-nearest fp16 of the value
         p = split_bf16x3(w.cuda(), 16).cpu()[0]
         assert torch.equal(p.view(torch.float16), w.to(torch.float16))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 64, 64, 1), (1, 20, 9, 128, 128, 1),
+                                                   (3, 14, 22, 128, 256, 2), (2, 9, 9, 256, 64, 2),
+                                                   (1, 40, 56, 64, 192, 1)])
+def test_conv3x3_split_vs_torch(N, H, W, Cin, Cout, stride):
+    """The split-operand kernel as an implicit-GEMM 3x3 convolution: 3 planes at fp32 level, one
+    fp16 plane at the 16-bit level, zero padding and stride handled in the operand loader."""
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin**0.5)
+    b = torch.randn(Cout, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    exp = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    out = conv3x3_split(xd, split_conv3x3_weight(w.cuda(), 3), b.cuda(), stride=stride)
+    assert out.shape == exp.shape
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    out = conv3x3_split(xd, split_conv3x3_weight(w.cuda(), 3), b.cuda(), stride=stride, relu=True)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.relu(exp).numpy(), rtol=1e-5, atol=1e-5)
+    out = conv3x3_split(xd, split_conv3x3_weight(w.cuda(), 16), None, stride=stride, fp16=True)
+    np.testing.assert_allclose(out.cpu().numpy(), (exp - b.double()[None, :, None, None]).numpy(),
+                               rtol=5e-3, atol=5e-3)

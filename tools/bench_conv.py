@@ -38,12 +38,17 @@ def main():
         wt = w.permute(2, 3, 1, 0).contiguous()
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         fl = 2.0 * N * Ho * Wo * Cout * Cin * 9
-        t_lib = timeit(lambda: torch.relu_(F.conv2d(x, w, b, s, 1)))
+        t_lib = timeit(lambda: ops.bias_act_rows_(F.conv2d(x, w, None, s, 1), b, None, relu=True))
+        wp3 = ops.split_conv3x3_weight(w, 3)
+        wp16 = ops.split_conv3x3_weight(w, 16)
+        t_s3 = timeit(lambda: ops.conv3x3_split(x, wp3, b, stride=s, relu=True))
+        t_s16 = timeit(lambda: ops.conv3x3_split(x, wp16, b, stride=s, relu=True, fp16=True))
         t_own = timeit(lambda: ops.conv3x3_nhwc(x, wt, b, stride=s, relu=True))
         err = (ops.conv3x3_nhwc(x, wt, b, stride=s, relu=True) -
                torch.relu(F.conv2d(x, w, b, s, 1))).abs().max().item()
-        print(f'{N}x{H}x{W} {Cin}->{Cout} s{s}: MIOpen+relu {t_lib:7.3f} ms ({fl / t_lib / 1e9:6.1f} TF/s)'
-              f'   mfma {t_own:7.3f} ms ({fl / t_own / 1e9:6.1f} TF/s)   max|d| {err:.2e}')
+        print(f'{N}x{H}x{W} {Cin}->{Cout} s{s}: MIOpen+bias/relu pass {t_lib:7.3f} ms ({fl / t_lib / 1e9:6.1f} TF/s)'
+              f'   mfma {t_own:7.3f} ms ({fl / t_own / 1e9:6.1f} TF/s)   max|d| {err:.2e}'
+              f'   split-bf16x3 {t_s3:7.3f} ms ({fl / t_s3 / 1e9:6.1f} TF/s)   fp16 {t_s16:7.3f} ms')
 
 
 if __name__ == '__main__':
