@@ -93,6 +93,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    # PAVE_BENCH_ONE_DEVICE=1 (+ gloo): every rank on GPU 0, to exercise the N > 1 path on a 1-GPU box
+    one_device = os.environ.get('PAVE_BENCH_ONE_DEVICE', '0') == '1'
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # let MIOpen time its solvers per convolution shape once (during warm-up) instead of
     # trusting the immediate-mode heuristic of a cold find-db
@@ -101,7 +105,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = 'gloo' if one_device else 'nccl'   # RCCL refuses two ranks on one device
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
+        host_collectives = backend == 'gloo'
 
     from pavenet_amd import ops
     from pavenet_amd.models import build_model, videopose_r50_cfg
@@ -140,9 +149,14 @@ def main():
         res = graphed(img) if graphed is not None else model.forward_device(img, metas)
         packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1),
                             res['keep'].float()], dim=1)  # [B, N*5 + N*K*3 + N]
+        if dist is not None and host_collectives:
+            packed = packed.cpu()
+            out = torch.empty((world * packed.shape[0], packed.shape[1]))
+            dist.all_gather_into_tensor(out, packed)
+            return out
         if dist is not None:
             out = torch.empty((world * packed.shape[0], packed.shape[1]), device=dev)
-            dist.all_gather_into_tensor(out, packed)
+            dist.all_gather_into_tensor(out, packed)   # RCCL over xGMI
             packed = out
         return packed.cpu()  # results on the host, as simple_test returns them
 
@@ -163,7 +177,7 @@ def main():
     events = ops.KERNEL_EVENTS
     ops.KERNEL_EVENTS = None
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device='cpu' if host_collectives else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     enc = [s.elapsed_time(e) * 1e-3 for tag, s, e in events if tag == 'enc_grid_T1']
