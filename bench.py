@@ -190,7 +190,7 @@ def main():
         tj = os.path.join(ROOT, 'profiles', 'enc_kernel_traffic.json')
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
-        roofline = dict(bound='hbm', kernel='fused_deform_attn_kernel<GRID,T=1> (encoder MSDA)',
+        roofline = dict(bound='hbm', kernel='enc_head_major_kernel (encoder MSDA: fused softmax + sampling, GRID T=1)',
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         launches=len(enc), avg_us=round(avg * 1e6, 1),

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pave_hip.h"
@@ -939,6 +940,153 @@ __global__ __launch_bounds__(512, 4) void enc_window_kernel(const WinParams p) {
   if (valid) *reinterpret_cast<float4*>(p.out + unit * kRowFloats + head * kDim + j * 4) = acc;
 }
 
+// ---------------------------------------------------------------------------
+// Encoder (GRID, T = 1), head-major work split.  The kernel above gives a wave ONE query and all
+// 8 heads: its 64 corner rows per point set lie in 8 different 128-byte head rows per pixel, so
+// the ~32 queries resident on a CU touch ~100 KB of value rows -- three times the 32-KB L1
+// (measured: 59 % L1 hit rate, 10 TB/s of L2 -> L1 traffic).  Here a wave takes 8 QUERIES of one
+// head (lane = (query slot lane>>3, sub lane&7)) and a workgroup 32 neighbouring queries of that
+// head, so the rows a workgroup gathers are one head's rows of a small pixel neighbourhood
+// (~12 KB) and repeat across its queries and points while they are in L1.
+// Logical block = (patch of 32 units, head); same FusedParams / outputs as the kernel above.
+// ---------------------------------------------------------------------------
+// kHmPatches: patches of 32 units a workgroup walks (same head); UNR: gather-loop unroll
+template <int kHmPatches, int UNR>
+__global__ __launch_bounds__(256) void enc_head_major_kernel(const FusedParams p) {
+  constexpr int kSlots = 16;
+  constexpr int kGroupStride = kSlots * 8 + 8;  // floats
+  __shared__ __attribute__((aligned(16))) float lds[4 * 8 * kGroupStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 3, j = lane & 7;
+  const int lb = xcd_remap(blockIdx.x, p.n_blocks_logical);
+  const int head = lb & 7, pgroup = lb >> 3;
+  const int L = p.L, LP = L * 4;  // 4 points per level, LP <= 16
+  const int rowbytes = kRowFloats * 4;
+  float* my_lds = lds + (wave * 8 + g) * kGroupStride;
+
+  int Hs[4], Ws[4], St[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int ll = l < L ? l : 0;
+    Hs[l] = (int)p.shapes[2 * ll];
+    Ws[l] = (int)p.shapes[2 * ll + 1];
+    St[l] = (int)p.lsi[ll];
+  }
+  const int i0 = j * 2;                 // this lane prepares points i0, i0 + 1 (same level)
+  const int lvl = i0 >> 2;
+  const int H = lvl == 0 ? Hs[0] : lvl == 1 ? Hs[1] : lvl == 2 ? Hs[2] : Hs[3];
+  const int W = lvl == 0 ? Ws[0] : lvl == 1 ? Ws[1] : lvl == 2 ? Ws[2] : Ws[3];
+  const int st = lvl == 0 ? St[0] : lvl == 1 ? St[1] : lvl == 2 ? St[2] : St[3];
+  const bool pts_ok = i0 < LP;
+
+  // Two-deep software pipeline over the workgroup's patches: the unit index of patch it + 2
+  // and the projections / reference point of patch it + 1 are loaded while patch it gathers.
+  struct Pre {
+    float2 lg, rf;
+    float4 of;
+  };
+  auto slot_of = [&](int it) { return (pgroup * kHmPatches + it) * 32 + wave * 8 + g; };
+  auto unit_of = [&](int it) {
+    const int s = slot_of(it);
+    return (it < kHmPatches && s < p.n_units) ? (p.order ? p.order[s] : s) : 0;
+  };
+  auto prefetch = [&](int unit) {
+    Pre q;
+    const float* row = p.proj + (long long)unit * p.proj_stride;
+    const int ii = pts_ok ? i0 : 0;
+    q.lg = *reinterpret_cast<const float2*>(row + kHeads * LP * 2 + head * LP + ii);
+    q.of = *reinterpret_cast<const float4*>(row + head * LP * 2 + 2 * ii);
+    q.rf = *reinterpret_cast<const float2*>(p.ref + ((long long)unit * L + (pts_ok ? lvl : 0)) * 2);
+    return q;
+  };
+  int unit = unit_of(0);
+  int unit_n = unit_of(1);
+  Pre cur = prefetch(unit);
+  for (int it = 0; it < kHmPatches; ++it) {
+    const int unit_nn = unit_of(it + 2);
+    const Pre nxt = prefetch(unit_n);
+    const bool active = slot_of(it) < p.n_units;
+    // softmax statistics over the LP logits of (unit, head): 2 per lane
+    const float x0 = pts_ok ? cur.lg.x : -INFINITY, x1 = pts_ok ? cur.lg.y : -INFINITY;
+    const float mx = group8_max(fmaxf(x0, x1));
+    const float e0 = pts_ok ? expf(x0 - mx) : 0.f, e1 = pts_ok ? expf(x1 - mx) : 0.f;
+    const float sm = group8_sum(e0 + e1);
+    const float inv_sum = 1.f / sm;
+    const int clip = p.unit_clip ? p.unit_clip[unit] : unit / p.units_per_clip;
+    const char* frame =
+        reinterpret_cast<const char*>(p.value) + (long long)clip * p.S * rowbytes + j * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Corners c;
+      if (pts_ok) {
+        const float ox = s ? cur.of.z : cur.of.x, oy = s ? cur.of.w : cur.of.y;
+        const float aw = (s ? e1 : e0) * inv_sum;
+        const float lx = cur.rf.x + ox / (float)W, ly = cur.rf.y + oy / (float)H;
+        c = make_corners(lx * (float)W - 0.5f, ly * (float)H - 0.5f, H, W, st, head * kDim * 4,
+                         rowbytes, aw);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c.w[k] = 0.f;
+          c.o[k] = head * kDim * 4;
+        }
+      }
+      float4* dst = reinterpret_cast<float4*>(my_lds + (i0 + s) * 8);
+      dst[0] = make_float4(c.w[0], c.w[1], c.w[2], c.w[3]);
+      dst[1] = make_float4(__int_as_float(c.o[0]), __int_as_float(c.o[1]), __int_as_float(c.o[2]),
+                           __int_as_float(c.o[3]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll UNR
+    for (int i = 0; i < kSlots; ++i) {
+      const float4* src = reinterpret_cast<const float4*>(my_lds + i * 8);
+      const float4 w = src[0];
+      const float4 o = src[1];
+      const float4 v0 = ld16(frame, (unsigned)__float_as_int(o.x));
+      const float4 v1 = ld16(frame, (unsigned)__float_as_int(o.y));
+      const float4 v2 = ld16(frame, (unsigned)__float_as_int(o.z));
+      const float4 v3 = ld16(frame, (unsigned)__float_as_int(o.w));
+      fma4(acc, w.x, v0);
+      fma4(acc, w.y, v1);
+      fma4(acc, w.z, v2);
+      fma4(acc, w.w, v3);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // descriptors consumed before the next patch overwrites
+    if (active) {
+      *reinterpret_cast<float4*>(p.out + (long long)unit * kRowFloats + head * kDim + j * 4) = acc;
+      if (p.stat_max && j == 0) {
+        p.stat_max[(long long)unit * kHeads + head] = mx;
+        p.stat_sum[(long long)unit * kHeads + head] = sm;
+      }
+    }
+    unit = unit_n;
+    unit_n = unit_nn;
+    cur = nxt;
+  }
+}
+
+template <int PATCHES, int UNR>
+int launch_enc_head_major_t(const FusedParams& p0, hipStream_t stream) {
+  FusedParams p = p0;
+  const int npatch = (p.n_units + 31) / 32;
+  const int nb = ((npatch + PATCHES - 1) / PATCHES) * 8;
+  p.n_blocks_logical = nb;
+  hipLaunchKernelGGL((enc_head_major_kernel<PATCHES, UNR>), dim3(nb), dim3(256), 0, stream, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int launch_enc_head_major(const FusedParams& p, hipStream_t stream) {
+  // 2 patches per workgroup, gather loop unrolled by 4: the best of {2,4,8,16} x {2,4} on the
+  // bench workload (1.51-1.64 ms; all within 8 %)
+  return launch_enc_head_major_t<2, 4>(p, stream);
+}
+
 template <int MODE, int PPL, int WQ>
 int launch_fused(const FusedParams& p0, hipStream_t stream) {
   FusedParams p = p0;
@@ -1504,6 +1652,16 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
   p.P = P;
   p.proj_stride = proj_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (T == 1 && P == 4 && L <= 4) {
+    // A/B switch while the head-major split is evaluated (PAVE_ENC_HEAD_MAJOR=0 -> per-query waves)
+    static const bool hm = [] {
+      const char* e = getenv("PAVE_ENC_HEAD_MAJOR");
+      return e == nullptr || e[0] != '0';
+    }();
+    // its float4 / float2 projection loads need 16-byte aligned rows
+    if (hm && proj_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0)
+      return launch_enc_head_major(p, st);
+  }
   if (T == 1) return launch_fused<kGrid, 2, 1>(p, st);
   if (T == 2) return launch_fused<kGrid, 2, 2>(p, st);
   return launch_fused<kGrid, 2, 4>(p, st);

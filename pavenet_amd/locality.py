@@ -19,7 +19,8 @@ def encoder_unit_order(levels, n_frames, mode='band'):
 
     levels: [(H, W), ...] in flattening order.  mode 'band': tokens of a frame sorted by
     normalised row centre (ties: level, column), cut into 8 equal bands; units laid out
-    band-major, then frame, then in-band order.  mode 'none': identity.
+    band-major, then frame, then in-band order.  mode 'patch': as 'band' but 8 x 4 pixel patches
+    consecutive inside a band.  mode 'none': identity.
     """
     S = sum(int(h) * int(w) for h, w in levels)
     if mode == 'none':
@@ -41,6 +42,13 @@ def encoder_unit_order(levels, n_frames, mode='band'):
         ysq = np.concatenate([((np.repeat(np.arange(int(h)), int(w)) // 2) * 2 + 1.0) / int(h)
                               for h, w in levels])
         tok = np.lexsort((qx, qy, pxx, lv, ysq))
+    elif mode == 'patch':
+        # 8 x 4 pixel patches are consecutive: the 32 queries of a workgroup of the head-major
+        # kernel (one head, 32 units) then share one small neighbourhood of value rows
+        rows = np.concatenate([np.repeat(np.arange(int(h)), int(w)) for h, w in levels])
+        hs = np.concatenate([np.full(int(h) * int(w), int(h)) for h, w in levels])
+        ysp = ((rows // 4) * 4 + 2.0) / hs                    # patch-row centre
+        tok = np.lexsort((xs % 8, rows % 4, xs // 8, lv, ysp))
     else:
         tok = np.lexsort((xs, lv, ys))  # primary key: y centre
     bounds = [(S * i) // N_XCD for i in range(N_XCD + 1)]

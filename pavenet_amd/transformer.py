@@ -14,6 +14,7 @@ start indices, XCD unit order) are cached; the clip memory is never replicated p
 value projections of all decoder layers are hoisted out of the layer loop when asked.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -241,6 +242,10 @@ class Transformer(BaseModule):
         self._is_init = True
 
 
+# processing order of encoder tokens (pavenet_amd/locality.py); PAVE_UNIT_ORDER overrides for A/B runs
+UNIT_ORDER_MODE = os.environ.get('PAVE_UNIT_ORDER', 'band')
+
+
 class _LevelGeometry:
     """Host-side description of the flattened multi-level token sequence (cached per shape)."""
 
@@ -257,7 +262,7 @@ class _LevelGeometry:
 
     def unit_order(self, n_frames, device):
         if n_frames not in self._order:
-            self._order[n_frames] = encoder_unit_order(self.hw, n_frames).to(device)
+            self._order[n_frames] = encoder_unit_order(self.hw, n_frames, UNIT_ORDER_MODE).to(device)
         return self._order[n_frames]
 
     def window_plan(self, n_frames, device):

@@ -246,3 +246,18 @@ def test_gemm_mode_switch_validates():
         assert torch.equal(y, torch.relu(x @ w.t()))
     finally:
         bricks.set_gemm_mode('native')
+
+
+@pytest.mark.parametrize('mode', ['band', 'quad', 'patch', 'none'])
+def test_encoder_unit_order_is_a_permutation(mode):
+    """Every processing order of the encoder tokens (locality.py) visits each (frame, token) once."""
+    from pavenet_amd.locality import encoder_unit_order
+    levels, F = [(13, 21), (7, 11), (4, 6), (2, 3)], 3
+    S = sum(h * w for h, w in levels)
+    order = encoder_unit_order(levels, F, mode)
+    assert order.dtype == torch.int32 and order.shape == (F * S,)
+    assert torch.equal(order.long().sort()[0], torch.arange(F * S))
+    if mode == 'patch':   # the first 32 level-0 units of a band form 8 x 4 pixel patches
+        first = order[:32].long() % S
+        ys, xs = first // 21, first % 21
+        assert int(xs.max() - xs.min()) <= 7 and int(ys.max() - ys.min()) <= 3
