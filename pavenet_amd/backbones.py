@@ -328,7 +328,16 @@ class _Folded:
     def conv_bn(cls, x, conv, bn, relu=False, residual=None):
         """act(bn(conv(x)) + residual); x, residual channels_last; the result is a fresh tensor."""
         from . import ops
+        from .bricks import get_gemm_mode, split_conv_weight
         w, b = cls.weights(conv, bn)
+        if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) \
+                and conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
+            wsplit = split_conv_weight(w)   # split / 16-bit GEMM modes, Cin, Cout % 64 == 0
+            if wsplit is not None:
+                y = ops.conv3x3_split(x, wsplit, b, stride=conv.stride[0],
+                                      relu=relu and residual is None,
+                                      fp16=get_gemm_mode() == 'fp16')
+                return y if residual is None else ops.bias_act_rows_(y, None, residual, relu=relu)
         y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)

@@ -494,11 +494,14 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
       ymax = fmaxf(ymax, y);
     }
     area[j] = (xmax - xmin) * (ymax - ymin);
-    // descending score; ties: larger index first (reverse of a stable ascending sort)
-    const float s = sc[j];
+    // descending score; ties: larger index first (reverse of a stable ascending sort).  A NaN
+    // score sorts as +inf (numpy's argsort puts NaNs last, the reference reverses that order):
+    // every comparison with a raw NaN is false, which would leave `order` a non-permutation and
+    // send the suppression loop to arbitrary addresses.
+    const float s0 = sc[j], s = (s0 != s0) ? INFINITY : s0;
     int rank = 0;
     for (int i = 0; i < N; ++i) {
-      const float t = sc[i];
+      const float t0 = sc[i], t = (t0 != t0) ? INFINITY : t0;
       rank += (t > s) || (t == s && i > j);
     }
     order[rank] = j;

@@ -68,7 +68,16 @@ def load():
     return lib
 
 
+_SYNC_DEBUG = os.environ.get('PAVE_SYNC_DEBUG', '0') == '1'
+
+
 def check(status, what):
     if status != 0:
         msg = load().pave_last_error().decode()
         raise RuntimeError(f'{what} failed with status {status}: {msg}')
+    if _SYNC_DEBUG:   # fault localisation: every native launch is drained and reported
+        import sys
+
+        import torch
+        torch.cuda.synchronize()
+        print(f'[pave] {what} ok', file=sys.stderr, flush=True)

@@ -201,6 +201,24 @@ def test_end_to_end_vs_oracle(T, B):
         np.testing.assert_allclose(gb.cpu().numpy(), eb.numpy(), rtol=1e-4, atol=1e-2)
 
 
+def test_oks_nms_kernel_survives_nan_and_inf():
+    """Non-finite scores / keypoints (e.g. an fp16-operand mode overflowing on un-normalised
+    weights) must still give a valid permutation and no out-of-range access."""
+    from pavenet_amd.ops import oks_nms
+    g = torch.Generator().manual_seed(3)
+    kp = torch.rand(2, 30, 15, 3, generator=g) * 100
+    sc = torch.rand(2, 30, generator=g)
+    sc[0, ::3] = float('nan')
+    sc[1, 5] = float('inf')
+    kp[0, 4] = float('nan')
+    kp[1, 7, :, 0] = float('inf')
+    keep, order = oks_nms(kp.cuda(), sc.cuda(), _t(R.OKS_SIGMAS_15).cuda(), 0.45)
+    torch.cuda.synchronize()
+    for b in range(2):
+        assert sorted(order[b].cpu().tolist()) == list(range(30))
+    assert set(order[0, :10].cpu().tolist()) == set(range(0, 30, 3))   # NaNs first, as numpy [::-1]
+
+
 def test_oks_nms_kernel_vs_oracle():
     from pavenet_amd.ops import oks_nms
     rng = np.random.default_rng(0)

@@ -485,3 +485,45 @@ def test_conv3x3_split_vs_torch(N, H, W, Cin, Cout, stride):
     out = conv3x3_split(xd, split_conv3x3_weight(w.cuda(), 16), None, stride=stride, fp16=True)
     np.testing.assert_allclose(out.cpu().numpy(), (exp - b.double()[None, :, None, None]).numpy(),
                                rtol=5e-3, atol=5e-3)
+
+
+def test_kernels_survive_non_finite_inputs():
+    """NaN / Inf sampling locations, offsets and logits must never turn into out-of-range reads
+    (the reference kernel's range tests are false for NaN, ms_deform_attn_cuda_kernel.cuh:226-233):
+    results may be NaN, the process must survive."""
+    from pavenet_amd.ops import (deform_attn_grid_fused, deform_attn_pose_fused,
+                                 ms_deform_attn_forward)
+    shapes, lsi, sd, ld = _levels(LEVELS)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(9)
+    v = torch.randn(2, S, 8, 32, generator=g).cuda()
+    bad = torch.tensor([float('nan'), float('inf'), -float('inf'), 1e30, -1e30])
+    loc = torch.rand(2, 40, 8, 4, 4, 2, generator=g)
+    loc.view(-1)[::7] = bad.repeat(loc.numel() // 7 // 5 + 1)[:loc.view(-1)[::7].numel()]
+    aw = torch.rand(2, 40, 8, 4, 4, generator=g)
+    aw.view(-1)[::11] = float('nan')
+    out = ms_deform_attn_forward(v, sd, ld, loc.cuda(), aw.cuda(), 64)
+    torch.cuda.synchronize()
+    assert out.shape == (2, 40, 256)
+    # fused encoder form (T = 1, head-major kernel) and T = 2 form: poisoned projections / refs
+    for T in (1, 2):
+        U = 96
+        proj = torch.randn(U, T * 8 * 16 * 3, generator=g)
+        proj.view(-1)[::13] = bad.repeat(proj.numel() // 13 // 5 + 1)[:proj.view(-1)[::13].numel()]
+        ref = torch.rand(T, U, 4, 2, generator=g)
+        ref.view(-1)[::17] = float('nan')
+        vv = torch.randn(2 * T, S, 8, 32, generator=g).cuda()
+        o = deform_attn_grid_fused(vv, sd, ld, proj.cuda(), ref.cuda(), T=T, n_clips=2,
+                                   units_per_clip=U // 2)
+        torch.cuda.synchronize()
+        assert o.shape == (U, 256)
+    K, Q, T = 15, 6, 3
+    proj = torch.randn(2 * Q, T * 8 * 4 * K * 3, generator=g)
+    proj.view(-1)[::19] = float('nan')
+    ref = torch.rand(2, T * Q, 4, 2 * K, generator=g)
+    ref.view(-1)[::23] = float('inf')
+    vv = torch.randn(2 * T, S, 8, 32, generator=g).cuda()
+    o = deform_attn_pose_fused(vv, sd, ld, proj.cuda(), ref.cuda(), T=T, n_clips=2, num_query=Q,
+                               num_keypoints=K)
+    torch.cuda.synchronize()
+    assert o.shape == (2 * Q, 256)

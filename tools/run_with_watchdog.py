@@ -6,6 +6,7 @@ import runpy
 import sys
 
 secs = int(sys.argv[1])
+faulthandler.enable()          # a GPU memory fault aborts the process: show where Python was
 faulthandler.dump_traceback_later(secs, exit=True)
 sys.argv = sys.argv[2:]
 runpy.run_path(sys.argv[0], run_name='__main__')
