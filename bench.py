@@ -168,13 +168,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    ops.KERNEL_EVENTS = []  # encoder launches record (start, end) HIP events on their stream
+    if graphed is None:  # (a replayed graph launches nothing through the Python wrappers)
+        ops.KERNEL_EVENTS = []  # encoder launches record (start, end) HIP events on their stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
     sync()
     dt = time.perf_counter() - t0
-    events = ops.KERNEL_EVENTS
+    events = ops.KERNEL_EVENTS or []
     ops.KERNEL_EVENTS = None
     if dist is not None:
         tt = torch.tensor([dt], device='cpu' if host_collectives else dev, dtype=torch.float64)

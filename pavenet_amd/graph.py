@@ -18,6 +18,9 @@ import torch
 class GraphedForward:
     """``g = GraphedForward(model, example_img, img_metas); res = g(img)``.
 
+    KNOWN LIMIT: at 14+ frames of 800x1344 a replay that follows an explicit
+    ``torch.cuda.synchronize()`` faults on this ROCm stack; small batches (T = 3, B = 1) are fine.
+
     `res` is the head's fixed-shape result dict; its tensors are static buffers that the next
     call overwrites (clone what must survive)."""
 
