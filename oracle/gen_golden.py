@@ -243,6 +243,93 @@ def gen_e2e(which=None):
               cls_last=taps['cls_all'][-1], score_topk=score_topk,
               det_bboxes=det_bboxes, det_labels=det_labels, det_kpts=det_kpts, **extra)
 
+
+# ---------------------------------------------------------------------------
+def _stats(t):
+    t = t.detach().double()
+    return [float(t.mean()), float(t.abs().max()), float(t.std())]
+
+
+def gen_fullsize():
+    """the BENCHMARK-size artefacts.  T = 3 R-50 PAVE-Net at 800 x 1344 (un-padded,
+    as bench.py feeds it) run through the real reference: per-stage mean / abs-max / std, a few
+    hundred sampled rows of `memory`, all proposal logits, `hs`, `inter_references`, final
+    detections.  Neither image nor weights are stored (both name-seeded)."""
+    name = 'full_videopose_r50_t3'
+    cfg_path, T = E2E['e2e_videopose_r50_t3']
+
+    def small(cfg):
+        cfg.model['test_cfg'] = dict(max_per_img=20)
+
+    model, cfg = ref_shim.build_reference_model(cfg_path, cfg_overrides=small)
+    keys = _load_seeded(model)
+    H, W = 800, 1344
+    img = _t(seeded_array(f'{name}.img', (1, T, 3, H, W)))
+    meta = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))]
+    taps, stats = {}, {}
+    tr = model.bbox_head.transformer
+
+    def bb_hook(mod, args, out):
+        for i, o in enumerate(out):
+            stats[f'backbone{i}'] = _stats(o)
+        taps['c5_rows'] = out[-1][:, :, ::6, ::10].detach().clone()
+
+    def layer_hook(i):
+        def h(mod, args, kwargs, out):
+            stats[f'enc_layer{i}'] = _stats(out)
+        return h
+
+    def enc_hook(mod, args, kwargs, out):
+        taps['memory'] = out.permute(1, 0, 2).detach().clone()  # [B*T, S, C]
+
+    def dec_hook(mod, args, kwargs, out):
+        taps['hs'], taps['inter_references'] = out[0].detach().clone(), out[1].detach().clone()
+
+    def ref_hook(mod, args, kwargs, out):
+        taps['refine_hs'] = out[0].detach().clone()
+        taps['refine_refs'] = out[1].detach().clone()
+
+    head_forward = model.bbox_head.forward
+
+    def tapped_forward(*a, **k):
+        out = head_forward(*a, **k)
+        taps['cls_all'] = out[0].detach().clone()
+        taps['enc_cls'] = out[3].detach().clone()
+        return out
+
+    model.bbox_head.forward = tapped_forward
+    hs = [model.backbone.register_forward_hook(bb_hook),
+          tr.encoder.register_forward_hook(enc_hook, with_kwargs=True),
+          tr.decoder.register_forward_hook(dec_hook, with_kwargs=True),
+          tr.refine_decoder.register_forward_hook(ref_hook, with_kwargs=True)]
+    hs += [l.register_forward_hook(layer_hook(i), with_kwargs=True)
+           for i, l in enumerate(tr.encoder.layers)]
+    with torch.no_grad():
+        feats = model.extract_feat(img)
+        res = model.bbox_head.simple_test(feats, meta, rescale=False)
+    for h in hs:
+        h.remove()
+    for i, f in enumerate(feats):
+        stats[f'neck{i}'] = _stats(f)
+    stats['memory'] = _stats(taps['memory'])
+    stats['hs'] = _stats(taps['hs'])
+    stats['refine_hs'] = _stats(taps['refine_hs'])
+    det_bboxes, det_labels, det_kpts = res[0]
+    S = taps['memory'].shape[1]
+    rows = np.sort(np.random.default_rng(0).choice(S, 160, replace=False))
+    Q = model.bbox_head.num_query
+    enc_topk = torch.topk(taps['enc_cls'][..., 0], Q, dim=1)[1]
+    N = model.bbox_head.test_cfg['max_per_img']
+    score_topk = taps['cls_all'][-1][0].sigmoid().view(-1).topk(N)[1]
+    _save(name, keys=keys, stats=json.dumps(stats), rows=rows,
+          memory_rows=taps['memory'][:, rows], neck3=feats[3], c5_rows=taps['c5_rows'],
+          enc_cls=taps['enc_cls'][0, :, 0], enc_topk=enc_topk, hs_last=taps['hs'][-1],
+          inter_references=taps['inter_references'], cls_last=taps['cls_all'][-1],
+          score_topk=score_topk, refine_hs_last=taps['refine_hs'][-1],
+          det_bboxes=det_bboxes, det_labels=det_labels, det_kpts=det_kpts)
+    print(json.dumps(stats, indent=1))
+
+
 PETR_E2E = {
     'e2e_petr_r50': 'configs/petr/petr_r50_16x2_100e_coco.py',
     'e2e_vedpose_r50': 'configs/vedpose/single_frame_posetrack_resnet50_inference.py',
@@ -312,5 +399,7 @@ if __name__ == '__main__':
         gen_modules()
     if what in ('e2e', 'all'):
         gen_e2e(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ('full', 'all'):
+        gen_fullsize()
     if what in ('petr', 'all'):
         gen_petr(sys.argv[2] if len(sys.argv) > 2 else None)

@@ -502,3 +502,55 @@ def test_fp16_projection_mode_within_half_pixel():
         bricks._GEMM['min_rows'] = old_rows
     d = (res2['kpts'][..., :2] - res['kpts'][..., :2]).abs().max().item()
     assert 0 < d < 0.5, d
+
+
+def test_full_size_800x1344_vs_reference_golden(golden_dir):
+    """SURVEY 8c(4): outputs at the BENCHMARK size.  T = 3 R-50 at 800 x 1344 (S = 22 323 tokens;
+    XCD band ordering, tile kernel, shipped per-shape GEMM selections, tail kernel at 1.9 M rows --
+    everything bench.py runs) against artefacts of the real reference: per-stage statistics,
+    sampled memory rows, all proposal logits, decoder states, detections within 1e-2 px."""
+    from pavenet_amd import tuning
+    g = _g(golden_dir, 'full_videopose_r50_t3')
+    stats = json.loads(str(g['stats']))
+    N = int(g['score_topk'].shape[0])
+    m = _build(3, N, g)
+    img = _t(seeded_array('full_videopose_r50_t3.img', (1, 3, 3, 800, 1344))).cuda()
+    metas = [dict(batch_input_shape=(800, 1344), img_shape=(800, 1344, 3),
+                  scale_factor=(1., 1., 1., 1.))]
+    tuning.use_tuned_gemms()
+    try:
+        with torch.no_grad():
+            feat = m.extract_feat(img)
+            for i, f in enumerate(feat):
+                mean, amax, _ = stats[f'neck{i}']
+                assert abs(float(f.mean()) - mean) < 1e-4
+                assert abs(float(f.abs().max()) - amax) < 1e-3 * amax
+            np.testing.assert_allclose(feat[3].cpu().numpy(), g['neck3'], rtol=1e-3, atol=3e-4)
+            outs = m.bbox_head(feat, metas)
+            memory = outs['memory'].permute(1, 0, 2)  # [B*T, S, C]
+            mean, amax, _ = stats['memory']
+            assert abs(float(memory.mean()) - mean) < 1e-4
+            assert abs(float(memory.abs().max()) - amax) < 2e-3 * amax
+            rows = _t(g['rows']).cuda()
+            np.testing.assert_allclose(memory[:, rows].cpu().numpy(), g['memory_rows'],
+                                       rtol=2e-3, atol=5e-4)
+            np.testing.assert_allclose(outs['enc_cls_scores'][0, :, 0].cpu().numpy(), g['enc_cls'],
+                                       rtol=1e-3, atol=1e-3)
+            _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 1e-4, 'proposals')
+            outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
+            np.testing.assert_allclose(outs['hs'][-1].permute(1, 0, 2).cpu().numpy(), g['hs_last'],
+                                       rtol=2e-3, atol=1e-3)
+            np.testing.assert_allclose(outs['inter_references'].cpu().numpy(),
+                                       g['inter_references'], rtol=1e-3, atol=2e-4)
+            np.testing.assert_allclose(outs['all_cls_scores'][-1].cpu().numpy(), g['cls_last'],
+                                       rtol=1e-3, atol=1e-3)
+            _assert_same_selection(outs['all_cls_scores'][-1][0].sigmoid(), g['score_topk'], 1e-5,
+                                   'score top-k')
+            res = m.bbox_head.get_bboxes(outs, metas, rescale=False,
+                                         force_score_topk=_t(g['score_topk'])[None].cuda())
+            (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
+    finally:
+        tuning.disable()
+    assert kpts.shape == g['det_kpts'].shape, 'OKS-NMS keep set differs from the reference'
+    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
