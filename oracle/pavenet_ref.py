@@ -367,6 +367,115 @@ def resnet_forward(sd, pre, x, depth=50, out_indices=(1, 2, 3)):
     return outs
 
 
+# --------------------------------------------------------------------------
+# a14: HRNet (mmdet)  third_party/mmdetection/mmdet/models/backbones/hrnet.py
+# The module tree is read off the state-dict keys, so one function serves every `extra` config.
+# --------------------------------------------------------------------------
+def _conv_bn(sd, conv, bn, x, stride=1, pad=0):
+    return _bn(sd, bn, F.conv2d(x, sd[conv + '.weight'], None, stride, pad))
+
+
+def _hr_basic_block(sd, bp, x):
+    """resnet.py BasicBlock.forward (3x3 - 3x3, identity shortcut; HRNet branches never stride)."""
+    y = F.relu(_conv_bn(sd, bp + '.conv1', bp + '.bn1', x, 1, 1))
+    y = _conv_bn(sd, bp + '.conv2', bp + '.bn2', y, 1, 1)
+    return F.relu(y + x)
+
+
+def _hr_bottleneck(sd, bp, x):
+    """resnet.py Bottleneck.forward, style='pytorch', stride 1 (HRNet layer1, hrnet.py:462-507)."""
+    y = F.relu(_conv_bn(sd, bp + '.conv1', bp + '.bn1', x))
+    y = F.relu(_conv_bn(sd, bp + '.conv2', bp + '.bn2', y, 1, 1))
+    y = _conv_bn(sd, bp + '.conv3', bp + '.bn3', y)
+    idt = x
+    if bp + '.downsample.0.weight' in sd:
+        idt = _conv_bn(sd, bp + '.downsample.0', bp + '.downsample.1', x)
+    return F.relu(y + idt)
+
+
+def _hr_blocks(sd, pre, x):
+    b = 0
+    while f'{pre}.{b}.conv1.weight' in sd:
+        bp = f'{pre}.{b}'
+        x = _hr_bottleneck(sd, bp, x) if bp + '.conv3.weight' in sd else _hr_basic_block(sd, bp, x)
+        b += 1
+    return x
+
+
+def _has_prefix(sd, pre):
+    return any(k.startswith(pre) for k in sd)
+
+
+def hr_module(sd, mp, xs):
+    """HRModule.forward hrnet.py:183-205 (+ fuse layers :121-181)."""
+    nb = len(xs)
+    xs = [_hr_blocks(sd, f'{mp}.branches.{i}', xs[i]) for i in range(nb)]
+    if nb == 1:
+        return xs
+    outs = []
+    i = 0
+    while _has_prefix(sd, f'{mp}.fuse_layers.{i}.'):
+        y = 0
+        for j in range(nb):
+            fp = f'{mp}.fuse_layers.{i}.{j}'
+            if j == i:
+                y = y + xs[j]
+            elif j > i:  # 1x1 conv + BN + nearest upsample by 2^(j-i)
+                t = _conv_bn(sd, fp + '.0', fp + '.1', xs[j])
+                y = y + F.interpolate(t, scale_factor=2 ** (j - i), mode='nearest')
+            else:        # (i - j) stride-2 3x3 conv + BN, ReLU between them but not after the last
+                t = xs[j]
+                for k in range(i - j):
+                    t = _conv_bn(sd, f'{fp}.{k}.0', f'{fp}.{k}.1', t, 2, 1)
+                    if k != i - j - 1:
+                        t = F.relu(t)
+                y = y + t
+        outs.append(F.relu(y))
+        i += 1
+    return outs
+
+
+def _hr_transition(sd, tp, i, pre_list):
+    """HRNet._make_transition_layer hrnet.py:416-460: None / 3x3 conv / chain of stride-2 convs."""
+    if f'{tp}.{i}.0.weight' in sd:
+        return F.relu(_conv_bn(sd, f'{tp}.{i}.0', f'{tp}.{i}.1', pre_list[i], 1, 1))
+    if f'{tp}.{i}.0.0.weight' in sd:
+        t = pre_list[-1]
+        j = 0
+        while f'{tp}.{i}.{j}.0.weight' in sd:
+            t = F.relu(_conv_bn(sd, f'{tp}.{i}.{j}.0', f'{tp}.{i}.{j}.1', t, 2, 1))
+            j += 1
+        return t
+    return pre_list[i]
+
+
+def hrnet_forward(sd, pre, x, stage_branches=(2, 3, 4)):
+    """HRNet.forward hrnet.py:549-583; the reference returns y_list[1:] (three coarser branches).
+    5-d video input is flattened to frames first (the reference HRNet has no such branch; the
+    build's HRNet under the MulFrames head does exactly this)."""
+    if x.dim() == 5:
+        x = x.flatten(0, 1)
+    x = F.relu(_conv_bn(sd, pre + '.conv1', pre + '.bn1', x, 2, 1))
+    x = F.relu(_conv_bn(sd, pre + '.conv2', pre + '.bn2', x, 2, 1))
+    x = _hr_blocks(sd, pre + '.layer1', x)
+    y_list = [x]
+    for s, nbr in enumerate(stage_branches):
+        tp = f'{pre}.transition{s + 1}'
+        x_list = [_hr_transition(sd, tp, i, y_list) for i in range(nbr)]
+        m = 0
+        while _has_prefix(sd, f'{pre}.stage{s + 2}.{m}.'):
+            x_list = hr_module(sd, f'{pre}.stage{s + 2}.{m}', x_list)
+            m += 1
+        y_list = x_list
+    return y_list[1:]
+
+
+def backbone_forward(sd, cfg, img):
+    if cfg.get('backbone', 'resnet') == 'hrnet':
+        return hrnet_forward(sd, 'backbone', img)
+    return resnet_forward(sd, 'backbone', img, depth=cfg.get('depth', 50))
+
+
 def channel_mapper(sd, pre, feats, num_groups=32):
     """third_party/mmdetection/mmdet/models/necks/channel_mapper.py:90-100 (conv + GN, no act)."""
     outs = []
@@ -661,8 +770,7 @@ def videopose_simple_test(sd, cfg, img, img_shape=None, rescale_factor=None, tap
     H, W = img.shape[-2:]
     if img_shape is None:
         img_shape = (H, W, 3)
-    feats = resnet_forward(sd, 'backbone', img, depth=cfg.get('depth', 50))
-    feats = channel_mapper(sd, 'neck', feats)
+    feats = channel_mapper(sd, 'neck', backbone_forward(sd, cfg, img))
     if taps is not None:
         taps['neck'] = feats
     masks, poss = make_masks_and_pos(feats, (H, W), img_shape)
@@ -748,7 +856,7 @@ def petr_simple_test(sd, cfg, img, img_shape=None, taps=None):
     H, W = img.shape[-2:]
     if img_shape is None:
         img_shape = (H, W, 3)
-    feats = channel_mapper(sd, 'neck', resnet_forward(sd, 'backbone', img, depth=cfg.get('depth', 50)))
+    feats = channel_mapper(sd, 'neck', backbone_forward(sd, cfg, img))
     masks, poss = make_masks_and_pos(feats, (H, W), img_shape)
     feat_f, mask_f, pos_f, shapes, lsi, valid_ratios = flatten_levels(sd, tpre, feats, masks, poss)
     reference_points = get_reference_points(shapes, valid_ratios)

@@ -31,6 +31,9 @@ class FrameShard:
 
     def __init__(self, num_frames, rank, world, group=None):
         assert 0 <= rank < world
+        # every rank must own a frame: an empty rank would reshape a zero-frame memory and the
+        # others would hang in the collective
+        assert world <= num_frames, f'frame sharding needs world ({world}) <= num_frames ({num_frames})'
         self.num_frames, self.rank, self.world, self.group = num_frames, rank, world, group
         self.local = [t for t in range(num_frames) if t % world == rank]
         self.center = num_frames // 2

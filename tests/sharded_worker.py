@@ -12,8 +12,73 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def vs_oracle(T, gemm_mode, tol_px):
+    """BASELINE configs[4] shape (long clip, frame-sharded, optional fp16 projections) against
+    the ORACLE: rank 0 runs oracle/pavenet_ref.py on the whole clip, its top-k selections are
+    forced on every rank (near-ties under random weights), the sharded product's keypoints must
+    be within `tol_px` of the oracle's."""
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    from oracle import pavenet_ref as R
+    from oracle.seeded import seeded_array, seeded_state_dict
+    from pavenet_amd import bricks
+    from pavenet_amd.dist import FrameShard, broadcast_from
+    from pavenet_amd.models import build_model, videopose_r50_cfg
+    N = 12
+    m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=N))
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(seeded_state_dict(shapes, like=m.state_dict()))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    H, W = 128, 160
+    img = torch.from_numpy(seeded_array(f'sharded.oracle.{T}', (1, T, 3, H, W)))
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))]
+    sel_p = torch.zeros(1, 300, dtype=torch.long, device='cuda')
+    sel_s = torch.zeros(1, N, dtype=torch.long, device='cuda')
+    exp = None
+    if rank == 0:
+        taps = {}
+        with torch.no_grad():
+            exp = R.videopose_simple_test(sd, dict(num_frames=T, num_keypoints=15, num_query=300,
+                                                   max_per_img=N), img, taps=taps)
+        sel_p.copy_(taps['topk_idx'])
+        sel_s.copy_(taps['score_topk_idx'].view(1, -1))
+    broadcast_from(sel_p, 0)
+    broadcast_from(sel_s, 0)
+    shard = FrameShard(T, rank, world)
+    bricks.set_gemm_mode(gemm_mode)
+    bricks._GEMM['min_rows'] = 1   # exercise the hand-written GEMM at test sizes
+    with torch.no_grad():
+        feat = m.extract_feat(img[:, shard.local].contiguous().cuda())
+        outs = m.bbox_head(feat, metas, frame_shard=shard, force_topk_proposals=sel_p)
+        res = m.bbox_head.get_bboxes(outs, metas, force_score_topk=sel_s)
+        (gb, gl, gk), = m.bbox_head.results_to_list(res)
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        eb, el, ek = exp
+        if gk.shape != ek.shape:
+            print(f'MISMATCH keep set: {tuple(gk.shape)} vs oracle {tuple(ek.shape)}', flush=True)
+            ok = False
+        else:
+            d = (gk.cpu()[..., :2] - ek[..., :2]).abs().max().item()
+            ds = (gk.cpu()[..., 2] - ek[..., 2]).abs().max().item()
+            print(f'T={T} gemm={gemm_mode} world={world}: max |kpt - oracle| = {d:.4g} px, '
+                  f'score {ds:.3g}', flush=True)
+            if not (d <= tol_px and ds <= 1e-2):
+                print(f'MISMATCH kpts: {d} px > {tol_px}', flush=True)
+                ok = False
+        print('sharded == oracle:', ok, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
 def main():
     T = int(sys.argv[1])
+    if len(sys.argv) > 2:
+        return vs_oracle(T, sys.argv[2], float(sys.argv[3]))
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)

@@ -97,3 +97,13 @@ def test_merge_is_exact_for_any_split():
                                            torch.stack([p[1] for p in parts]),
                                            torch.stack([p[2] for p in parts]))
         np.testing.assert_allclose(merged.numpy(), full.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_frame_shard_rejects_more_ranks_than_frames():
+    """world > T would leave a rank without a frame (zero-frame memory reshape, peers hanging in
+    the collective): refused up front."""
+    import pytest
+    from pavenet_amd.dist import FrameShard
+    with pytest.raises(AssertionError):
+        FrameShard(3, 0, 4)
+    assert FrameShard(3, 2, 3).local == [2] and FrameShard(15, 3, 4).local == [3, 7, 11]

@@ -165,7 +165,7 @@ def test_end_to_end_vs_reference_golden(golden_dir, T):
     assert labels.cpu().tolist() == g['det_labels'].tolist()
 
 
-@pytest.mark.parametrize('T,B', [(7, 1), (3, 2)])
+@pytest.mark.parametrize('T,B', [(7, 1), (3, 2), (7, 4), (15, 1)])
 def test_end_to_end_vs_oracle(T, B):
     """T = 7 has no reference implementation (the reference hard-codes 3 / 5): the oracle's
     generalised restatement defines it.  B = 2 checks the batched-clip path against two
@@ -237,11 +237,7 @@ def test_oks_nms_kernel_vs_oracle():
     assert 0 < int(keep.sum()) < B * N
 
 
-@pytest.mark.parametrize('T', [3, 5])
-def test_frame_sharded_two_ranks(T):
-    """Frame-sharded path (SURVEY 8e ii) with REAL collectives: two processes on this box's one
-    GPU, frames t % 2 == rank each, partial-softmax rows merged by all-gather; must equal the
-    un-sharded model."""
+def _run_sharded_worker(args, nproc=2):
     import socket
     import subprocess
     import sys
@@ -250,15 +246,32 @@ def test_frame_sharded_two_ranks(T):
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'tests', 'sharded_worker.py'), str(T)]
-    torch.cuda.empty_cache()  # the two workers share this process's GPU
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+           os.path.join(root, 'tests', 'sharded_worker.py')] + [str(a) for a in args]
+    torch.cuda.empty_cache()  # the workers share this process's GPU
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if r.returncode != 0 and 'MISMATCH' not in r.stdout:  # rendezvous hiccup: one retry
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:] + '\n---\n' + r.stderr[-6000:])
-    assert 'sharded == unsharded: True' in r.stdout
+    return r.stdout
+
+
+@pytest.mark.parametrize('T', [3, 5])
+def test_frame_sharded_two_ranks(T):
+    """Frame-sharded path (SURVEY 8e ii) with REAL collectives: two processes on this box's one
+    GPU, frames t % 2 == rank each, partial-softmax rows merged by all-gather; must equal the
+    un-sharded model."""
+    assert 'sharded == unsharded: True' in _run_sharded_worker([T])
+
+
+@pytest.mark.parametrize('gemm,tol_px,nproc', [('native', 1e-2, 2), ('fp16', 0.5, 2),
+                                               ('fp16', 0.5, 4)])
+def test_t15_frame_sharded_vs_oracle(gemm, tol_px, nproc):
+    """BASELINE configs[4]: R-50, T = 15 long clip, frames sharded over ranks (t % G), partial
+    softmax rows merged by all-gather, projections in fp32 or with fp16 MFMA operands -- against
+    the ORACLE's un-sharded fp32 run (fp32: 1e-2 px; fp16 projections: 0.5 px)."""
+    assert 'sharded == oracle: True' in _run_sharded_worker([15, gemm, tol_px], nproc)
 
 
 @pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'opera.PETRHead'),
@@ -341,17 +354,41 @@ def test_petr_hrnet_w48_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
 
 
-def test_videopose_hrnet_t7_runs_and_matches_structure():
-    """BASELINE configs[3] shape: HRNet-w48 + MulFrames head, T = 7 (no reference config
-    exists; the backbone is pinned above and the head by the R-50 tests)."""
+@pytest.mark.parametrize('B', [1, 2])
+def test_videopose_hrnet_w48_t7_vs_oracle(B):
+    """BASELINE configs[3]: HRNet-w48 + MulFrames head, T = 7, 300 pose queries.  No reference
+    config composes these two, so the oracle does: its HRNet is pinned by the reference's
+    HRNet-w48 PETR golden (tests/test_oracle_golden.py), its T-frame head by the T = 3 / 5 goldens."""
     from pavenet_amd.models import build_model, videopose_r50_cfg, with_hrnet_w48
-    m = _seed(build_model(with_hrnet_w48(videopose_r50_cfg(num_frames=7, max_per_img=10))))
+    T, N = 7, 10
+    m = _seed(build_model(with_hrnet_w48(videopose_r50_cfg(num_frames=T, max_per_img=N))))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     m = m.cuda().eval()
-    img = _t(seeded_array('hrnet.t7', (1, 7, 3, 128, 160))).cuda()
+    img = _t(seeded_array(f'hrnet.t7.{B}', (B, T, 3, 128, 160)))
     metas = [dict(batch_input_shape=(128, 160), img_shape=(128, 160, 3),
-                  scale_factor=(1., 1., 1., 1.))]
-    res = m.forward_device(img, metas)
-    assert res['kpts'].shape == (1, 10, 15, 3) and torch.isfinite(res['kpts']).all()
+                  scale_factor=(1., 1., 1., 1.)) for _ in range(B)]
+    cfg = dict(num_frames=T, num_keypoints=15, num_query=300, max_per_img=N, backbone='hrnet')
+    exp, taps = [], []
+    for b in range(B):
+        taps.append({})
+        with torch.no_grad():
+            exp.append(R.videopose_simple_test(sd, cfg, img[b:b + 1], taps=taps[b]))
+    prop = torch.cat([t['topk_idx'] for t in taps], 0)
+    score = torch.stack([t['score_topk_idx'].view(-1) for t in taps], 0)
+    with torch.no_grad():
+        outs = m.bbox_head(m.extract_feat(img.cuda()), metas)
+        for b in range(B):
+            np.testing.assert_allclose(outs['memory'].permute(1, 0, 2)[b * T:(b + 1) * T].cpu().numpy(),
+                                       taps[b]['memory'].numpy(), rtol=2e-3, atol=5e-4)
+            _assert_same_selection(m.bbox_head.transformer.last_enc_cls[b, :, 0], prop[b], 1e-4,
+                                   'proposals')
+        res = m.forward_device(img.cuda(), metas, force_topk_proposals=prop.cuda(),
+                               force_score_topk=score.cuda())
+        got = m.bbox_head.results_to_list(res)
+    for b in range(B):
+        assert got[b][2].shape == exp[b][2].shape
+        np.testing.assert_allclose(got[b][2].cpu().numpy(), exp[b][2].numpy(), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(got[b][0].cpu().numpy(), exp[b][0].numpy(), rtol=1e-4, atol=1e-2)
 
 
 def test_deterministic_mode_is_bit_reproducible_and_matches_default():

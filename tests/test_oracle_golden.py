@@ -133,13 +133,16 @@ def test_end_to_end(golden_dir, T):
     np.testing.assert_allclose(bboxes.numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'petr'), ('e2e_vedpose_r50', 15, 'vedpose')])
-def test_end_to_end_petr(golden_dir, name, K, head):
-    """Single-image PETR (BASELINE configs[0]) and the vedpose single-frame head."""
+@pytest.mark.parametrize('name,K,head,backbone', [('e2e_petr_r50', 17, 'petr', 'resnet'),
+                                                  ('e2e_vedpose_r50', 15, 'vedpose', 'resnet'),
+                                                  ('e2e_petr_hrnetw48', 17, 'petr', 'hrnet')])
+def test_end_to_end_petr(golden_dir, name, K, head, backbone):
+    """Single-image PETR (BASELINE configs[0]), the vedpose single-frame head, and the HRNet-w48
+    backbone (configs/petr/petr_hrnetw48_16x2_100e_coco.py; pins oracle.hrnet_forward)."""
     g = _load(golden_dir, name)
     sd = _sd(g)
     N = int(g['score_topk'].shape[0])
-    cfg = dict(num_keypoints=K, num_query=300, max_per_img=N, head=head)
+    cfg = dict(num_keypoints=K, num_query=300, max_per_img=N, head=head, backbone=backbone)
     taps = {}
     with torch.no_grad():
         bboxes, labels, kpts = R.petr_simple_test(
