@@ -37,8 +37,10 @@ extern "C" {
 #define PAVE_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define PAVE_E_LAUNCH (-2)  /* hipLaunchKernel reported an error */
 #define PAVE_E_STEP (-3)    /* batch %% im2col_step != 0, as the reference asserts */
+#define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
-/* ABI version; bumped on any signature change. */
+/* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
+#define PAVE_ABI_VERSION 2
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -139,21 +141,22 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
                                     long long rows, int C, float eps, void* stream);
 
 /*
- * Encoder deformable attention ([R2], T = 1, L = 4, P = 4) with an LDS-staged value window for
- * the level-0 queries (75 % of the tokens at 800x1344) and the direct-gather kernel for the
- * listed remaining units.  Same inputs / outputs / results as
- * pave_deform_attn_grid_fused_f32 with T = 1; ref is [n_frames*S, 4, 2].
- *   levels_hw   HOST array of 8 ints (h0, w0, ..., h3, w3): host copy of spatial_shapes, so the
- *               kernel prologue has no dependent loads
- *   grid_ref    1 if every reference point is the query's own pixel centre on all levels (no
- *               padded frame): window origins are then computed without loading ref
- *   rest_order  [n_rest] int32 unit indices (frame*S + token) of all tokens of levels 1..3
+ * Encoder deformable attention ([R2]: mmcv MultiScaleDeformableAttention.forward, MO:373-404,
+ * T = 1, M = 8, D = 32, L = 4, P = 4) with the value rows staged in LDS per 8 x 8-pixel image
+ * tile and head (pavenet_amd/csrc/pave_enc_tile.hip).  Same inputs, outputs and results as
+ * pave_deform_attn_grid_fused_f32 with T = 1 and no unit_clip / order; corners outside a tile's
+ * LDS window are fetched from global memory, so results do not depend on the window size.
+ *   value [n_frames, S, 8, 32]; proj [n_frames*S, proj_stride] (offsets [8][4][4][2], then
+ *   logits [8][4][4]); ref [n_frames*S, 4, 2]; out [n_frames*S, 256]
+ *   levels_hw   HOST array of 8 ints (h0, w0, ..., h3, w3), levels in flattening order
+ *   variant     0: windows of -3 .. +3 px (3 workgroups per CU), 1: -4 .. +4 px (2 per CU)
+ * Returns PAVE_E_UNSUPPORTED (nothing launched) unless every level l satisfies
+ * H_l <= (8 >> l) * ceil(H_0 / 8) and W_l likewise (a halving pyramid): callers then use
+ * pave_deform_attn_grid_fused_f32.
  */
-int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_shapes,
-                                    const int64_t* level_start, const float* proj,
-                                    const float* ref, const int32_t* rest_order, float* out,
-                                    int n_frames, int S, const int* levels_hw, int grid_ref,
-                                    int n_rest, int proj_stride, void* stream);
+int pave_enc_deform_attn_tile_f32(const float* value, const float* proj, const float* ref,
+                                  float* out, int n_frames, int S, const int* levels_hw,
+                                  int proj_stride, int variant, void* stream);
 
 /*
  * [R1] backward: void ms_deform_attn_backward(value, spatial_shapes, level_start_index,

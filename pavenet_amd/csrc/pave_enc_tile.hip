@@ -79,98 +79,94 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 template <int W0, int W1, int W2, int W3>
 struct WinGeom {
-  static constexpr int pad8(int r) { return (r + 7) & ~7; }
-  static constexpr int R0 = pad8(W0 * W0), R1 = pad8(W1 * W1), R2 = pad8(W2 * W2),
-                       R3 = pad8(W3 * W3);
-  static constexpr int B0 = 0, B1 = R0, B2 = R0 + R1, B3 = R0 + R1 + R2;
-  static constexpr int kRows = R0 + R1 + R2 + R3;  // multiple of 8
-  // two all-zero rows (one of each parity) live in a region's pad rows when one has room
-  // (the DMA never writes pad rows), else behind the last region
-  static constexpr int zero_pair() {
-    const int b[4] = {B0, B1, B2, B3}, r[4] = {R0, R1, R2, R3}, w[4] = {W0, W1, W2, W3};
-    for (int l = 0; l < 4; ++l)
-      if (r[l] - w[l] * w[l] >= 2) return b[l] + w[l] * w[l];
-    return kRows;
-  }
-  static constexpr int kZ = zero_pair();
-  static constexpr int kZeroEven = (kZ & 1) ? kZ + 1 : kZ, kZeroOdd = (kZ & 1) ? kZ : kZ + 1;
-  static constexpr int kLdsBytes = (kZ == kRows ? kRows + 2 : kRows) * 128;
+  static constexpr int B0 = 0, B1 = W0 * W0, B2 = B1 + W1 * W1, B3 = B2 + W2 * W2;
+  static constexpr int kRows = B3 + W3 * W3;
+  // two all-zero rows behind the windows: kZ is even, kZ + 1 odd
+  static constexpr int kZ = (kRows + 1) & ~1;
+  static constexpr int kLdsBytes = (kZ + 2) * 128;
 };
 
-// LDS-DMA of one level's window: 8 rows (1 KiB) per wave instruction; lane = (row, 16-byte chunk)
-template <int WW, int RPAD, int NW>
+// LDS-DMA of one level's window, one window row (<= 16 pixels) at a time: 8 pixels x 128 B per
+// wave instruction, lane = (pixel, 16-byte chunk).  Window pixels beyond the map are filled from
+// the clamped neighbour (their corners always carry weight 0).  `voff_lo / voff_hi`: per-lane
+// byte offset of pixel ox + (lane >> 3) (+ 8) inside a map row, incl. the lane's chunk.
+template <int WW, int NW>
 __device__ __forceinline__ void stage_level(char* lds_level, const char* vhead, int wave, int lane,
                                             int ox, int oy, int H, int W, int st) {
-  constexpr int kGroups = RPAD / 8;
-  for (int g = wave; g < kGroups; g += NW) {
-    const int r = g * 8 + (lane >> 3);
-    const int wy = r / WW, wx = r - wy * WW;
-    // window rows beyond the map hold a clamped neighbour (their corners carry weight 0 and are
-    // redirected to the zero rows anyway); pad rows of the region are not written
-    const int x = min(max(ox + wx, 0), W - 1), y = min(max(oy + wy, 0), H - 1);
-    const char* src = vhead + (size_t)(st + y * W + x) * kRowBytes + (lane & 7) * 16;
-    if (r < WW * WW)
+  static_assert(WW <= 16, "one window row = at most two DMA instructions");
+  const int px_lo = lane >> 3, px_hi = px_lo + 8;
+  const unsigned cofs = (lane & 7) * 16;
+  const unsigned xlo = (unsigned)min(max(ox + px_lo, 0), W - 1) * kRowBytes + cofs;
+  const unsigned xhi = (unsigned)min(max(ox + px_hi, 0), W - 1) * kRowBytes + cofs;
+  for (int wy = wave; wy < WW; wy += NW) {
+    const int y = min(max(oy + wy, 0), H - 1);                 // scalar
+    const unsigned rowb = (unsigned)(st + y * W) * kRowBytes;  // scalar
+    char* dst = lds_level + wy * (WW * 128);
+    if (px_lo < WW)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)(lds_level + g * 1024), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(vhead + (rowb + xlo)),
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if (WW > 8 && px_hi < WW)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(vhead + (rowb + xhi)),
+          (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
   }
 }
 
-// one bilinear point of the owner lane -> 4 (weight, LDS byte address, fallback token)
+// Corner descriptors of one bilinear point, in VISITING order: slots 0, 1 = the two x-neighbours
+// of the upper row, slots 2, 3 = of the lower row; inside a row the pair visits first the pixel
+// whose LDS row parity equals its parity role.
 struct PointDesc {
-  float w[4];
-  int a[4];
-  int fb[4];  // global token index of a corner outside the window, -1 otherwise
+  float w[4];  // bilinear weight x attention weight; 0 for a corner outside the map
+  int a[4];    // LDS byte address of the 128-byte row (a zero row if the point is not in LDS)
+  int tok00;   // token of the footprint's upper-left pixel (second pass)
 };
 
-__device__ __forceinline__ void make_point(PointDesc& d, float px, float py, float aw, int H, int W,
-                                           int st, int ox, int oy, int WW, int wbase, int par,
-                                           int zero_even, int zero_odd) {
-  // identical arithmetic to make_corners() of pave_kernels.hip (the direct kernels)
-  const bool inside = (py > -1.f) && (px > -1.f) && (py < (float)H) && (px < (float)W);
-  const float fy = floorf(py), fx = floorf(px);
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + 1, x1 = x0 + 1;
-  const float ly = py - fy, lx = px - fx;
-  const float hy = 1.f - ly, hx = 1.f - lx;
-  const bool y0ok = inside && (y0 >= 0), y1ok = inside && (y1 <= H - 1);
-  const bool x0ok = (x0 >= 0), x1ok = (x1 <= W - 1);
-  float w[4];
-  w[0] = (y0ok && x0ok) ? hy * hx * aw : 0.f;
-  w[1] = (y0ok && x1ok) ? hy * lx * aw : 0.f;
-  w[2] = (y1ok && x0ok) ? ly * hx * aw : 0.f;
-  w[3] = (y1ok && x1ok) ? ly * lx * aw : 0.f;
+__device__ __forceinline__ float div_by(float x, float d, float rd) {
+  // x / d with rd = 1 / d: one residual correction of the product (correctly rounded up to rare
+  // half-way cases), 3 instructions instead of the ~10 of an IEEE division
+  const float q = x * rd;
+  return fmaf(fmaf(-q, d, x), rd, q);
+}
+
+// returns the point's 3 flag bits: 1 = footprint not (entirely) inside the window -> second
+// pass, 2 = upper row visited right-to-left, 4 = lower row visited right-to-left
+__device__ __forceinline__ int make_point(PointDesc& d, float px, float py, float aw, int H, int W,
+                                          int st, int ox, int oy, int WW, int wbase, int zrow,
+                                          int par) {
+  // NaN / Inf-safe clamp: fmaxf / fminf return the non-NaN operand, so a NaN position becomes
+  // -2 (every corner outside the map), exactly what the reference's range test yields
+  px = fminf(fmaxf(px, -2.f), (float)W + 1.f);
+  py = fminf(fmaxf(py, -2.f), (float)H + 1.f);
+  const float fx = floorf(px), fy = floorf(py);
+  const int x0 = (int)fx, y0 = (int)fy;
+  float lx = px - fx, ly = py - fy;
+  float hx = 1.f - lx, hy = 1.f - ly;
+  // corner validity == the reference's (h_im > -1 && w_im > -1 && h_im < H && w_im < W) plus
+  // its per-corner range tests (ms_deform_attn_cuda_kernel.cuh:36-60)
+  hx = (unsigned)x0 < (unsigned)W ? hx : 0.f;
+  lx = (unsigned)(x0 + 1) < (unsigned)W ? lx : 0.f;
+  hy = (unsigned)y0 < (unsigned)H ? hy * aw : 0.f;
+  ly = (unsigned)(y0 + 1) < (unsigned)H ? ly * aw : 0.f;
   const int dx0 = x0 - ox, dy0 = y0 - oy;
-  const int r00 = wbase + __mul24(dy0, WW) + dx0;
-  int a[4], fb[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int dy = dy0 + (c >> 1), dx = dx0 + (c & 1);
-    const int row = wbase + __mul24(dy, WW) + dx;
-    const bool in_win = (unsigned)dy < (unsigned)WW && (unsigned)dx < (unsigned)WW;
-    const bool live = w[c] != 0.f;
-    // the x-neighbours of a footprint have rows of opposite parity; a masked or out-of-window
-    // corner reads the all-zero row of the parity its slot expects
-    const int want_odd = (r00 ^ c ^ ((c >> 1) & WW)) & 1;  // parity `row` would have
-    const int zrow = want_odd ? zero_odd : zero_even;
-    a[c] = ((live && in_win) ? row : zrow) * 128;
-    fb[c] = (live && !in_win) ? st + (y0 + (c >> 1)) * W + (x0 + (c & 1)) : -1;
-  }
-  // visiting order of each x-pair: slot 0 reads the row whose parity equals the pair's role
-  const bool swap = ((r00 ^ par) & 1) != 0;          // top pair (c = 0, 1)
-  const bool swap2 = (((r00 + WW) ^ par) & 1) != 0;  // bottom pair (c = 2, 3)
-  d.w[0] = swap ? w[1] : w[0];
-  d.w[1] = swap ? w[0] : w[1];
-  d.a[0] = swap ? a[1] : a[0];
-  d.a[1] = swap ? a[0] : a[1];
-  d.fb[0] = swap ? fb[1] : fb[0];
-  d.fb[1] = swap ? fb[0] : fb[1];
-  d.w[2] = swap2 ? w[3] : w[2];
-  d.w[3] = swap2 ? w[2] : w[3];
-  d.a[2] = swap2 ? a[3] : a[2];
-  d.a[3] = swap2 ? a[2] : a[3];
-  d.fb[2] = swap2 ? fb[3] : fb[2];
-  d.fb[3] = swap2 ? fb[2] : fb[3];
+  const bool inwin = (unsigned)dx0 < (unsigned)(WW - 1) && (unsigned)dy0 < (unsigned)(WW - 1);
+  // outside the window: the zero rows (zrow even, zrow + 1 odd, "window width" 0)
+  const int r00 = inwin ? wbase + __mul24(dy0, WW) + dx0 : zrow;
+  const int wws = inwin ? WW : 0;
+  const int e = (r00 ^ par) & 1, eb = e ^ (wws & 1);
+  const float xf = e ? lx : hx, xs = e ? hx : lx;
+  const float xfb = eb ? lx : hx, xsb = eb ? hx : lx;
+  d.w[0] = hy * xf;
+  d.w[1] = hy * xs;
+  d.w[2] = ly * xfb;
+  d.w[3] = ly * xsb;
+  const int r10 = r00 + wws;
+  d.a[0] = (r00 + e) << 7;
+  d.a[1] = (r00 + 1 - e) << 7;
+  d.a[2] = (r10 + eb) << 7;
+  d.a[3] = (r10 + 1 - eb) << 7;
+  d.tok00 = st + __mul24(y0, W) + x0;
+  return (inwin ? 0 : 1) | (e << 1) | (eb << 2);
 }
 
 __device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
@@ -198,28 +194,45 @@ __device__ __forceinline__ void gather_level(float4& accA, float4& accB, const c
   }
 }
 
+// second pass: points of level LVL whose footprint is not in the LDS window, straight from global
+// memory, one point (8 x 16-byte loads per lane in flight) at a time
 template <int LVL>
-__device__ __forceinline__ void fallback_level(float4& accA, float4& accB, const char* vlane,
-                                               const PointDesc (&d)[4], int offA, int offB) {
+__device__ __forceinline__ void far_level(float4& accA, float4& accB, const char* vlane,
+                                          const PointDesc (&d)[4], int flags, int W, int S) {
+  const int fl = qbi<LVL>(flags);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int tok = qbi<LVL>(d[i].fb[c]);
-      if (__builtin_amdgcn_ballot_w64(tok >= 0) != 0ull) {
-        const float w = qbf<LVL>(d[i].w[c]);
-        if (tok >= 0) {
-          const char* src = vlane + (size_t)tok * kRowBytes;
-          fma4(accA, w, *reinterpret_cast<const float4*>(src + offA));
-          fma4(accB, w, *reinterpret_cast<const float4*>(src + offB));
-        }
-      }
+    const int f = fl >> (3 * i);
+    if (__builtin_amdgcn_ballot_w64((f & 1) != 0) == 0ull) continue;
+    const int t00 = qbi<LVL>(d[i].tok00);
+    const float w0 = qbf<LVL>(d[i].w[0]), w1 = qbf<LVL>(d[i].w[1]), w2 = qbf<LVL>(d[i].w[2]),
+                w3 = qbf<LVL>(d[i].w[3]);
+    if (f & 1) {
+      const int e = (f >> 1) & 1, eb = (f >> 2) & 1;
+      // a corner outside the map has weight 0 and may have any token: clamp, never mask by value
+      const int t0 = min(max(t00 + e, 0), S - 1), t1 = min(max(t00 + 1 - e, 0), S - 1);
+      const int t2 = min(max(t00 + W + eb, 0), S - 1), t3 = min(max(t00 + W + 1 - eb, 0), S - 1);
+      const float4* r0 = reinterpret_cast<const float4*>(vlane + (size_t)t0 * kRowBytes);
+      const float4* r1 = reinterpret_cast<const float4*>(vlane + (size_t)t1 * kRowBytes);
+      const float4* r2 = reinterpret_cast<const float4*>(vlane + (size_t)t2 * kRowBytes);
+      const float4* r3 = reinterpret_cast<const float4*>(vlane + (size_t)t3 * kRowBytes);
+      const float4 a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+      const float4 a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
+      fma4(accA, w0, a0);
+      fma4(accB, w0, b0);
+      fma4(accA, w1, a1);
+      fma4(accB, w1, b1);
+      fma4(accA, w2, a2);
+      fma4(accB, w2, b2);
+      fma4(accA, w3, a3);
+      fma4(accB, w3, b3);
     }
   }
 }
 
 // TILE = 8: 64 + 16 + 4 + 1 = 85 queries -> 96 pair slots = 6 waves of 16 pairs
-template <int W0, int W1, int W2, int W3, int MB0, int MB1, int MB2, int MB3, int WPE>
+// ABL: timing-only ablations for tools/ (1: no window staging, 2: no gather loop); 0 in the product
+template <int W0, int W1, int W2, int W3, int MB0, int MB1, int MB2, int MB3, int WPE, int ABL = 0>
 __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) {
   using G = WinGeom<W0, W1, W2, W3>;
   constexpr int kWaves = 6;
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const int k = lane & 3;       // level whose points this lane prepares; channel octet it owns
   const int pr = lane >> 2;     // pair within the wave
   const int par = (pr >> 1) & 1, setr = (pr >> 2) & 1;  // bank roles (see header)
+  // second pass reads chunks in memory order: accA always holds the chunk at offA
   const int offA = k * 32 + setr * 16, offB = k * 32 + (setr ^ 1) * 16;
 
   const int lb = xcd_remap(blockIdx.x, p.n_blocks);
@@ -238,107 +252,115 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const int tile = (lb >> 3) % tiles, frame = (lb >> 3) / tiles;
   const int ty = tile / p.nx, tx = tile - ty * p.nx;
 
-  // ---- which query this pair is (slot -> level, position inside the tile)
-  const int slot = wave * 16 + pr;
-  int ql, qy, qx;
-  if (slot < 64) {
-    ql = 0, qy = ty * 8 + (slot >> 3), qx = tx * 8 + (slot & 7);
-  } else if (slot < 80) {
-    ql = 1, qy = ty * 4 + ((slot - 64) >> 2), qx = tx * 4 + ((slot - 64) & 3);
-  } else if (slot < 84) {
-    ql = 2, qy = ty * 2 + ((slot - 80) >> 1), qx = tx * 2 + ((slot - 80) & 1);
+  // ---- which query this pair is: waves 0-3 level 0, wave 4 level 1, wave 5 levels 2, 3
+  int qy, qx, qH, qW, qS;
+  bool valid = true;
+  if (wave < 4) {
+    qy = ty * 8 + wave * 2 + (pr >> 3), qx = tx * 8 + (pr & 7);
+    qH = p.Hs[0], qW = p.Ws[0], qS = p.St[0];
+  } else if (wave == 4) {
+    qy = ty * 4 + (pr >> 2), qx = tx * 4 + (pr & 3);
+    qH = p.Hs[1], qW = p.Ws[1], qS = p.St[1];
   } else {
-    ql = 3, qy = ty, qx = tx;
+    const bool l2 = pr < 4;
+    qy = l2 ? ty * 2 + (pr >> 1) : ty, qx = l2 ? tx * 2 + (pr & 1) : tx;
+    qH = l2 ? p.Hs[2] : p.Hs[3], qW = l2 ? p.Ws[2] : p.Ws[3], qS = l2 ? p.St[2] : p.St[3];
+    valid = pr < 5;
   }
-  const int qH = ql == 0 ? p.Hs[0] : ql == 1 ? p.Hs[1] : ql == 2 ? p.Hs[2] : p.Hs[3];
-  const int qW = ql == 0 ? p.Ws[0] : ql == 1 ? p.Ws[1] : ql == 2 ? p.Ws[2] : p.Ws[3];
-  const int qS = ql == 0 ? p.St[0] : ql == 1 ? p.St[1] : ql == 2 ? p.St[2] : p.St[3];
-  const bool valid = slot < 85 && qy < qH && qx < qW;
-  const long long fbase = (long long)frame * p.S;
-  const long long unit = fbase + (valid ? qS + qy * qW + qx : 0);
+  valid = valid && qy < qH && qx < qW;
+  const unsigned ubase = (unsigned)frame * (unsigned)p.S;
+  const unsigned unit = ubase + (valid ? (unsigned)(qS + qy * qW + qx) : 0u);
+
+  // ---- projections of (unit, head, level k): 4 offset pairs + 4 logits, reference point
+  const float* row = p.proj + (size_t)unit * (unsigned)p.proj_stride + head * 32 + k * 8;
+  const float4 of01 = *reinterpret_cast<const float4*>(row);
+  const float4 of23 = *reinterpret_cast<const float4*>(row + 4);
+  const float4 lg = *reinterpret_cast<const float4*>(row + (kHeads - head) * 32 + head * 16 - k * 4);
+  const float2 rf = *reinterpret_cast<const float2*>(p.ref + (size_t)unit * 8 + k * 2);
+
+  // ---- stage the four windows (LDS-DMA) and the two zero rows
+  const int ox0 = tx * 8 - MB0, oy0 = ty * 8 - MB0, ox1 = tx * 4 - MB1, oy1 = ty * 4 - MB1;
+  const int ox2 = tx * 2 - MB2, oy2 = ty * 2 - MB2, ox3 = tx - MB3, oy3 = ty - MB3;
+  const char* vhead = reinterpret_cast<const char*>(p.value) + (size_t)ubase * kRowBytes + head * 128;
+  if (!(ABL & 1)) {
+    stage_level<W0, kWaves>(lds + G::B0 * 128, vhead, wave, lane, ox0, oy0, p.Hs[0], p.Ws[0], p.St[0]);
+    stage_level<W1, kWaves>(lds + G::B1 * 128, vhead, wave, lane, ox1, oy1, p.Hs[1], p.Ws[1], p.St[1]);
+    stage_level<W2, kWaves>(lds + G::B2 * 128, vhead, wave, lane, ox2, oy2, p.Hs[2], p.Ws[2], p.St[2]);
+    stage_level<W3, kWaves>(lds + G::B3 * 128, vhead, wave, lane, ox3, oy3, p.Hs[3], p.Ws[3], p.St[3]);
+  }
+  if (threadIdx.x < 64) reinterpret_cast<float*>(lds + G::kZ * 128)[threadIdx.x] = 0.f;
 
   // ---- my level's constants (lane k <-> level k)
   const int H = k == 0 ? p.Hs[0] : k == 1 ? p.Hs[1] : k == 2 ? p.Hs[2] : p.Hs[3];
   const int W = k == 0 ? p.Ws[0] : k == 1 ? p.Ws[1] : k == 2 ? p.Ws[2] : p.Ws[3];
   const int st = k == 0 ? p.St[0] : k == 1 ? p.St[1] : k == 2 ? p.St[2] : p.St[3];
-  const int ox0 = tx * 8 - MB0, oy0 = ty * 8 - MB0, ox1 = tx * 4 - MB1, oy1 = ty * 4 - MB1;
-  const int ox2 = tx * 2 - MB2, oy2 = ty * 2 - MB2, ox3 = tx - MB3, oy3 = ty - MB3;
   const int ox = k == 0 ? ox0 : k == 1 ? ox1 : k == 2 ? ox2 : ox3;
   const int oy = k == 0 ? oy0 : k == 1 ? oy1 : k == 2 ? oy2 : oy3;
   const int wbase = k == 0 ? G::B0 : k == 1 ? G::B1 : k == 2 ? G::B2 : G::B3;
   const int ww = k == 0 ? W0 : k == 1 ? W1 : k == 2 ? W2 : W3;
-
-  // ---- projections of (unit, head, level k): 4 offsets pairs + 4 logits, reference point
-  const float* row = p.proj + unit * p.proj_stride;
-  const float4 of01 = *reinterpret_cast<const float4*>(row + head * 32 + k * 8);
-  const float4 of23 = *reinterpret_cast<const float4*>(row + head * 32 + k * 8 + 4);
-  const float4 lg = *reinterpret_cast<const float4*>(row + kHeads * 32 + head * 16 + k * 4);
-  const float2 rf = *reinterpret_cast<const float2*>(p.ref + unit * 8 + k * 2);
-
-  // ---- stage the four windows (LDS-DMA) and the two zero rows
-  const char* vframe = reinterpret_cast<const char*>(p.value) + fbase * kRowBytes;
-  const char* vhead = vframe + head * 128;
-  stage_level<W0, G::R0, kWaves>(lds + G::B0 * 128, vhead, wave, lane, ox0, oy0, p.Hs[0], p.Ws[0], p.St[0]);
-  stage_level<W1, G::R1, kWaves>(lds + G::B1 * 128, vhead, wave, lane, ox1, oy1, p.Hs[1], p.Ws[1], p.St[1]);
-  stage_level<W2, G::R2, kWaves>(lds + G::B2 * 128, vhead, wave, lane, ox2, oy2, p.Hs[2], p.Ws[2], p.St[2]);
-  stage_level<W3, G::R3, kWaves>(lds + G::B3 * 128, vhead, wave, lane, ox3, oy3, p.Hs[3], p.Ws[3], p.St[3]);
-  if (threadIdx.x < 64) {
-    reinterpret_cast<float*>(lds + G::kZeroEven * 128)[threadIdx.x & 31] = 0.f;
-    reinterpret_cast<float*>(lds + G::kZeroOdd * 128)[threadIdx.x & 31] = 0.f;
-  }
+  const float fW = (float)W, fH = (float)H;
+  const float rW = 1.f / fW, rH = 1.f / fH;
 
   // ---- softmax over the 16 logits of (unit, head): 4 per lane, quad reduction
   const float mx = quad_max(fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w)));
-  const float e0 = expf(lg.x - mx), e1 = expf(lg.y - mx), e2 = expf(lg.z - mx),
-              e3 = expf(lg.w - mx);
-  const float inv_sum = 1.f / quad_sum((e0 + e1) + (e2 + e3));
+  const float e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx), e2 = __expf(lg.z - mx),
+              e3 = __expf(lg.w - mx);
+  float inv_sum = 1.f / quad_sum((e0 + e1) + (e2 + e3));
+  if (!valid) inv_sum = 0.f;  // idle slots carry weight 0 through the DPP steps
 
   // ---- corner descriptors of my 4 points
   PointDesc d[4];
+  int flags = 0;
   {
-    const float fW = (float)W, fH = (float)H;
     const float ofx[4] = {of01.x, of01.z, of23.x, of23.z}, ofy[4] = {of01.y, of01.w, of23.y, of23.w};
     const float ee[4] = {e0, e1, e2, e3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float lx = rf.x + ofx[i] / fW, ly = rf.y + ofy[i] / fH;  // MO:381-384
-      const float px = lx * fW - 0.5f, py = ly * fH - 0.5f;           // cuda_kernel.cuh:233-234
-      make_point(d[i], px, py, ee[i] * inv_sum, H, W, st, ox, oy, ww, wbase, par, G::kZeroEven,
-                 G::kZeroOdd);
+      const float lx = rf.x + div_by(ofx[i], fW, rW), ly = rf.y + div_by(ofy[i], fH, rH);  // MO:381-384
+      const float px = lx * fW - 0.5f, py = ly * fH - 0.5f;  // cuda_kernel.cuh:233-234
+      flags |= make_point(d[i], px, py, ee[i] * inv_sum, H, W, st, ox, oy, ww, wbase, G::kZ, par)
+               << (3 * i);
     }
   }
-  bool any_fb = false;
+  if (!valid) flags &= ~0x249;  // no second pass for idle slots
+  const bool any_far = (flags & 0x249) != 0;
+  // descriptors are final here: keep hipcc from sinking their arithmetic into the gather loop
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) any_fb |= d[i].fb[c] >= 0;
-  if (!valid) {  // idle slots: weights 0 on the zero rows (they still take part in the DPP steps)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        d[i].w[c] = 0.f;
-        d[i].fb[c] = -1;
-      }
-    any_fb = false;
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(d[i].w[c]), "+v"(d[i].a[c]));
+    asm volatile("" : "+v"(d[i].tok00));
   }
+  asm volatile("" : "+v"(flags));
   __syncthreads();  // (emits s_waitcnt vmcnt(0): the windows have landed)
 
   float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-  gather_level<0>(accA, accB, lds, d, offA, offB);
-  gather_level<1>(accA, accB, lds, d, offA, offB);
-  gather_level<2>(accA, accB, lds, d, offA, offB);
-  gather_level<3>(accA, accB, lds, d, offA, offB);
+  if (!(ABL & 2)) {
+    gather_level<0>(accA, accB, lds, d, offA, offB);
+    gather_level<1>(accA, accB, lds, d, offA, offB);
+    gather_level<2>(accA, accB, lds, d, offA, offB);
+    gather_level<3>(accA, accB, lds, d, offA, offB);
+  } else {  // keep the descriptors alive
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accA.x += d[i].w[c] + __int_as_float(d[i].a[c]);
+  }
 
-  if (__builtin_amdgcn_ballot_w64(any_fb) != 0ull) {  // rare with trained-size offsets
-    const char* vlane = vhead;
-    fallback_level<0>(accA, accB, vlane, d, offA, offB);
-    fallback_level<1>(accA, accB, vlane, d, offA, offB);
-    fallback_level<2>(accA, accB, vlane, d, offA, offB);
-    fallback_level<3>(accA, accB, vlane, d, offA, offB);
+  if (__builtin_amdgcn_ballot_w64(any_far) != 0ull) {  // rare with trained-size offsets
+    // memory order inside the lane's 32 bytes: chunk 2k (flo), then 2k + 1 (fhi)
+    float4 flo = make_float4(0.f, 0.f, 0.f, 0.f), fhi = flo;
+    const char* vlane = vhead + k * 32;
+    far_level<0>(flo, fhi, vlane, d, flags, p.Ws[0], p.S);
+    far_level<1>(flo, fhi, vlane, d, flags, p.Ws[1], p.S);
+    far_level<2>(flo, fhi, vlane, d, flags, p.Ws[2], p.S);
+    far_level<3>(flo, fhi, vlane, d, flags, p.Ws[3], p.S);
+    const float4 fa = setr ? fhi : flo, fb = setr ? flo : fhi;  // accA holds the chunk at offA
+    accA.x += fa.x, accA.y += fa.y, accA.z += fa.z, accA.w += fa.w;
+    accB.x += fb.x, accB.y += fb.y, accB.z += fb.z, accB.w += fb.w;
   }
   if (valid) {
-    char* o = reinterpret_cast<char*>(p.out + unit * 256 + head * 32);
+    char* o = reinterpret_cast<char*>(p.out + (size_t)unit * 256 + head * 32);
     *reinterpret_cast<float4*>(o + offA) = accA;
     *reinterpret_cast<float4*>(o + offB) = accB;
   }
@@ -346,10 +368,10 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
 
 }  // namespace
 
-extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* proj,
-                                              const float* ref, float* out, int n_frames, int S,
-                                              const int* levels_hw, int proj_stride, int variant,
-                                              void* stream) {
+template <int ABL>
+static int enc_tile_launch(const float* value, const float* proj, const float* ref, float* out,
+                           int n_frames, int S, const int* levels_hw, int proj_stride, int variant,
+                           void* stream) {
   if (!value || !proj || !ref || !out || !levels_hw)
     return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: null pointer");
   if (n_frames <= 0 || S <= 0) return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: sizes must be positive");
@@ -385,11 +407,32 @@ extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* pr
   p.n_blocks = (int)nb;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (variant == 1) {  // +-4 px windows, 2 workgroups per CU
-    hipLaunchKernelGGL((enc_tile_kernel<16, 12, 10, 9, 4, 4, 4, 4, 1>), dim3((unsigned)nb), dim3(384), 0, st, p);
+    hipLaunchKernelGGL((enc_tile_kernel<16, 12, 10, 9, 4, 4, 4, 4, 1, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   } else {             // -4 .. +3 px windows (52 KB), 3 workgroups per CU
-    hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 1>), dim3((unsigned)nb), dim3(384), 0, st, p);
+    hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
+}
+
+extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* proj,
+                                              const float* ref, float* out, int n_frames, int S,
+                                              const int* levels_hw, int proj_stride, int variant,
+                                              void* stream) {
+  return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant,
+                            stream);
+}
+
+// Timing-only ablations for tools/bench_kernels.py (not part of the C ABI, outputs are wrong):
+// ablate 1 = no window staging, 2 = no gather loop, 3 = neither.
+extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, const float* ref,
+                                         float* out, int n_frames, int S, const int* levels_hw,
+                                         int proj_stride, int variant, int ablate, void* stream) {
+  switch (ablate) {
+    case 1: return enc_tile_launch<1>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
+    case 2: return enc_tile_launch<2>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
+    case 3: return enc_tile_launch<3>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
+    default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
+  }
 }

@@ -671,282 +671,6 @@ __global__ __launch_bounds__(256) void bias_add_layernorm_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Encoder deformable attention with an LDS-staged value window (level-0 queries).
-//
-// The direct kernel above is bound by the texture-address / L1 path: 64 corner rows x 128 B
-// per (query, head) = 1.46 GB of gather requests per frame-layer at ~40 B/clk/CU, 18x the
-// algorithmic bytes (profiles/r01_pmc_sampling_kernels_7frames.txt: TA_BUSY 83-94 %).
-// Queries sample around their own position on every level, so a TILE x TILE tile of level-0
-// queries touches, per head, only a small window of each level's map.  One workgroup =
-// (frame, tile, head): it stages the four windows (W0^2 + W1^2 + W2^2 + W3^2 rows of 128 B,
-// ~61 KB, two workgroups per CU) from HBM/L2 into LDS with coalesced 16-byte loads, then
-// serves every in-window corner from LDS (256 B/clk/CU) and only the rare out-of-window
-// corner from global memory, so results never depend on the window size.
-// Lane layout inside a wave: 8 queries x 8 lanes x float4 (one head's 32 channels).
-// ---------------------------------------------------------------------------
-struct WinParams {
-  const float* value;
-  const int64_t* shapes;
-  const int64_t* lsi;
-  const float* proj;
-  const float* ref;  // [n_units, 4, 2]
-  float* out;
-  int S;
-  int proj_stride;
-  int tiles_x;
-  int tiles_y;
-  int n_blocks;
-  int Hs[4], Ws[4], St[4];  // host copy of the level table: no dependent loads in the prologue
-  int grid_ref;             // 1: every reference point is the query's own pixel centre
-};
-
-// loads of one level's window rows (issued first, stored to LDS later so that every load of
-// the block is in flight before the first wait)
-template <int WW, int N, int RPP>
-__device__ __forceinline__ void win_load(float4 (&v)[N], const char* vframe, int tid8, int ox,
-                                         int oy, int H, int W, int st) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int r = tid8 + k * RPP;
-    const int wy = r / WW, wx = r - wy * WW;  // WW is a compile-time constant
-    const int x = ox + wx, y = oy + wy;
-    const bool ok = (r < WW * WW) && x >= 0 && x < W && y >= 0 && y < H;
-    // out-of-map rows are staged as zeros: a masked corner (weight 0) may point anywhere
-    v[k] = ok ? ld16(vframe, (unsigned)((st + y * W + x) * (kRowFloats * 4)))
-              : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-
-template <int WW, int N, int RPP>
-__device__ __forceinline__ void win_store(const float4 (&v)[N], float* win, int rbase, int tid8,
-                                          int j) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int r = tid8 + k * RPP;
-    if (r < WW * WW) *reinterpret_cast<float4*>(win + (rbase + r) * 32 + j * 4) = v[k];
-  }
-}
-
-// Broadcast of lane JJ's value to the 8 lanes of its group on the VALU (2 DPP moves + 1 select),
-// not through the LDS crossbar: ds_bpermute costs ~9 LDS cycles per wave instruction on the
-// pipe all four SIMDs share, which made the exchange 65 % of the LDS time.
-template <int JJ>
-__device__ __forceinline__ int bcast8(int x, bool hi) {
-  constexpr int q = JJ & 3;
-  const int t = __builtin_amdgcn_update_dpp(x, x, q * 0x55, 0xf, 0xf, false);  // quad_perm[q,q,q,q]
-  if constexpr (JJ < 4) {
-    const int u = __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xf, false);   // row_shr:4
-    return hi ? u : t;
-  } else {
-    const int u = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0xf, false);   // row_shl:4
-    return hi ? t : u;
-  }
-}
-
-template <int JJ>
-__device__ __forceinline__ void win_gather_pair(float4& acc, const char* wbytes,
-                                                const float (&dw)[2][4],
-                                                const unsigned (&pk)[2][2], bool hi) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const float w0 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][0]), hi));
-    const float w1 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][1]), hi));
-    const float w2 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][2]), hi));
-    const float w3 = __int_as_float(bcast8<JJ>(__float_as_int(dw[s][3]), hi));
-    const unsigned p0 = (unsigned)bcast8<JJ>((int)pk[s][0], hi);
-    const unsigned p1 = (unsigned)bcast8<JJ>((int)pk[s][1], hi);
-    const float4 v0 = *reinterpret_cast<const float4*>(wbytes + (p0 & 0xffffu));
-    const float4 v1 = *reinterpret_cast<const float4*>(wbytes + (p0 >> 16));
-    const float4 v2 = *reinterpret_cast<const float4*>(wbytes + (p1 & 0xffffu));
-    const float4 v3 = *reinterpret_cast<const float4*>(wbytes + (p1 >> 16));
-    fma4(acc, w0, v0);
-    fma4(acc, w1, v1);
-    fma4(acc, w2, v2);
-    fma4(acc, w3, v3);
-  }
-}
-
-// 512 threads = 8 waves x (8 queries x 8 lanes); LDS holds only the window (61 KB), so two
-// workgroups (16 waves) share a CU.  Each lane prepares the corner descriptors of its 2 points
-// and the 8 lanes of a query exchange them with DPP moves (no LDS storage, no LDS traffic).
-template <int TILE, int W0, int W1, int W2, int W3>
-__global__ __launch_bounds__(512, 4) void enc_window_kernel(const WinParams p) {
-  static_assert(TILE * TILE == 64, "8 waves x 8 queries");
-  constexpr int kR0 = W0 * W0, kR1 = W1 * W1, kR2 = W2 * W2, kR3 = W3 * W3;
-  constexpr int kRows = kR0 + kR1 + kR2 + kR3;
-  static_assert(kRows * 128 < 65536, "window byte offsets are packed into 16 bits");
-  __shared__ __attribute__((aligned(16))) float win[kRows * 32];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 3, j = lane & 7;
-  const int lb = xcd_remap(blockIdx.x, p.n_blocks);
-  const int head = lb & 7;
-  const int tiles = p.tiles_x * p.tiles_y;
-  const int tile = (lb >> 3) % tiles;
-  const int frame = (lb >> 3) / tiles;
-  const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-
-  int Hs[4], Ws[4], St[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    Hs[q] = p.Hs[q];
-    Ws[q] = p.Ws[q];
-    St[q] = p.St[q];
-  }
-  const int qx0 = tx * TILE, qy0 = ty * TILE;
-  const int qx1 = min(qx0 + TILE, Ws[0]) - 1, qy1 = min(qy0 + TILE, Hs[0]) - 1;
-  const long long ubase = (long long)frame * p.S;
-
-  // ---- this lane's query: projection row / reference point (issued before the staging loads)
-  // lane j: points 2j, 2j+1 of this head -> both on level l = j >> 1
-  const int l = j >> 1;
-  const int qi = wave * 8 + g;
-  const int qy = qy0 + qi / TILE, qx = qx0 + qi % TILE;
-  const bool valid = (qy < Hs[0]) && (qx < Ws[0]);
-  const long long unit = ubase + (valid ? (long long)qy * Ws[0] + qx : 0);
-  const float* row = p.proj + unit * p.proj_stride;
-  const float4 off = *reinterpret_cast<const float4*>(row + head * 32 + 4 * j);
-  const float2 lgt = *reinterpret_cast<const float2*>(row + 256 + head * 16 + 2 * j);
-  const float2 rf = *reinterpret_cast<const float2*>(p.ref + unit * 8 + 2 * l);
-
-  // window origin per level, from the reference points of the tile's corner queries
-  int ox[4], oy[4];
-  {
-    float r0[8], r1[8];
-    if (p.grid_ref) {  // un-padded frames: ref = own pixel centre on every level, no loads
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        r0[2 * q] = ((float)qx0 + 0.5f) / (float)Ws[0];
-        r0[2 * q + 1] = ((float)qy0 + 0.5f) / (float)Hs[0];
-        r1[2 * q] = ((float)qx1 + 0.5f) / (float)Ws[0];
-        r1[2 * q + 1] = ((float)qy1 + 0.5f) / (float)Hs[0];
-      }
-    } else {
-      const float* g0 = p.ref + (ubase + (long long)qy0 * Ws[0] + qx0) * 8;
-      const float* g1 = p.ref + (ubase + (long long)qy1 * Ws[0] + qx1) * 8;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        r0[q] = g0[q];
-        r1[q] = g1[q];
-      }
-    }
-    constexpr int WWs[4] = {W0, W1, W2, W3};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int xa = (int)floorf(r0[2 * q] * Ws[q] - 0.5f), xb = (int)floorf(r1[2 * q] * Ws[q] - 0.5f);
-      const int ya = (int)floorf(r0[2 * q + 1] * Hs[q] - 0.5f),
-                yb = (int)floorf(r1[2 * q + 1] * Hs[q] - 0.5f);
-      ox[q] = xa - max(0, (WWs[q] - (xb - xa + 2)) >> 1);
-      oy[q] = ya - max(0, (WWs[q] - (yb - ya + 2)) >> 1);
-    }
-  }
-
-  // ---- stage the four windows: one 128-byte row per 8 lanes, all loads before all stores
-  const char* vframe = reinterpret_cast<const char*>(p.value) + ubase * (kRowFloats * 4) +
-                       head * (kDim * 4) + j * 16;
-  {
-    const int tid8 = threadIdx.x >> 3;  // 0..63
-    constexpr int N0 = (kR0 + 63) / 64, N1 = (kR1 + 63) / 64, N2 = (kR2 + 63) / 64,
-                  N3 = (kR3 + 63) / 64;
-    float4 v0[N0], v1[N1], v2[N2], v3[N3];
-    win_load<W0, N0, 64>(v0, vframe, tid8, ox[0], oy[0], Hs[0], Ws[0], St[0]);
-    win_load<W1, N1, 64>(v1, vframe, tid8, ox[1], oy[1], Hs[1], Ws[1], St[1]);
-    win_load<W2, N2, 64>(v2, vframe, tid8, ox[2], oy[2], Hs[2], Ws[2], St[2]);
-    win_load<W3, N3, 64>(v3, vframe, tid8, ox[3], oy[3], Hs[3], Ws[3], St[3]);
-    win_store<W0, N0, 64>(v0, win, 0, tid8, j);
-    win_store<W1, N1, 64>(v1, win, kR0, tid8, j);
-    win_store<W2, N2, 64>(v2, win, kR0 + kR1, tid8, j);
-    win_store<W3, N3, 64>(v3, win, kR0 + kR1 + kR2, tid8, j);
-  }
-
-  // ---- descriptors of my two points (overlaps the staging loads' latency)
-  const int H = l == 0 ? Hs[0] : l == 1 ? Hs[1] : l == 2 ? Hs[2] : Hs[3];
-  const int W = l == 0 ? Ws[0] : l == 1 ? Ws[1] : l == 2 ? Ws[2] : Ws[3];
-  const int st = l == 0 ? St[0] : l == 1 ? St[1] : l == 2 ? St[2] : St[3];
-  const int wox = l == 0 ? ox[0] : l == 1 ? ox[1] : l == 2 ? ox[2] : ox[3];
-  const int woy = l == 0 ? oy[0] : l == 1 ? oy[1] : l == 2 ? oy[2] : oy[3];
-  const int ww = l == 0 ? W0 : l == 1 ? W1 : l == 2 ? W2 : W3;
-  const int wbase = l == 0 ? 0 : l == 1 ? kR0 : l == 2 ? kR0 + kR1 : kR0 + kR1 + kR2;
-  const float mx = group8_max(fmaxf(lgt.x, lgt.y));
-  const float e0 = expf(lgt.x - mx), e1 = expf(lgt.y - mx);
-  const float inv = 1.f / group8_sum(e0 + e1);
-  float dw[2][4];
-  unsigned dofs[2][4];
-  bool my_fb = false;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const float ofx = s == 0 ? off.x : off.z, ofy = s == 0 ? off.y : off.w;
-    const float aw = (s == 0 ? e0 : e1) * inv;
-    const float px = (rf.x + ofx / (float)W) * (float)W - 0.5f;
-    const float py = (rf.y + ofy / (float)H) * (float)H - 0.5f;
-    const bool inside = (py > -1.f) && (px > -1.f) && (py < (float)H) && (px < (float)W);
-    const float fy = floorf(py), fx = floorf(px);
-    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-    const bool y0ok = inside && (y0 >= 0), y1ok = inside && (y1 <= H - 1);
-    const bool x0ok = (x0 >= 0), x1ok = (x1 <= W - 1);
-    dw[s][0] = (y0ok && x0ok) ? hy * hx * aw : 0.f;
-    dw[s][1] = (y0ok && x1ok) ? hy * lx * aw : 0.f;
-    dw[s][2] = (y1ok && x0ok) ? ly * hx * aw : 0.f;
-    dw[s][3] = (y1ok && x1ok) ? ly * lx * aw : 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int cy = (c < 2) ? y0 : y1, cx = (c & 1) ? x1 : x0;
-      const int dy = cy - woy, dx = cx - wox;
-      if (dw[s][c] == 0.f) {
-        dofs[s][c] = 0u;  // masked corner: weight 0 on a staged (finite) row
-      } else if (dy >= 0 && dy < ww && dx >= 0 && dx < ww) {
-        dofs[s][c] = (unsigned)((wbase + dy * ww + dx) * 128);
-      } else {
-        dofs[s][c] = 0x80000000u | (unsigned)(st + cy * W + cx);  // global fallback: token
-        my_fb = true;
-      }
-    }
-  }
-  const bool wave_fb = __builtin_amdgcn_ballot_w64(my_fb) != 0ull;
-  // in-window offsets fit 16 bits: two per register on the common path
-  const unsigned pk[2][2] = {{dofs[0][0] | (dofs[0][1] << 16), dofs[0][2] | (dofs[0][3] << 16)},
-                             {dofs[1][0] | (dofs[1][1] << 16), dofs[1][2] | (dofs[1][3] << 16)}};
-  __syncthreads();  // windows staged
-
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const char* wbytes = reinterpret_cast<const char*>(win) + j * 16;
-  const int gbase = lane & 56;
-  if (!wave_fb) {
-    const bool hi = (lane & 4) != 0;
-    win_gather_pair<0>(acc, wbytes, dw, pk, hi);  // points 0, 1 (from lane 0 of the group)
-    win_gather_pair<1>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<2>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<3>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<4>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<5>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<6>(acc, wbytes, dw, pk, hi);
-    win_gather_pair<7>(acc, wbytes, dw, pk, hi);
-  } else {  // some corner of this wave lies outside its window: unpacked descriptors
-#pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {
-      const int src = gbase | jj;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float wc = __shfl(dw[s][c], src);
-          const unsigned oc = (unsigned)__shfl((int)dofs[s][c], src);
-          float4 v;
-          if (oc & 0x80000000u) {
-            v = ld16(vframe, (oc & 0x7fffffffu) * (unsigned)(kRowFloats * 4));
-          } else {
-            v = *reinterpret_cast<const float4*>(wbytes + oc);
-          }
-          fma4(acc, wc, v);
-        }
-      }
-    }
-  }
-  if (valid) *reinterpret_cast<float4*>(p.out + unit * kRowFloats + head * kDim + j * 4) = acc;
-}
-
-// ---------------------------------------------------------------------------
 // Encoder (GRID, T = 1), head-major work split.  The kernel above gives a wave ONE query and all
 // 8 heads: its 64 corner rows per point set lie in 8 different 128-byte head rows per pixel, so
 // the ~32 queries resident on a CU touch ~100 KB of value rows -- three times the 32-KB L1
@@ -1600,7 +1324,7 @@ int pave_internal_fail(int code, const char* msg) { return fail(code, msg); }
 
 extern "C" {
 
-int pave_abi_version(void) { return 1; }
+int pave_abi_version(void) { return PAVE_ABI_VERSION; }
 const char* pave_last_error(void) { return g_err; }
 
 int pave_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
@@ -1775,78 +1499,6 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
 #undef PAVE_LN
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  return PAVE_OK;
-}
-
-int pave_enc_deform_attn_window_f32(const float* value, const int64_t* spatial_shapes,
-                                    const int64_t* level_start, const float* proj,
-                                    const float* ref, const int32_t* rest_order, float* out,
-                                    int n_frames, int S, const int* levels_hw, int grid_ref,
-                                    int n_rest, int proj_stride, void* stream) {
-  if (!levels_hw) return fail(PAVE_E_ARG, "enc_deform_attn_window: levels_hw missing");
-  const int H0 = levels_hw[0], W0 = levels_hw[1];
-  if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
-    return fail(PAVE_E_ARG, "enc_deform_attn_window: null pointer");
-  if (n_frames <= 0 || S <= 0 || H0 <= 0 || W0 <= 0 || n_rest < 0)
-    return fail(PAVE_E_ARG, "enc_deform_attn_window: sizes must be positive");
-  if ((long long)H0 * W0 > S) return fail(PAVE_E_ARG, "enc_deform_attn_window: H0*W0 > S");
-  if (n_rest > 0 && !rest_order)
-    return fail(PAVE_E_ARG, "enc_deform_attn_window: rest_order missing");
-  if (proj_stride < kHeads * 16 * 3)
-    return fail(PAVE_E_ARG, "enc_deform_attn_window: proj_stride too small");
-  if ((long long)S * kRowFloats * 4 >= (1ll << 31))
-    return fail(PAVE_E_ARG, "enc_deform_attn_window: one value slab must be < 2 GiB");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  constexpr int kTile = 8;
-  WinParams w{};
-  w.value = value;
-  w.shapes = spatial_shapes;
-  w.lsi = level_start;
-  w.proj = proj;
-  w.ref = ref;
-  w.out = out;
-  w.S = S;
-  w.proj_stride = proj_stride;
-  w.tiles_x = (W0 + kTile - 1) / kTile;
-  w.tiles_y = (H0 + kTile - 1) / kTile;
-  w.grid_ref = grid_ref ? 1 : 0;
-  {
-    long long start = 0;
-    for (int l = 0; l < 4; ++l) {
-      if (levels_hw[2 * l] <= 0 || levels_hw[2 * l + 1] <= 0)
-        return fail(PAVE_E_ARG, "enc_deform_attn_window: bad level size");
-      w.Hs[l] = levels_hw[2 * l];
-      w.Ws[l] = levels_hw[2 * l + 1];
-      w.St[l] = (int)start;
-      start += (long long)w.Hs[l] * w.Ws[l];
-    }
-    if (start != S) return fail(PAVE_E_ARG, "enc_deform_attn_window: levels do not add up to S");
-  }
-  const long long nb = (long long)n_frames * w.tiles_x * w.tiles_y * kHeads;
-  if (nb >= (1ll << 31)) return fail(PAVE_E_ARG, "enc_deform_attn_window: grid too large");
-  w.n_blocks = (int)nb;
-  hipLaunchKernelGGL((enc_window_kernel<kTile, 15, 11, 9, 8>), dim3((unsigned)nb), dim3(512), 0,
-                     st, w);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  if (n_rest > 0) {  // queries of the coarser levels: direct-gather kernel on the listed units
-    FusedParams p{};
-    p.value = value;
-    p.shapes = spatial_shapes;
-    p.lsi = level_start;
-    p.proj = proj;
-    p.ref = ref;
-    p.order = rest_order;
-    p.out = out;
-    p.n_units = n_rest;
-    p.units_per_clip = S;
-    p.T = 1;
-    p.S = S;
-    p.L = 4;
-    p.P = 4;
-    p.proj_stride = proj_stride;
-    return launch_fused<kGrid, 2, 1>(p, st);
-  }
   return PAVE_OK;
 }
 

@@ -168,14 +168,13 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             if not ref.is_contiguous():
                 ref = ref.contiguous()
             clip_index = kwargs.get('memory_clip_index')
-            plan = kwargs.get('window_plan')
+            tile_levels = kwargs.get('tile_levels')
             unit_clip = None
             if clip_index is not None:  # queries of pose n read the memory of image clip_index[n]
                 unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
-            if plan is not None and clip_index is None and num_query == num_value:
-                out = ops.deform_attn_enc_window(v, spatial_shapes, level_start_index, proj, ref,
-                                                 levels_hw=plan[0], rest_order=plan[1],
-                                                 grid_ref=plan[2])
+            if tile_levels is not None and clip_index is None and num_query == num_value:
+                # encoder self-attention over a halving pyramid: LDS-tile kernel
+                out = ops.deform_attn_enc_tile(v, proj, ref, levels_hw=tile_levels)
             else:
                 out = ops.deform_attn_grid_fused(
                     v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=v.shape[0],

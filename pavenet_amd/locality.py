@@ -60,12 +60,3 @@ def encoder_unit_order(levels, n_frames, mode='band'):
     order = np.concatenate(out).astype(np.int32)
     assert order.shape[0] == n_frames * S
     return torch.from_numpy(order)
-
-
-def rest_unit_order(levels, n_frames):
-    """Units (frame * S + token) of levels 1.. in band order -- what the LDS-window encoder
-    kernel leaves to the direct-gather kernel."""
-    S = sum(int(h) * int(w) for h, w in levels)
-    n0 = int(levels[0][0]) * int(levels[0][1])
-    full = encoder_unit_order(levels, n_frames).numpy()
-    return torch.from_numpy(full[(full % S) >= n0].copy())

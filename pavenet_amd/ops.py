@@ -331,44 +331,40 @@ def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5, pos=None):
     return out, out_plus
 
 
-def deform_attn_enc_window(value, spatial_shapes, level_start_index, proj, ref, *, levels_hw,
-                           rest_order, grid_ref=False):
-    """Encoder deformable attention, LDS-window kernel for level-0 queries + direct kernel for
-    `rest_order` (int32 unit indices of the other levels).  value [F, S, 8, 32];
-    proj [F*S, >= 384]; ref [1, F*S, 4, 2] -> out [F*S, 256]."""
+def enc_tile_supported(levels_hw):
+    """The LDS-tile encoder kernel covers 4-level halving pyramids: every token of level l sits
+    in exactly one 8 x 8-pixel image tile (H_l <= (8 >> l) * ceil(H_0 / 8), same for W)."""
+    if len(levels_hw) != 4:
+        return False
+    ny, nx = (int(levels_hw[0][0]) + 7) // 8, (int(levels_hw[0][1]) + 7) // 8
+    return all(int(h) <= (8 >> l) * ny and int(w) <= (8 >> l) * nx
+               for l, (h, w) in enumerate(levels_hw))
+
+
+def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0):
+    """Encoder deformable attention ([R2], T = 1) with LDS-staged value windows per image tile.
+    value [F, S, 8, 32]; proj [F*S, >= 384]; ref [.., F*S, 4, 2] -> out [F*S, 256].
+    Same results as ``deform_attn_grid_fused(..., T=1)``."""
     lib = native.load()
     f32 = torch.float32
     _dev(value, 'value', f32)
-    _dev(spatial_shapes, 'spatial_shapes', torch.int64)
-    _dev(level_start_index, 'level_start_index', torch.int64)
     _dev(proj, 'proj', f32)
     _dev(ref, 'ref', f32)
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
-             'deform_attn_enc_window: value must be [frames, S, 8, 32]')
+             'deform_attn_enc_tile: value must be [frames, S, 8, 32]')
     F_, S = value.shape[0], value.shape[1]
-    _require(spatial_shapes.shape[0] == 4, 'deform_attn_enc_window: 4 levels')
-    _require(proj.dim() == 2 and proj.shape[0] == F_ * S, 'deform_attn_enc_window: proj rows')
-    _require(ref.numel() == F_ * S * 8, 'deform_attn_enc_window: ref must be [F*S, 4, 2]')
+    _require(proj.dim() == 2 and proj.shape[0] == F_ * S, 'deform_attn_enc_tile: proj rows')
+    _require(ref.numel() == F_ * S * 8, 'deform_attn_enc_tile: ref must be [F*S, 4, 2]')
+    _require(enc_tile_supported(levels_hw), 'deform_attn_enc_tile: needs a 4-level halving pyramid')
     import ctypes
     flat = [int(v) for hw in levels_hw for v in hw]
-    _require(len(flat) == 8, 'deform_attn_enc_window: levels_hw must hold 4 (h, w) pairs')
     hw_arr = (ctypes.c_int * 8)(*flat)
-    H0, W0 = flat[0], flat[1]
-    n_rest = 0
-    if rest_order is not None:
-        _dev(rest_order, 'rest_order', torch.int32)
-        n_rest = rest_order.numel()
-    _require(H0 * W0 * F_ + n_rest == F_ * S, 'deform_attn_enc_window: rest_order must list '
-             'exactly the units of levels 1..3')
     out = torch.empty((F_ * S, 256), dtype=f32, device=value.device)
-    with torch.cuda.device(value.device), _Timed('enc_window'):
-        st = lib.pave_enc_deform_attn_window_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            proj.data_ptr(), ref.data_ptr(),
-            rest_order.data_ptr() if n_rest else None, out.data_ptr(), F_, S,
-            ctypes.cast(hw_arr, ctypes.c_void_p), int(bool(grid_ref)), n_rest, proj.stride(0),
-            _stream_ptr())
-    native.check(st, 'deform_attn_enc_window')
+    with torch.cuda.device(value.device), _Timed('enc_tile'):
+        st = lib.pave_enc_deform_attn_tile_f32(
+            value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), F_, S,
+            ctypes.cast(hw_arr, ctypes.c_void_p), proj.stride(0), int(variant), _stream_ptr())
+    native.check(st, 'deform_attn_enc_tile')
     return out
 
 

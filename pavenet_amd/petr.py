@@ -91,10 +91,10 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
         reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
         attn_mask = mask_flatten if has_padding else None
         extra = dict(inplace_residual=True)
-        if self.xcd_unit_order and feat_flatten.is_cuda:
+        if self.enc_lds_tile and feat_flatten.is_cuda and geom.tile_levels() is not None:
+            extra['tile_levels'] = geom.tile_levels()
+        elif self.xcd_unit_order and feat_flatten.is_cuda:
             extra['unit_order'] = geom.unit_order(bs, dev)
-            if self.lds_window and len(geom.hw) == 4:
-                extra['window_plan'] = geom.window_plan(bs, dev) + (not has_padding,)
         memory = self.encoder(
             query=seq_first_view(feat_flatten), key=None, value=None,
             query_pos=seq_first_view(lvl_pos_embed_flatten), query_key_padding_mask=attn_mask,

@@ -24,7 +24,7 @@ from .bricks import (BaseModule, TransformerLayerSequence, batch_first, inverse_
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
                           MultiScaleDeformableAttention, frame_prefixes)
-from .locality import encoder_unit_order, rest_unit_order
+from .locality import encoder_unit_order
 from .registry import (MMCV_TRANSFORMER, MMCV_TRANSFORMER_LAYER_SEQUENCE, TRANSFORMER,
                        TRANSFORMER_LAYER_SEQUENCE, build_transformer_layer_sequence)
 
@@ -265,12 +265,10 @@ class _LevelGeometry:
             self._order[n_frames] = encoder_unit_order(self.hw, n_frames, UNIT_ORDER_MODE).to(device)
         return self._order[n_frames]
 
-    def window_plan(self, n_frames, device):
-        """(level-0 size, unit list of levels 1..) for the LDS-window encoder kernel."""
-        key = ('win', n_frames)
-        if key not in self._order:
-            self._order[key] = rest_unit_order(self.hw, n_frames).to(device)
-        return self.hw, self._order[key]
+    def tile_levels(self):
+        """Level sizes if the LDS-tile encoder kernel covers this pyramid, else None."""
+        from .ops import enc_tile_supported
+        return self.hw if enc_tile_supported(self.hw) else None
 
 
 @TRANSFORMER.register_module()
@@ -293,9 +291,9 @@ class VideoPoseTransformerMulFrames(Transformer):
         self._geom = {}
         self.hoist_value_proj = True
         self.xcd_unit_order = True
-        # LDS-window encoder kernel: correct and tested, but at 8 waves/CU it only ties the
-        # direct-gather kernel; off until the persistent version lands
-        self.lds_window = False
+        # encoder sampling through the LDS-tile kernel (pave_enc_tile.hip); False = head-major
+        # direct-gather kernel (also the path for pyramids the tile kernel does not cover)
+        self.enc_lds_tile = True
 
     def init_layers(self):
         self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
@@ -432,10 +430,10 @@ class VideoPoseTransformerMulFrames(Transformer):
             attn_mask = attn_mask.expand(feat_flatten.shape[0], -1)
         bs = feat_flatten.shape[0]
         extra = {}
-        if self.xcd_unit_order and feat_flatten.is_cuda:
+        if self.enc_lds_tile and feat_flatten.is_cuda and geom.tile_levels() is not None:
+            extra['tile_levels'] = geom.tile_levels()
+        elif self.xcd_unit_order and feat_flatten.is_cuda:
             extra['unit_order'] = geom.unit_order(bs, dev)
-            if self.lds_window and len(geom.hw) == 4:
-                extra['window_plan'] = geom.window_plan(bs, dev) + (not has_padding,)
         # every encoder layer input is a temporary owned by this function, so the residual
         # GEMMs may accumulate into it (saves a copy of the 0.6 GB activation per GEMM)
         extra['inplace_residual'] = True

@@ -22,7 +22,8 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(native.EXPORTED)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pave_abi_version() == 1
+    m = re.search(r'#define PAVE_ABI_VERSION (\d+)', header)
+    assert lib.pave_abi_version() == int(m.group(1)) == native.ABI_VERSION
 
 
 def test_ops_fail_loudly_without_device():

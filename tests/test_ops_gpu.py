@@ -241,14 +241,16 @@ def test_bias_act_rows_vs_torch():
 
 @pytest.mark.parametrize('sigma', [0.7, 3.0, 12.0])
 @pytest.mark.parametrize('gr', [False, True])
+@pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('levels', [[(24, 40), (12, 20), (6, 10), (3, 5)],
-                                    [(25, 42), (13, 21), (7, 11), (4, 6)]])
-def test_enc_window_kernel_equals_direct_and_oracle(levels, sigma, gr):
-    """LDS-window encoder kernel == direct-gather kernel == oracle, for small offsets (all
-    corners served from LDS), medium and huge offsets (mostly the global fallback), maps whose
-    sizes are not multiples of the tile, and reference points scaled by valid ratios."""
-    from pavenet_amd.locality import rest_unit_order
-    from pavenet_amd.ops import deform_attn_enc_window, deform_attn_grid_fused
+                                    [(25, 42), (13, 21), (7, 11), (4, 6)],
+                                    [(16, 20), (8, 10), (4, 5), (2, 3)]])
+def test_enc_tile_kernel_equals_direct_and_oracle(levels, sigma, gr, variant):
+    """LDS-tile encoder kernel == direct-gather kernel == oracle, for small offsets (all corners
+    served from LDS), medium and huge offsets (mostly the global second pass), maps whose sizes are
+    not multiples of the tile, and reference points scaled by valid ratios (padded frames)."""
+    from pavenet_amd.ops import deform_attn_enc_tile, deform_attn_grid_fused, enc_tile_supported
+    assert enc_tile_supported(levels)
     shapes, lsi, sd, ld = _levels(levels)
     S = int(shapes.prod(1).sum())
     F = 2
@@ -260,15 +262,40 @@ def test_enc_window_kernel_equals_direct_and_oracle(levels, sigma, gr):
     xs = torch.cat([((torch.arange(h * w) % w).float() + 0.5) / w for h, w in levels])
     ref = (torch.stack([xs, ys], -1)[None, :, None, :] * vr).expand(F, S, 4, 2)
     ref = ref.reshape(1, F * S, 4, 2).contiguous()
-    rest = rest_unit_order(levels, F).cuda()
-    a = deform_attn_enc_window(value.cuda(), sd, ld, proj.cuda(), ref.cuda(),
-                               levels_hw=levels, rest_order=rest, grid_ref=gr)
+    a = deform_attn_enc_tile(value.cuda(), proj.cuda(), ref.cuda(), levels_hw=levels,
+                             variant=variant)
     b = deform_attn_grid_fused(value.cuda(), sd, ld, proj.cuda(), ref.cuda(), T=1, n_clips=F,
                                units_per_clip=S)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5)
     idx = torch.arange(0, F * S, 7)
     exp = grid_expected(value, shapes, lsi, proj[idx], ref[:, idx], 1, idx // S)
     np.testing.assert_allclose(a.cpu()[idx].numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_enc_tile_kernel_rejects_non_pyramid_and_survives_non_finite():
+    """A pyramid that is not a halving one is refused (callers use the direct kernel); NaN / Inf
+    offsets, logits or reference points never become out-of-range accesses."""
+    from pavenet_amd.ops import deform_attn_enc_tile, enc_tile_supported
+    assert not enc_tile_supported([(8, 8), (5, 4), (2, 2), (1, 1)])
+    assert not enc_tile_supported([(8, 8), (4, 4), (2, 2)])
+    levels = [(16, 20), (8, 10), (4, 5), (2, 3)]
+    S = sum(h * w for h, w in levels)
+    value = _t(seeded_array('tile.nf.value', (1, S, 8, 32))).cuda()
+    proj = _t(seeded_array('tile.nf.proj', (S, 384)))
+    proj[::5, :256] = float('nan')
+    proj[1::5, 3] = float('inf')
+    proj[2::5, 300] = float('inf')
+    proj[3::5, :256] = 1e30
+    ref = torch.rand(1, S, 4, 2)
+    ref[0, ::11] = float('nan')
+    with pytest.raises(RuntimeError):
+        deform_attn_enc_tile(value, proj.cuda(), ref.cuda(), levels_hw=[(16, 20), (9, 10), (4, 5), (2, 3)])
+    out = deform_attn_enc_tile(value, proj.cuda(), ref.cuda(), levels_hw=levels)
+    torch.cuda.synchronize()
+    assert out.shape == (S, 256)
+    clean = torch.arange(S) % 5 == 4
+    clean &= torch.arange(S) % 11 != 0
+    assert torch.isfinite(out.cpu()[clean]).all()
 
 
 @pytest.mark.parametrize('D', [4, 30, 32, 64, 71])

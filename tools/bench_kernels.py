@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--sigma', type=float, default=3.0, help='offset std-dev in pixels')
     ap.add_argument('--order', default='none')
+    ap.add_argument('--enc-only', action='store_true')
+    ap.add_argument('--ablate', action='store_true')
     args = ap.parse_args()
     dev = 'cuda'
     shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
@@ -58,12 +60,27 @@ def main():
     alg = 4 * (F * S * 256 + U * 384 + U * 256)
     print(f'enc_fused   frames={F} order={args.order}: {us:9.1f} us  {us / F:8.1f} us/frame  '
           f'alg {alg / us / 1e3:7.1f} GB/s')
-    from pavenet_amd.locality import rest_unit_order
-    rest = rest_unit_order(LEVELS, F).to(dev)
-    us = timeit(lambda: ops.deform_attn_enc_window(value, shapes, lsi, proj, ref,
-                                                   levels_hw=LEVELS, rest_order=rest, grid_ref=True))
-    print(f'enc_window  frames={F}: {us:9.1f} us  {us / F:8.1f} us/frame  '
-          f'alg {alg / us / 1e3:7.1f} GB/s')
+    for variant in (0, 1):
+        us = timeit(lambda: ops.deform_attn_enc_tile(value, proj, ref, levels_hw=LEVELS,
+                                                     variant=variant))
+        print(f'enc_tile v{variant} frames={F} sigma={args.sigma}: {us:9.1f} us  {us / F:8.1f} us/frame  '
+              f'alg {alg / us / 1e3:7.1f} GB/s = {alg / us / 1e3 / 8000:.3f} of 8 TB/s')
+    if args.ablate:
+        import ctypes
+        from pavenet_amd import native
+        lib = native.load()
+        fn = lib.pave_diag_enc_tile_ablate
+        fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + \
+            [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        hw = (ctypes.c_int * 8)(*[v for hw_ in LEVELS for v in hw_])
+        out = torch.empty(U, 256, device=dev)
+        for ab in (0, 1, 2, 3):
+            us = timeit(lambda: fn(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                   F, S, ctypes.cast(hw, ctypes.c_void_p), 384, 0, ab,
+                                   torch.cuda.current_stream().cuda_stream))
+            print(f'enc_tile v0 ablate={ab} (1: no staging, 2: no gather): {us:9.1f} us')
+    if args.enc_only:
+        return
     # the un-fused reference-shaped op on the same work
     off = proj[:, :256].view(F, S, 8, 4, 4, 2)
     norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
