@@ -25,7 +25,9 @@
 // footprint sit in rows of opposite parity, and a pair with parity role 1 simply visits them in
 // the other order.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "pave_hip.h"
 #include "pave_internal.h"
@@ -45,6 +47,9 @@ struct TileParams {
   int nx, ny;          // tiles per frame
   int n_blocks;
   int Hs[4], Ws[4], St[4];
+  // per-level constants each lane fetches by its level k = lane & 3 (one 32-byte kernarg row):
+  // H, W, first token, window side, first LDS row of the window, 1/W, 1/H (float bits), unused
+  int tab[4][8];
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -151,7 +156,7 @@ __device__ __forceinline__ int make_point(PointDesc& d, float px, float py, floa
   const int dx0 = x0 - ox, dy0 = y0 - oy;
   const bool inwin = (unsigned)dx0 < (unsigned)(WW - 1) && (unsigned)dy0 < (unsigned)(WW - 1);
   // outside the window: the zero rows (zrow even, zrow + 1 odd, "window width" 0)
-  const int r00 = inwin ? wbase + __mul24(dy0, WW) + dx0 : zrow;
+  const int r00 = inwin ? __mul24(dy0, WW) + (dx0 + wbase) : zrow;
   const int wws = inwin ? WW : 0;
   const int e = (r00 ^ par) & 1, eb = e ^ (wws & 1);
   const float xf = e ? lx : hx, xs = e ? hx : lx;
@@ -165,7 +170,7 @@ __device__ __forceinline__ int make_point(PointDesc& d, float px, float py, floa
   d.a[1] = (r00 + 1 - e) << 7;
   d.a[2] = (r10 + eb) << 7;
   d.a[3] = (r10 + 1 - eb) << 7;
-  d.tok00 = st + __mul24(y0, W) + x0;
+  d.tok00 = __mul24(y0, W) + (x0 + st);
   return (inwin ? 0 : 1) | (e << 1) | (eb << 2);
 }
 
@@ -277,6 +282,9 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const float4 of23 = *reinterpret_cast<const float4*>(row + 4);
   const float4 lg = *reinterpret_cast<const float4*>(row + (kHeads - head) * 32 + head * 16 - k * 4);
   const float2 rf = *reinterpret_cast<const float2*>(p.ref + (size_t)unit * 8 + k * 2);
+  const int4* tab = reinterpret_cast<const int4*>(
+      (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileParams, tab)) + k * 2;
+  const int4 tabA = tab[0], tabB = tab[1];
 
   // ---- stage the four windows (LDS-DMA) and the two zero rows
   const int ox0 = tx * 8 - MB0, oy0 = ty * 8 - MB0, ox1 = tx * 4 - MB1, oy1 = ty * 4 - MB1;
@@ -290,22 +298,19 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   }
   if (threadIdx.x < 64) reinterpret_cast<float*>(lds + G::kZ * 128)[threadIdx.x] = 0.f;
 
-  // ---- my level's constants (lane k <-> level k)
-  const int H = k == 0 ? p.Hs[0] : k == 1 ? p.Hs[1] : k == 2 ? p.Hs[2] : p.Hs[3];
-  const int W = k == 0 ? p.Ws[0] : k == 1 ? p.Ws[1] : k == 2 ? p.Ws[2] : p.Ws[3];
-  const int st = k == 0 ? p.St[0] : k == 1 ? p.St[1] : k == 2 ? p.St[2] : p.St[3];
-  const int ox = k == 0 ? ox0 : k == 1 ? ox1 : k == 2 ? ox2 : ox3;
-  const int oy = k == 0 ? oy0 : k == 1 ? oy1 : k == 2 ? oy2 : oy3;
-  const int wbase = k == 0 ? G::B0 : k == 1 ? G::B1 : k == 2 ? G::B2 : G::B3;
-  const int ww = k == 0 ? W0 : k == 1 ? W1 : k == 2 ? W2 : W3;
+  // ---- my level's constants (lane k <-> level k): one vector load of the kernarg table row
+  // instead of seven 4-way select chains
+  static_assert(MB0 == MB1 && MB1 == MB2 && MB2 == MB3, "one window margin for all levels");
+  const int ox = ((tx * 8) >> k) - MB0, oy = ((ty * 8) >> k) - MB0;
+  const int H = tabA.x, W = tabA.y, st = tabA.z, ww = tabA.w, wbase = tabB.x;
   const float fW = (float)W, fH = (float)H;
-  const float rW = 1.f / fW, rH = 1.f / fH;
+  const float rW = __int_as_float(tabB.y), rH = __int_as_float(tabB.z);
 
   // ---- softmax over the 16 logits of (unit, head): 4 per lane, quad reduction
   const float mx = quad_max(fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w)));
   const float e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx), e2 = __expf(lg.z - mx),
               e3 = __expf(lg.w - mx);
-  float inv_sum = 1.f / quad_sum((e0 + e1) + (e2 + e3));
+  float inv_sum = __builtin_amdgcn_rcpf(quad_sum((e0 + e1) + (e2 + e3)));  // 1 ulp
   if (!valid) inv_sum = 0.f;  // idle slots carry weight 0 through the DPP steps
 
   // ---- corner descriptors of my 4 points
@@ -406,9 +411,23 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
   if (nb >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: grid too large");
   p.n_blocks = (int)nb;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto fill = [&](auto geom, int w0, int w1, int w2, int w3) {
+    using G = decltype(geom);
+    const int ww[4] = {w0, w1, w2, w3}, wb[4] = {G::B0, G::B1, G::B2, G::B3};
+    for (int l = 0; l < 4; ++l) {
+      const float rw = 1.f / (float)p.Ws[l], rh = 1.f / (float)p.Hs[l];
+      int irw, irh;
+      memcpy(&irw, &rw, 4);
+      memcpy(&irh, &rh, 4);
+      const int row[8] = {p.Hs[l], p.Ws[l], p.St[l], ww[l], wb[l], irw, irh, 0};
+      memcpy(p.tab[l], row, sizeof(row));
+    }
+  };
   if (variant == 1) {  // +-4 px windows, 2 workgroups per CU
+    fill(WinGeom<16, 12, 10, 9>{}, 16, 12, 10, 9);
     hipLaunchKernelGGL((enc_tile_kernel<16, 12, 10, 9, 4, 4, 4, 4, 1, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   } else {             // -4 .. +3 px windows (52 KB), 3 workgroups per CU
+    fill(WinGeom<14, 10, 8, 7>{}, 14, 10, 8, 7);
     hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   }
   const hipError_t e = hipGetLastError();

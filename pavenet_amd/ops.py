@@ -20,9 +20,11 @@ import torch
 from . import native
 
 
-# When set to a list, the fused launches append (tag, start_event, end_event) recorded on the
-# stream they launch on (bench.py uses this to time the dominant kernel inside its timed region).
+# When set to a list, launches whose tag is in KERNEL_EVENT_TAGS append (tag, start_event,
+# end_event) recorded on the stream they launch on (bench.py times the dominant kernel this way
+# inside its timed region; every other launch records nothing).
 KERNEL_EVENTS = None
+KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1')
 
 
 def _stream_ptr():
@@ -31,7 +33,7 @@ def _stream_ptr():
 
 class _Timed:
     def __init__(self, tag):
-        self.tag = tag if KERNEL_EVENTS is not None else None
+        self.tag = tag if (KERNEL_EVENTS is not None and tag in KERNEL_EVENT_TAGS) else None
 
     def __enter__(self):
         if self.tag is not None:

@@ -591,3 +591,30 @@ def test_full_size_800x1344_vs_reference_golden(golden_dir):
     assert kpts.shape == g['det_kpts'].shape, 'OKS-NMS keep set differs from the reference'
     np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('shard', ['clips', 'frames'])
+def test_bench_multi_rank_code_path_on_one_gpu(shard):
+    """bench.py's N > 1 code (rank set-up, clip-parallel result all-gather / frame-sharded forward,
+    max-over-ranks timing, the JSON line) executed every round: two ranks share this box's GPU over
+    gloo (PAVE_BENCH_ONE_DEVICE=1; on the 8-GPU node the same code runs on nccl = RCCL)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '128', '--width', '160',
+           '--shard', shard, '--frames', '5' if shard == 'frames' else '3', '--no-cpu-baseline',
+           '--gemm-select', 'default']
+    env = dict(os.environ, PAVE_BENCH_ONE_DEVICE='1')
+    torch.cuda.empty_cache()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:] + '\n---\n' + r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['steps'] == 2
+    assert line['scaling'] == ('strong' if shard == 'frames' else 'weak')

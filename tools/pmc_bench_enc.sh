@@ -16,10 +16,11 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$R/gpurun_out/$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'][:90]][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[r['Kernel_Name'][:120]][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, d in agg.items():
-    if 'enc_head_major_kernel' in k or 'fused_deform_attn_kernel<0, 2, 1>' in k:
+    if 'enc_tile_kernel' in k or 'enc_head_major_kernel' in k:
+        kname = 'enc_tile_kernel' if 'enc_tile_kernel' in k else 'enc_head_major_kernel'
         for c, v in sorted(d.items()):
             v = sorted(v)[len(v) // 4: len(v) - len(v) // 4] or v   # inter-quartile mean
             out[c] = dict(n=len(d[c]), mean=sum(v) / len(v))
@@ -30,7 +31,7 @@ for k, d in agg.items():
 if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
     rd = out['FETCH_SIZE']['mean'] * 1024 * 2
     wr = out['WRITE_SIZE']['mean'] * 1024
-    res = dict(kernel='enc_head_major_kernel (encoder MSDA, GRID T=1)', workload='bench.py default (28 frames/launch)',
+    res = dict(kernel=kname + ' (encoder MSDA, T=1)', workload='bench.py default (28 frames/launch)', frames_per_launch=28,
                fetch_size_kb_raw=out['FETCH_SIZE']['mean'], write_size_kb=out['WRITE_SIZE']['mean'],
                read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
                note='FETCH_SIZE doubled per the gfx950 correction for 16-B/lane loads; separate --pmc passes')
