@@ -330,6 +330,53 @@ def gen_fullsize():
     print(json.dumps(stats, indent=1))
 
 
+
+def gen_rescale():
+    """f3: the PUBLIC entry VideoPoseV1.simple_test(img, img_metas, rescale=True) with a non-unit
+    scale_factor, through bbox_kpt2result (opera/core/keypoint/transforms.py:132-154): the
+    per-class lists the reference returns for the T = 3 R-50 clip of `e2e_videopose_r50_t3`."""
+    name = 'e2e_videopose_r50_t3'
+    cfg_path, T = E2E[name]
+    model, cfg = ref_shim.build_reference_model(cfg_path)
+    keys = _load_seeded(model)
+    H, W = 128, 160
+    img = _t(seeded_array(f'{name}.img', (1, T, 3, H, W)))
+    sf = (0.375, 0.4, 0.375, 0.4)  # (w, h, w, h) as mmdet's Resize writes it
+    meta = [dict(batch_input_shape=(H, W), img_shape=(120, 150, 3), scale_factor=sf)]
+    with torch.no_grad():
+        (bbox_results, kpt_results), = model.simple_test(img, meta, rescale=True)
+    assert len(bbox_results) == 1 and len(kpt_results) == 1  # one class (person)
+    _save('e2e_videopose_r50_t3_rescale', keys=keys, scale_factor=np.array(sf, dtype=np.float32),
+          bbox_results=bbox_results[0], kpt_results=kpt_results[0])
+
+
+
+def gen_pipeline_shapes():
+    """f4: the pure-Python parts of the reference's test pipeline that CAN run here (cv2 is absent,
+    so mmcv.imresize / imnormalize / impad themselves cannot): mmcv.rescale_size (the size
+    Resize(keep_ratio=True) asks cv2 for), the scale_factor mmdet's Resize records and the shape
+    Pad(size_divisor) pads to (mmdet/datasets/pipelines/transforms.py Resize._resize_img /
+    Pad._pad_img; configs/_base_/datasets/posetrack17_video_keypoint.py:71-84)."""
+    ref_shim.install()
+    from mmcv.image.geometric import rescale_size
+    cases = []
+    for (w, h) in [(1920, 1080), (1280, 720), (640, 480), (480, 640), (333, 500), (1333, 800),
+                   (1344, 800), (1000, 1000), (427, 640), (3, 2000)]:
+        for scale in [(1333, 800), (800, 1333), (1000, 600)]:
+            new_size, factor = rescale_size((w, h), scale, return_scale=True)
+            nw, nh = new_size
+            # Resize._resize_img: w_scale = new_w / w, h_scale = new_h / h (after mmcv.imrescale)
+            for div in (1, 32):
+                ph = int(np.ceil(nh / div)) * div      # mmcv.impad_to_multiple
+                pw = int(np.ceil(nw / div)) * div
+                cases.append(dict(src_wh=[w, h], scale=list(scale), new_wh=[nw, nh],
+                                  scale_factor=[nw / w, nh / h, nw / w, nh / h], divisor=div,
+                                  pad_hw=[ph, pw], factor=float(factor)))
+    path = os.path.join(OUT, 'pipeline_shapes.json')
+    open(path, 'w').write('[\n' + ',\n'.join(json.dumps(c) for c in cases) + '\n]\n')
+    print('wrote', path, len(cases), 'cases')
+
+
 PETR_E2E = {
     'e2e_petr_r50': 'configs/petr/petr_r50_16x2_100e_coco.py',
     'e2e_vedpose_r50': 'configs/vedpose/single_frame_posetrack_resnet50_inference.py',
@@ -399,6 +446,10 @@ if __name__ == '__main__':
         gen_modules()
     if what in ('e2e', 'all'):
         gen_e2e(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ('pipeline', 'all'):
+        gen_pipeline_shapes()
+    if what in ('rescale', 'all'):
+        gen_rescale()
     if what in ('full', 'all'):
         gen_fullsize()
     if what in ('petr', 'all'):

@@ -310,18 +310,18 @@ class _Folded:
     """Device inference path shared by the HRNet pieces: eval BatchNorm folded into its
     convolution (cached until a parameter changes), channels-last maps, MIOpen convolution
     without bias + ONE hand-written pass for bias / residual / ReLU (pave_bias_act_rows_f32)."""
-    cache = {}
-
     @classmethod
     def weights(cls, conv, bn):
-        key = tuple((t.data_ptr(), t._version) for t in
+        # the folded pair lives ON the conv module (dies with it; Python reuses id()s, so a
+        # class-level dict keyed on id(conv) could serve another model's weights)
+        key = tuple((id(t), t.data_ptr(), t._version) for t in
                     (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
-        hit = cls.cache.get(id(conv))
+        hit = conv.__dict__.get('_pave_folded')
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 w, b = _fold(conv, bn)
                 hit = (key, w.contiguous(memory_format=torch.channels_last), b.contiguous())
-            cls.cache[id(conv)] = hit
+            conv.__dict__['_pave_folded'] = hit
         return hit[1], hit[2]
 
     @classmethod

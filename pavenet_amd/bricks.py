@@ -114,7 +114,6 @@ def _fusable(*tensors):
 # than the broadcast add it saves), so it is off unless PAVE_POS_FUSION=1.
 FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
 _GEMM = {'mode': 'native', 'min_rows': 8192}
-_SPLIT_CACHE = {}
 
 
 _PLANES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'fp16': 16}   # 16 = ops.PLANES_FP16
@@ -133,20 +132,39 @@ def get_gemm_mode():
     return _GEMM['mode']
 
 
+def _split_slots(weight):
+    """Cache dict that LIVES ON the tensor owning the storage (the Parameter, or the folded-BN
+    weight kept in ResNet._folded / on the conv module): it dies with that tensor.  An address is
+    no identity -- the caching allocator hands a freed folded weight's address to the next
+    same-shaped one with _version 0 again -- so nothing here is keyed on data_ptr()."""
+    owner = weight._base if weight._base is not None else weight
+    slots = owner.__dict__.get('_pave_split')
+    if slots is None:
+        slots = owner.__dict__['_pave_split'] = {}
+    return slots
+
+
+def _split_cached(weight, kind, make):
+    planes = _PLANES[_GEMM['mode']]
+    slots = _split_slots(weight)
+    slot = (tuple(weight.shape), tuple(weight.stride()), weight.storage_offset(), planes, kind)
+    hit = slots.get(slot)
+    if hit is None or hit[0] != weight._version:
+        with torch.no_grad():
+            hit = (weight._version, make(planes))
+        slots[slot] = hit
+        _SPLIT_STATS['made'] += 1
+    return hit[1]
+
+
+_SPLIT_STATS = {'made': 0}   # number of weight splits performed (tests: the path was exercised)
+
+
 def _split_weight(weight):
     """Weight [N, K] -> cached slab-major bf16x3 planes (re-split when the tensor changes)."""
     from . import ops
-    planes = _PLANES[_GEMM['mode']]
-    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), planes)
-    hit = _SPLIT_CACHE.get(slot)
-    if hit is None or hit[0] != weight._version:
-        with torch.no_grad():
-            hit = (weight._version,
-                   ops.split_weight_bf16x3(weight.detach().contiguous(), planes))
-        if len(_SPLIT_CACHE) > 1024:
-            _SPLIT_CACHE.clear()
-        _SPLIT_CACHE[slot] = hit
-    return hit[1]
+    return _split_cached(weight, 'gemm',
+                         lambda planes: ops.split_weight_bf16x3(weight.detach().contiguous(), planes))
 
 
 def split_conv_weight(weight):
@@ -157,14 +175,8 @@ def split_conv_weight(weight):
             or weight.dtype != torch.float32:
         return None
     from . import ops
-    planes = _PLANES[_GEMM['mode']]
-    slot = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), planes, 'conv')
-    hit = _SPLIT_CACHE.get(slot)
-    if hit is None or hit[0] != weight._version:
-        with torch.no_grad():
-            hit = (weight._version, ops.split_conv3x3_weight(weight.detach(), planes))
-        _SPLIT_CACHE[slot] = hit
-    return hit[1]
+    return _split_cached(weight, 'conv',
+                         lambda planes: ops.split_conv3x3_weight(weight.detach(), planes))
 
 
 def split_gemm_ok(x2, weight):

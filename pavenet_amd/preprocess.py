@@ -27,6 +27,17 @@ def rescale_size(old_size, scale):
     return int(w * float(f) + 0.5), int(h * float(f) + 0.5)
 
 
+def plan_clip(H0, W0, img_scale=(1333, 800), size_divisor=1):
+    """Host arithmetic of Resize(keep_ratio=True) + Pad(size_divisor) for an H0 x W0 source:
+    -> (Hn, Wn, Hp, Wp, scale_factor) exactly as mmcv.rescale_size, mmdet's Resize._resize_img
+    (w_scale = new_w / w, h_scale = new_h / h) and mmcv.impad_to_multiple compute them."""
+    Wn, Hn = rescale_size((W0, H0), img_scale)
+    d = max(int(size_divisor), 1)
+    Hp, Wp = -(-Hn // d) * d, -(-Wn // d) * d
+    ws, hs = Wn / W0, Hn / H0
+    return Hn, Wn, Hp, Wp, (ws, hs, ws, hs)
+
+
 def preprocess_clip(frames, img_scale=(1333, 800), size_divisor=1, mean=MEAN, std=STD,
                     to_rgb=True):
     """frames [T, H0, W0, 3] uint8 / float32 BGR on the device -> (img [1, T, 3, Hp, Wp] fp32,
@@ -37,9 +48,7 @@ def preprocess_clip(frames, img_scale=(1333, 800), size_divisor=1, mean=MEAN, st
              '[T, H, W, 3] tensor')
     _require(frames.dtype in (torch.uint8, torch.float32), 'preprocess_clip: uint8 or float32')
     T, H0, W0, _ = frames.shape
-    Wn, Hn = rescale_size((W0, H0), img_scale)
-    d = max(int(size_divisor), 1)
-    Hp, Wp = -(-Hn // d) * d, -(-Wn // d) * d
+    Hn, Wn, Hp, Wp, scale_factor = plan_clip(H0, W0, img_scale, size_divisor)
     out = torch.empty((1, T, 3, Hp, Wp), dtype=torch.float32, device=frames.device)
     m = (ctypes.c_float * 3)(*mean)
     s = (ctypes.c_float * 3)(*std)
@@ -50,7 +59,6 @@ def preprocess_clip(frames, img_scale=(1333, 800), size_divisor=1, mean=MEAN, st
                                         ctypes.cast(s, ctypes.c_void_p), int(bool(to_rgb)),
                                         _stream_ptr())
     native.check(st, 'preprocess_frames')
-    ws, hs = Wn / W0, Hn / H0
     meta = dict(ori_shape=(H0, W0, 3), img_shape=(Hn, Wn, 3), pad_shape=(Hp, Wp, 3),
-                batch_input_shape=(Hp, Wp), scale_factor=(ws, hs, ws, hs), flip=False)
+                batch_input_shape=(Hp, Wp), scale_factor=scale_factor, flip=False)
     return out, meta

@@ -262,3 +262,43 @@ def test_encoder_unit_order_is_a_permutation(mode):
         first = order[:32].long() % S
         ys, xs = first // 21, first % 21
         assert int(xs.max() - xs.min()) <= 7 and int(ys.max() - ys.min()) <= 3
+
+
+def test_streaming_window_rule_is_the_reference_datasets():
+    """f2: VideoPoseStream.window_indices == the reference dataset's auxiliary-frame rule
+    (opera/datasets/posetrack_video_pose.py:578-609, PoseTrack17 branch, 1-based frame numbers):
+    prev = cur - 1 except at the first frame, next = cur + 1 except at the last one."""
+    from pavenet_amd.streaming import VideoPoseStream
+
+    def reference_rule(cur, nframes):          # restated from _get_auxiliary_frames
+        prev_delta, next_delta = 1, 1
+        if cur == 1:
+            prev_delta, next_delta = 0, 1
+        if cur == nframes:
+            prev_delta, next_delta = 1, 0
+        return [cur - prev_delta, cur, cur + next_delta]
+
+    for n in range(2, 9):
+        wins = VideoPoseStream.window_indices(n, 3)
+        assert wins == [[i - 1 for i in reference_rule(c + 1, n)] for c in range(n)]
+    # T = 5 generalisation: edge replication on both sides
+    assert VideoPoseStream.window_indices(4, 5) == [[0, 0, 0, 1, 2], [0, 0, 1, 2, 3], [0, 1, 2, 3, 3],
+                                                    [1, 2, 3, 3, 3]]
+
+
+def test_pipeline_shapes_vs_the_references_own_rescale_size(golden_dir):
+    """f4, the part that CAN be pinned without cv2: resize target size, recorded scale_factor and
+    padded shape against values produced by the reference's own mmcv.rescale_size /
+    impad_to_multiple arithmetic (tests/golden/pipeline_shapes.json, oracle/gen_golden.py
+    `pipeline`), for the product's host planner and for the oracle's."""
+    import json
+    from oracle import preprocess_ref as PR
+    from pavenet_amd.preprocess import plan_clip
+    cases = json.load(open(os.path.join(golden_dir, 'pipeline_shapes.json')))
+    assert len(cases) == 60
+    for c in cases:
+        (w, h), scale, div = c['src_wh'], tuple(c['scale']), c['divisor']
+        Hn, Wn, Hp, Wp, sf = plan_clip(h, w, scale, div)
+        assert [Wn, Hn] == c['new_wh'] and [Hp, Wp] == c['pad_hw'], c
+        assert list(sf) == c['scale_factor']
+        assert list(PR.rescale_size((w, h), scale)) == c['new_wh']

@@ -194,3 +194,19 @@ def test_full_size_800x1344_vs_reference(golden_dir):
     assert kpts.shape == g['det_kpts'].shape
     np.testing.assert_allclose(kpts.numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)  # pixels
     np.testing.assert_allclose(bboxes.numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+
+
+def test_end_to_end_rescale(golden_dir):
+    """simple_test(rescale=True) with scale_factor (0.375, 0.4, ...): keypoints in the original
+    image's pixels (HEAD:1455-1457), through the reference's bbox_kpt2result lists."""
+    g0 = _load(golden_dir, 'e2e_videopose_r50_t3')
+    g = _load(golden_dir, 'e2e_videopose_r50_t3_rescale')
+    sd = _sd(g0)
+    N = int(g0['score_topk'].shape[0])
+    cfg = dict(num_frames=3, num_keypoints=15, num_query=300, max_per_img=N)
+    with torch.no_grad():
+        bboxes, labels, kpts = R.videopose_simple_test(
+            sd, cfg, _t(g0['img']), img_shape=(120, 150, 3),
+            rescale_factor=tuple(float(v) for v in g['scale_factor']))
+    assert kpts.shape == g['kpt_results'].shape
+    np.testing.assert_allclose(kpts.numpy(), g['kpt_results'], rtol=1e-4, atol=3e-2)
