@@ -1383,13 +1383,9 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
   p.proj_stride = proj_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (T == 1 && P == 4 && L <= 4) {
-    // A/B switch while the head-major split is evaluated (PAVE_ENC_HEAD_MAJOR=0 -> per-query waves)
-    static const bool hm = [] {
-      const char* e = getenv("PAVE_ENC_HEAD_MAJOR");
-      return e == nullptr || e[0] != '0';
-    }();
-    // its float4 / float2 projection loads need 16-byte aligned rows
-    if (hm && proj_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0)
+    // head-major split; its float4 / float2 projection loads need 16-byte aligned rows, other
+    // row strides take the per-query form of the same kernel below
+    if (proj_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0)
       return launch_enc_head_major(p, st);
   }
   if (T == 1) return launch_fused<kGrid, 2, 1>(p, st);

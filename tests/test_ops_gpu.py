@@ -125,6 +125,32 @@ def test_grid_fused_vs_oracle(T, U, clips):
                                rtol=1e-5)
 
 
+def test_grid_fused_T1_unaligned_rows_take_the_per_query_kernel():
+    """T = 1 projections whose row stride is not a multiple of 4 floats cannot use the head-major
+    kernel's 16-byte loads: the C entry point falls back to the per-query form
+    (fused_deform_attn_kernel<GRID, 2, 1>).  Reached through the C ABI directly (the torch wrapper
+    only hands over dense rows); same numbers as the oracle."""
+    from pavenet_amd import native
+    lib = native.load()
+    shapes, lsi, sd, ld = _levels(LEVELS)
+    S = int(shapes.prod(1).sum())
+    U, stride = 37, 385
+    value = _t(seeded_array('gf1u.value', (1, S, 8, 32)))
+    wide = _t(seeded_array('gf1u.proj', (U, stride)))
+    wide[:, :256] *= 2.0
+    proj = wide[:, :384].contiguous()
+    ref = _t(seeded_array('gf1u.ref', (1, U, 4, 2), 0.35)) + 0.5
+    exp = grid_expected(value, shapes, lsi, proj, ref, 1, torch.zeros(U, dtype=torch.long))
+    vd, pd, rd = value.cuda(), wide.cuda(), ref.cuda()
+    out = torch.empty(U, 256, device='cuda')
+    st = lib.pave_deform_attn_grid_fused_f32(
+        vd.data_ptr(), sd.data_ptr(), ld.data_ptr(), pd.data_ptr(), rd.data_ptr(), None, None,
+        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride,
+        torch.cuda.current_stream().cuda_stream)
+    native.check(st, 'grid_fused (unaligned rows)')
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize('T,clips,Q,K', [(1, 2, 9, 17), (2, 2, 10, 15), (3, 2, 10, 15), (5, 1, 7, 15),
                                          (7, 1, 5, 15)])
 def test_pose_fused_vs_oracle(T, clips, Q, K):
