@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--max-per-img', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-native-side', action='store_true',
+                    help='skip the --gemm native side measurement (profiling runs: one mode per trace)')
     ap.add_argument('--cpu-baseline-clips', type=int, default=3,
                     help='timed oracle clips after one small warm-up (~50 s each on 128 cores)')
     ap.add_argument('--graph', type=int, default=0,
@@ -261,7 +263,7 @@ def main():
         return dt, ev, out
 
     native_dt = None
-    if args.gemm != 'native' and graphed is None:
+    if args.gemm != 'native' and graphed is None and not args.no_native_side:
         # the same workload on the vendor fp32-MFMA kernels, printed beside the headline
         set_gemm_mode('native')
         native_dt, _, _ = timed(False)
