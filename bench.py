@@ -25,10 +25,10 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import pavenet_amd  # noqa: E402,F401  (sets the runtime flag hipGraph replay needs, before HIP starts)
+import torch  # noqa: E402
 
 LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
 S_TOKENS = sum(h * w for h, w in LEVELS)

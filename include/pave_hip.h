@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 2
+#define PAVE_ABI_VERSION 3
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -241,6 +241,21 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
                          const float* bias, const float* residual, float* out, long long M, int K,
                          int N, int relu, int nplanes, void* stream);
+
+/*
+ * Same GEMM with two epilogue options (the encoder layer's `value_proj | sampling_offsets |
+ * attention_weights` Linears of third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:355-379 run
+ * as ONE launch over the layer input):
+ *   residual_rows > 0: `residual` is a [residual_rows, N] table and row m adds residual[m %
+ *     residual_rows] -- a per-token term shared by all frames (e.g. (query_pos @ W^T + b) when the
+ *     positional encoding is the same for every frame); 0: residual is [M, N] as above.
+ *   out2 != NULL: the product is cut at column n_split (n_split %% 128 == 0) into two dense
+ *     matrices, out [M, n_split] and out2 [M, N - n_split].
+ */
+int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_planes,
+                            const float* bias, const float* residual, long long residual_rows,
+                            float* out, float* out2, int n_split, long long M, int K, int N,
+                            int relu, int nplanes, void* stream);
 
 /*
  * 3x3 / pad 1 / stride 1|2 convolution, NHWC fp32 in and out, as an implicit GEMM through the same

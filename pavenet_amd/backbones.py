@@ -178,6 +178,14 @@ class ResNet(BaseModule):
         return f
 
     @staticmethod
+    def _ds_bias(f, name, bi):
+        """b3 + bd of a downsample block, summed once per folded parameter set."""
+        key = (name, bi, 'ds_b3')
+        if key not in f:
+            f[key] = f[(name, bi, 'ds')][1] + f[(name, bi, 'conv3')][1]
+        return f[key]
+
+    @staticmethod
     def _as_rows(x):
         """channels_last [N, C, H, W] -> ([N*H*W, C] view, (N, H, W))."""
         n, c, h, w = x.shape
@@ -237,6 +245,17 @@ class ResNet(BaseModule):
                 # relu([relu(y + b2) | x] @ [W3; Wd] + b3 + bd): the whole tail in one kernel
                 out = ops.rows_gemm_bias_res_act(yrows, tail[0], tail[1], None, relu=True,
                                                  a_bias=b2, a2=xrows)
+            elif split_gemm_ok(xrows, wd.flatten(1)) and \
+                    (w3_kn is not None or split_gemm_ok(yrows, w3.flatten(1))):
+                # split / 16-bit GEMM modes: downsample GEMM (both biases), then conv3 accumulates
+                # into it with the ReLU in its epilogue
+                idt = linear_rows(xrows, wd.flatten(1), self._ds_bias(f, name, bi))
+                if split_gemm_ok(yrows, w3.flatten(1)):
+                    out = linear_rows(yrows, w3.flatten(1), None, relu=True, residual=idt,
+                                      inplace_residual=True, a_bias=b2)
+                else:
+                    out = ops.rows_gemm_bias_res_act(yrows, w3_kn, None, idt, relu=True, out=idt,
+                                                     a_bias=b2)
             else:
                 idt = torch.addmm(bd + b3, xrows, wd.flatten(1).t())      # both biases here
                 if w3_kn is not None:                                     # += y @ W3, ReLU: one pass

@@ -180,11 +180,12 @@ def split_conv_weight(weight):
 
 
 def split_gemm_ok(x2, weight):
-    """Shapes / dtypes the split GEMM takes (and where it beats the library)."""
+    """Shapes / dtypes the split GEMM takes (and where it beats the library: every K % 64 == 0,
+    N % 128 == 0 shape of the model, down to the K = 64 Bottleneck tails -- tools/
+    bench_gemm_shapes.py, profiles/r02_gemm_shapes.txt)."""
     return (_GEMM['mode'] in _PLANES and x2.is_cuda and x2.dtype == torch.float32
             and x2.dim() == 2 and x2.is_contiguous() and weight.dtype == torch.float32
             and weight.shape[1] % 64 == 0
-            and weight.shape[1] >= (256 if _GEMM['mode'] == 'bf16x3' else 64)
             and weight.shape[0] % 128 == 0 and x2.shape[0] >= _GEMM['min_rows']
             and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
 

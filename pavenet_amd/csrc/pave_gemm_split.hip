@@ -81,6 +81,15 @@ struct ConvGeom {
   int H, W, Cin, Ho, Wo, stride;
 };
 
+// Epilogue options of the row GEMM: the residual may be a [res_rows, N] table indexed by
+// row % res_rows (a per-token term shared by all frames), and the output may be cut at column
+// nsplit into two dense matrices: out [M, nsplit] and out2 [M, N - nsplit] (nsplit % BN == 0).
+struct OutSplit {
+  float* out2;
+  int nsplit;
+  int res_rows;
+};
+
 // Software pipeline (one wave per SIMD, so nothing else hides latency):
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
@@ -89,7 +98,7 @@ template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g) {
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
   constexpr int BUF = P * (A_PLANE + W_PLANE);                 // one LDS buffer
@@ -309,6 +318,11 @@ __device__ __forceinline__ void gemm_split_body(
   const int ncol = n0 + wn * CW + c4 * 4;
   const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  // output segment of this column tile (block-uniform)
+  const bool seg2 = os.out2 != nullptr && n0 >= os.nsplit;
+  float* const obase = seg2 ? os.out2 : out;
+  const int ldo = os.out2 == nullptr ? N : (seg2 ? N - os.nsplit : os.nsplit);
+  const int ocol = seg2 ? ncol - os.nsplit : ncol;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -324,7 +338,8 @@ __device__ __forceinline__ void gemm_split_body(
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const long long gm = m0 + wm * TM * 32 + i * 32 + ps * RPP + lane / RV;
-        res[ps] = gm < M ? *reinterpret_cast<const float4*>(residual + gm * N + ncol)
+        const long long rr = os.res_rows ? (long long)((unsigned)gm % (unsigned)os.res_rows) : gm;
+        res[ps] = gm < M ? *reinterpret_cast<const float4*>(residual + rr * N + ncol)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -350,7 +365,7 @@ __device__ __forceinline__ void gemm_split_body(
           v.z = fmaxf(v.z, 0.f);
           v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(out + gm * N + ncol) = v;
+        *reinterpret_cast<float4*>(obase + gm * ldo + ocol) = v;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -364,15 +379,15 @@ template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os);
 }
 template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os);
 }
 
 // fp32 [n] -> nplanes bf16 planes [nplanes][n]: truncation terms, the last one rounded to
@@ -399,14 +414,15 @@ int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-ro
 template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, bool OCC2 = (P == 1)>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,
-                hipStream_t st, const ConvGeom g = ConvGeom{0, 0, 0, 0, 0, 0}) {
+                hipStream_t st, const ConvGeom g = ConvGeom{0, 0, 0, 0, 0, 0},
+                const OutSplit os = OutSplit{nullptr, 0, 0}) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int SMEM = (2 * P * (BM + BN) * RST > 4 * 32 * (TN * 32 + 4) * 4)
                            ? 2 * P * (BM + BN) * RST : 4 * 32 * (TN * 32 + 4) * 4;
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
   using kern_t = void (*)(const float*, const uint16_t*, const float*, const float*, float*, int, int,
-                          int, int, const float*, ConvGeom);
+                          int, int, const float*, ConvGeom, OutSplit);
   kern_t kern;
   if constexpr (OCC2) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV>;
   else kern = gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16, CONV>;
@@ -418,7 +434,7 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), SMEM, st, a, w, bias, residual, out,
-                     (int)M, K, N, relu, a_bias, g);
+                     (int)M, K, N, relu, a_bias, g, os);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -442,9 +458,35 @@ int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes
   return PAVE_OK;
 }
 
+static int gemm_split_entry(const float* a, const float* a_bias, const void* w_planes,
+                            const float* bias, const float* residual, float* out, long long M,
+                            int K, int N, int relu, int nplanes, void* stream, OutSplit os);
+
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
                          const float* bias, const float* residual, float* out, long long M, int K,
                          int N, int relu, int nplanes, void* stream) {
+  return gemm_split_entry(a, a_bias, w_planes, bias, residual, out, M, K, N, relu, nplanes, stream,
+                          OutSplit{nullptr, 0, 0});
+}
+
+int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_planes,
+                            const float* bias, const float* residual, long long residual_rows,
+                            float* out, float* out2, int n_split, long long M, int K, int N,
+                            int relu, int nplanes, void* stream) {
+  if (residual_rows < 0 || residual_rows >= (1ll << 31) || (residual_rows > 0 && !residual))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex: bad residual_rows");
+  if (out2 && (n_split <= 0 || n_split >= N || n_split % 128 != 0))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex: 0 < n_split < N, n_split %% 128 == 0");
+  if (out2 && residual == out)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex: in-place residual needs one output");
+  return gemm_split_entry(a, a_bias, w_planes, bias, residual, out, M, K, N, relu, nplanes, stream,
+                          OutSplit{out2, out2 ? n_split : 0,
+                                   residual_rows >= M ? 0 : (int)residual_rows});
+}
+
+static int gemm_split_entry(const float* a, const float* a_bias, const void* w_planes,
+                            const float* bias, const float* residual, float* out, long long M,
+                            int K, int N, int relu, int nplanes, void* stream, OutSplit os) {
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
@@ -457,13 +499,14 @@ int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_plan
   // P = 3: 128 x 128 tiles, two workgroups (8 waves) per CU -- one workgroup's operand split
   // (VALU) and LDS traffic overlap the other's MFMAs: 12-25 % faster than the 256 x 128 tile at
   // one wave per SIMD on every shape of the model (tools/bench_gemm_shapes.py)
+  const ConvGeom g0{0, 0, 0, 0, 0, 0};
 #define PAVE_GO(AB, P) \
   return (P == 3 && g_diag_variant != 2) \
-      ? launch_gemm<2, 2, AB, P, false, false, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st) \
-      : launch_gemm<4, 2, AB, P, false, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st)
+      ? launch_gemm<2, 2, AB, P, false, false, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os) \
+      : launch_gemm<4, 2, AB, P, false, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os)
   if (nplanes == PAVE_PLANES_FP16) {
-    if (a_bias) return launch_gemm<4, 2, true, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
-    return launch_gemm<4, 2, false, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st);
+    if (a_bias) return launch_gemm<4, 2, true, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os);
+    return launch_gemm<4, 2, false, 1, true, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os);
   }
   if (a_bias) {
     if (nplanes == 3) PAVE_GO(true, 3);

@@ -80,6 +80,42 @@ def _proj(linear, x):
     return linear(x)
 
 
+def project_values_hoisted(attns, value_bf, key_padding_mask=None):
+    """value_proj of several decoder layers over the same (constant) memory, as the modules'
+    own `project_value` would give them: [B*T, S, 8, 32] per layer.  In the split GEMM modes two
+    layers share one launch (N = 512, two dense outputs), so the memory is read once per pair."""
+    from .bricks import _split_weight, get_gemm_mode, split_gemm_ok
+    x = value_bf
+    if key_padding_mask is not None or not (x.is_cuda and x.is_contiguous()) or len(attns) < 2:
+        return [a.project_value(value_bf, key_padding_mask) for a in attns]
+    rows = x.reshape(-1, x.shape[-1])
+    outs = []
+    i = 0
+    while i < len(attns):
+        a = attns[i]
+        b = attns[i + 1] if i + 1 < len(attns) else None
+        if b is not None and a.value_proj.out_features == b.value_proj.out_features \
+                and a.value_proj.out_features % 128 == 0 \
+                and split_gemm_ok(rows, a.value_proj.weight):
+            srcs = (a.value_proj.weight, a.value_proj.bias, b.value_proj.weight, b.value_proj.bias)
+            key = tuple((p.data_ptr(), p._version) for p in srcs)
+            if getattr(a, '_pair_key', None) != key:
+                with torch.no_grad():
+                    a._pair_w = torch.cat([a.value_proj.weight, b.value_proj.weight], 0).contiguous()
+                    a._pair_b = torch.cat([a.value_proj.bias, b.value_proj.bias], 0).contiguous()
+                a._pair_key = key
+            nv = a.value_proj.out_features
+            v1, v2 = ops.gemm_bf16x3_ex(rows, _split_weight(a._pair_w), a._pair_b, n_split=nv,
+                                        fp16=get_gemm_mode() == 'fp16')
+            for m, v in ((a, v1), (b, v2)):
+                outs.append(v.view(-1, x.shape[-2], m.num_heads, nv // m.num_heads))
+            i += 2
+        else:
+            outs.append(a.project_value(value_bf, None))
+            i += 1
+    return outs
+
+
 def _fused_ok(mod, *tensors):
     """The fused kernels are built for 8 heads x 32 channels, fp32, on the device."""
     return (mod.embed_dims == 256 and mod.num_heads == 8
@@ -138,13 +174,66 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
     supports_post_norm = True
     supports_query_plus_pos = True
 
+    def _merged_proj(self):
+        """[value_proj ; sampling_offsets ; attention_weights] as one [640, 256] operand (and the
+        [384, 256] offsets / logits part alone), rebuilt when a source parameter changes."""
+        w_cat, b_cat = self._cat_proj()
+        srcs = (self.value_proj.weight, self.value_proj.bias, w_cat, b_cat)
+        key = tuple((p.data_ptr(), p._version) for p in srcs)
+        if getattr(self, '_merged_key', None) != key:
+            with torch.no_grad():
+                self._merged_w = torch.cat([self.value_proj.weight, w_cat], 0).contiguous()
+            self._merged_key = key
+        return self._merged_w, w_cat, b_cat
+
+    def _forward_merged(self, q, pos_row, reference_points, tile_levels):
+        """Self-attention over a frame batch whose positional encoding is the same for every
+        frame (no padding): (q + pos) W^T = q W^T + (pos W^T), so value_proj and the offsets /
+        logits Linears read the layer input ONCE, as one N = 640 GEMM whose epilogue adds the
+        per-token table [b_v | pos W_cat^T + b_cat] (row m -> token m % S) and writes value and
+        projections as two dense matrices.  No `query + query_pos` pass, no second read of q."""
+        from .bricks import _split_weight, get_gemm_mode
+        bs, S, C = q.shape
+        w_all, w_cat, b_cat = self._merged_proj()
+        nv = self.value_proj.out_features
+        table = torch.empty((S, w_all.shape[0]), dtype=torch.float32, device=q.device)
+        table[:, :nv] = self.value_proj.bias
+        torch.addmm(b_cat, pos_row, w_cat.t(), out=table[:, nv:])
+        v, proj = ops.gemm_bf16x3_ex(q.reshape(bs * S, C), _split_weight(w_all), None, table,
+                                     residual_rows=S, n_split=nv,
+                                     fp16=get_gemm_mode() == 'fp16')
+        ref = reference_points.reshape(1, bs * S, self.num_levels, 2)
+        if not ref.is_contiguous():
+            ref = ref.contiguous()
+        out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), proj, ref,
+                                       levels_hw=tile_levels)
+        return out.view(bs, S, self.embed_dims)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, post_norm=None, query_plus_pos=None, **kwargs):
+        self_value = value is None or value is query
         if value is None:
             value = query
         if identity is None:
             identity = query
+        tile_levels = kwargs.get('tile_levels')
+        if (self_value and query_pos is not None and query_plus_pos is None and not self.batch_first
+                and key_padding_mask is None and tile_levels is not None
+                and kwargs.get('memory_clip_index') is None and reference_points.shape[-1] == 2
+                and self.num_levels == 4 and self.num_points == 4 and query_pos.dim() == 3
+                and (query_pos.stride(1) == 0 or query_pos.shape[1] == 1)
+                and not torch.is_grad_enabled()):
+            # query_pos [S, bs, C] expanded over the frame axis: one positional table for all frames
+            from .bricks import split_gemm_ok
+            q = batch_first(query)
+            if _fused_ok(self, q) and split_gemm_ok(q.reshape(-1, q.shape[-1]),
+                                                    self.sampling_offsets.weight):
+                out = self._forward_merged(q, query_pos[:, 0], reference_points, tile_levels)
+                idt = batch_first(identity)
+                out = linear_residual_norm(out, self.output_proj, idt, post_norm,
+                                           inplace=kwargs.get('inplace_residual', False) is True)
+                return seq_first_view(out)
         if query_plus_pos is not None:   # `query + query_pos`, already made by the producer
             query = query_plus_pos
         elif query_pos is not None:

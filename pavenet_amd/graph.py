@@ -7,10 +7,13 @@ synchronise nor read device memory from the host, constant-per-shape tensors are
 device during the eager warm-up, and the only device->host copy (results) happens outside.
 
 Measured (MI355X, R-50, 800x1344, fp32): T = 3, B = 1: 19.96 ms eager -> 18.07 ms replayed.
-Validated up to 3-frame batches.  With the 28-frame headline batch (T = 7, B = 4) one capture +
-replay run ended in a GPU memory-access fault inside the replay (not reproduced eagerly, where the
-same launches run clean, and of no use there: that batch is GPU-bound, 128.0 vs 129.5 ms), so
-bench.py keeps graphs opt-in (--graph 1) until that is understood.
+
+Runtime requirement: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set by `import pavenet_amd` when it runs
+before the first HIP call).  With ROCm CLR's default graph packet capture a replay of a >= 14-frame
+capture that follows a device-wide synchronize ends in a GPU memory-access fault; the probe
+(tools/graph_fault_probe.sh, profiles/r02_graph_fault_probe.txt) shows the same capture replaying
+correctly with that one runtime flag off and faulting with it on, whatever the scratch-reclaim
+settings -- the pre-built dispatch packets, not a tensor of this package, are what goes stale.
 """
 import torch
 
@@ -18,15 +21,19 @@ import torch
 class GraphedForward:
     """``g = GraphedForward(model, example_img, img_metas); res = g(img)``.
 
-    KNOWN LIMIT: at 14+ frames of 800x1344 a replay that follows an explicit
-    ``torch.cuda.synchronize()`` faults on this ROCm stack; small batches (T = 3, B = 1) are fine.
-
     `res` is the head's fixed-shape result dict; its tensors are static buffers that the next
     call overwrites (clone what must survive)."""
 
     def __init__(self, model, example_img, img_metas, rescale=False, warmup=3, **head_kwargs):
         assert example_img.is_cuda
-        from . import ops
+        from . import GRAPH_REPLAY_SAFE, ops
+        n_frames = example_img.shape[0] * (example_img.shape[1] if example_img.dim() == 5 else 1)
+        if n_frames >= 14 and not GRAPH_REPLAY_SAFE:
+            raise RuntimeError(
+                'GraphedForward: a capture of >= 14 frames needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 '
+                'in the environment before the HIP runtime starts (import pavenet_amd before the '
+                'first torch.cuda call, or export it): with CLR graph packet capture on, a replay '
+                'after a device synchronize faults (pavenet_amd/graph.py)')
         self.model = model
         self.img_metas = img_metas
         self.static_in = example_img.clone()

@@ -31,6 +31,8 @@ SIGNATURES = {
     'pave_rows_gemm_bias_res_act_f32': [_vp] * 7 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
     'pave_bias_relu_maxpool_nhwc_f32': [_vp] * 3 + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_f32': [_vp] * 6 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
+    'pave_gemm_bf16x3_ex_f32': [_vp] * 5 + [ctypes.c_longlong, _vp, _vp, _c_int, ctypes.c_longlong]
+                               + [_c_int] * 4 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
@@ -39,7 +41,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
 
 _lib = None
-ABI_VERSION = 2  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 3  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

@@ -50,6 +50,38 @@ class ChannelMapper(BaseModule):
                 and all(m.with_norm and not m.with_activation and m.conv.bias is None
                         and isinstance(getattr(m, m.norm_name), nn.GroupNorm) for m in mods))
 
+    @staticmethod
+    def _conv_split(conv, x):
+        """1x1 convolution as a row GEMM on the NHWC map / 3x3 pad-1 convolution as an implicit
+        GEMM through the hand-written split-operand kernel, when the GEMM mode and the shape take
+        it (bricks.split_gemm_ok / split_conv_weight); None otherwise (library convolution)."""
+        from . import ops
+        from .bricks import get_gemm_mode, linear_rows, split_conv_weight, split_gemm_ok
+        if conv.groups != 1 or conv.dilation != (1, 1) or conv.bias is not None \
+                or torch.is_grad_enabled():
+            return None
+        n, c, h, w = x.shape
+        if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0):
+            xc = x.contiguous(memory_format=torch.channels_last)
+            rows = xc.permute(0, 2, 3, 1).reshape(-1, c)
+            w2 = conv.weight.flatten(1)
+            if not split_gemm_ok(rows, w2):
+                return None
+            y = linear_rows(rows, w2)
+            return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+        if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and \
+                conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
+            s_ = conv.stride[0]
+            if n * ((h - 1) // s_ + 1) * ((w - 1) // s_ + 1) < 16384:
+                return None     # too few 128-row tiles to fill 256 CUs: the library's split-K wins
+            wsplit = split_conv_weight(conv.weight)
+            if wsplit is None:
+                return None
+            xc = x.contiguous(memory_format=torch.channels_last)
+            return ops.conv3x3_split(xc, wsplit, None, stride=conv.stride[0], relu=False,
+                                     fp16=get_gemm_mode() == 'fp16')
+        return None
+
     def _forward_flat(self, inputs):
         """Same values as `forward`, but every level's GroupNorm writes straight into ONE
         [n, sum(h*w), C] buffer -- the transformer's flattened multi-level feature
@@ -59,6 +91,8 @@ class ChannelMapper(BaseModule):
         ys = []
         for m, x in zip(mods, xs):
             y = m._conv_deterministic(x) if m.deterministic else None
+            if y is None:
+                y = self._conv_split(m.conv, x)     # split / 16-bit GEMM modes: in-tree kernels
             y = m.conv(x) if y is None else y
             ys.append(y.contiguous(memory_format=torch.channels_last))
         n, C = ys[0].shape[0], ys[0].shape[1]

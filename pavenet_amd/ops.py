@@ -519,6 +519,48 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_split=0, relu=False,
+                   a_bias=None, fp16=False):
+    """gemm_bf16x3 with a row-periodic residual table (`residual` [residual_rows, N], row m adds
+    residual[m % residual_rows]) and / or the output cut at column `n_split` into two dense
+    matrices -> out [M, n_split], out2 [M, N - n_split] (n_split = 0: one output, out2 = None)."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(not fp16 or w_planes.shape[1] == 1, 'gemm_bf16x3_ex: fp16 takes a single plane')
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
+             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+             'gemm_bf16x3_ex: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
+    M, K = a.shape
+    N = w_planes.shape[2]
+    _require(N % 128 == 0, 'gemm_bf16x3_ex: N % 128 == 0')
+    for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
+        if t is not None:
+            _dev(t, nm, torch.float32)
+            _require(t.numel() == n, f'gemm_bf16x3_ex: {nm} has {t.numel()} elements, expected {n}')
+    rr = int(residual_rows)
+    if residual is not None:
+        _dev(residual, 'residual', torch.float32)
+        _require(tuple(residual.shape) == ((rr if rr > 0 else M), N),
+                 'gemm_bf16x3_ex: residual [residual_rows or M, N]')
+    else:
+        _require(rr == 0, 'gemm_bf16x3_ex: residual_rows without a residual')
+    n_split = int(n_split)
+    _require(n_split == 0 or (0 < n_split < N and n_split % 128 == 0),
+             'gemm_bf16x3_ex: 0 < n_split < N, n_split % 128 == 0')
+    out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
+    out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
+        st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
+                                         ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
+                                         M, K, N, int(bool(relu)),
+                                         PLANES_FP16 if fp16 else int(w_planes.shape[1]),
+                                         _stream_ptr())
+    native.check(st, 'gemm_bf16x3_ex')
+    return out, out2
+
+
 def split_conv3x3_weight(weight, planes=3):
     """Conv2d weight [Cout, Cin, 3, 3] -> the operand of `conv3x3_split`: rows [Cout, (ky, kx, cin)]
     split and re-laid by `split_weight_bf16x3`."""

@@ -23,7 +23,8 @@ from .bricks import (BaseModule, TransformerLayerSequence, batch_first, inverse_
                      layer_norm_any_layout, seq_first_view, xavier_init)
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
-                          MultiScaleDeformableAttention, frame_prefixes)
+                          MultiScaleDeformableAttention, frame_prefixes,
+                          project_values_hoisted)
 from .locality import encoder_unit_order
 from .registry import (MMCV_TRANSFORMER, MMCV_TRANSFORMER_LAYER_SEQUENCE, TRANSFORMER,
                        TRANSFORMER_LAYER_SEQUENCE, build_transformer_layer_sequence)
@@ -526,8 +527,8 @@ class VideoPoseTransformerMulFrames(Transformer):
         if self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
                 for l in self.decoder.layers):
-            dec_kwargs['values_projected'] = [
-                l.attentions[-1].project_value(memory, attn_mask) for l in self.decoder.layers]
+            dec_kwargs['values_projected'] = project_values_hoisted(
+                [l.attentions[-1] for l in self.decoder.layers], memory, attn_mask)
         inter_states, inter_references = self.decoder(
             query=seq_first_view(query.contiguous()), key=None, value=seq_first_view(memory),
             query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
@@ -579,9 +580,8 @@ class VideoPoseTransformerMulFrames(Transformer):
         if self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformableAttention)
                 for l in self.refine_decoder.layers):
-            dec_kwargs['values_projected'] = [
-                l.attentions[-1].project_value(mem_bt, attn_mask)
-                for l in self.refine_decoder.layers]
+            dec_kwargs['values_projected'] = project_values_hoisted(
+                [l.attentions[-1] for l in self.refine_decoder.layers], mem_bt, attn_mask)
         inter_states, inter_references = self.refine_decoder(
             query=seq_first_view(query.contiguous()), key=None, value=memory,
             query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,

@@ -79,6 +79,37 @@ def test_encoder_msda_module(golden_dir):
     np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
 
 
+def test_encoder_msda_shared_pos_merged_projection_vs_oracle(gemm_mode):
+    """Un-padded frame batch: the positional table is one [S, C] tensor expanded over the frames,
+    and (in the split GEMM modes) value_proj + offsets + logits run as ONE N = 640 launch with the
+    pos term folded into a per-token epilogue table.  Against the oracle's un-fused module."""
+    from pavenet_amd import bricks
+    from pavenet_amd.deform_attn import MultiScaleDeformableAttention
+    from pavenet_amd.transformer import VideoPoseTransformerMulFrames as VT
+    hw = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    S, bs = sum(h * w for h, w in hw), 3
+    m = _seed(MultiScaleDeformableAttention(embed_dims=256)).eval()
+    sd = {'a.' + k: v for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    query = torch.randn(S, bs, 256, generator=g)
+    pos = torch.randn(S, 1, 256, generator=g).expand(S, bs, 256)
+    shapes = torch.as_tensor(hw, dtype=torch.long)
+    vr = torch.ones(bs, 4, 2)
+    ref = VT.get_reference_points(hw, vr, device='cpu')
+    with torch.no_grad():
+        exp = R.msda_module(sd, 'a', query, pos, None, ref, shapes, _lsi(shapes))
+        md = m.cuda()
+        qd = query.transpose(0, 1).contiguous().cuda().transpose(0, 1)    # seq-first view
+        posd = pos[:, :1].cuda().expand(S, bs, 256)
+        made = bricks._SPLIT_STATS['made']
+        out = md(qd, None, None, query_pos=posd, key_padding_mask=None,
+                 reference_points=ref.cuda(), spatial_shapes=shapes.cuda(),
+                 level_start_index=_lsi(shapes).cuda(), tile_levels=hw)
+    if gemm_mode != 'native':
+        assert hasattr(md, '_merged_w') and bricks._SPLIT_STATS['made'] > made   # merged path ran
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=5e-5)
+
+
 def test_pose_single_module(golden_dir):
     from pavenet_amd.deform_attn import MultiScaleDeformablePoseAttention
     g = _g(golden_dir, 'mod_pose_single')

@@ -496,6 +496,35 @@ def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('M,K,N,rows,nsplit', [(1000, 256, 640, 125, 256), (777, 64, 384, 0, 128),
+                                               (300, 128, 256, 7, 0), (513, 256, 512, 0, 256)])
+def test_gemm_bf16x3_ex_row_table_and_two_outputs(M, K, N, rows, nsplit):
+    """pave_gemm_bf16x3_ex_f32: residual as a [rows, N] table indexed by m % rows, output cut at
+    column nsplit into two dense matrices -- against fp64."""
+    from pavenet_amd.ops import gemm_bf16x3_ex, split_weight_bf16x3
+    g = torch.Generator().manual_seed(M + K + N + rows)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(rows if rows else M, N, generator=g)
+    wp = split_weight_bf16x3(w.cuda())
+    exp = a.double() @ w.double().t() + b.double()
+    exp = exp + (r.double()[torch.arange(M) % rows] if rows else r.double())
+    o1, o2 = gemm_bf16x3_ex(a.cuda(), wp, b.cuda(), r.cuda(), residual_rows=rows, n_split=nsplit)
+    if nsplit:
+        assert tuple(o1.shape) == (M, nsplit) and tuple(o2.shape) == (M, N - nsplit)
+        assert o1.is_contiguous() and o2.is_contiguous()
+        got = torch.cat([o1, o2], 1)
+    else:
+        assert o2 is None
+        got = o1
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        gemm_bf16x3_ex(a.cuda(), wp, None, None, n_split=64)          # not a multiple of 128
+    with pytest.raises(RuntimeError):
+        gemm_bf16x3_ex(a.cuda(), wp, None, r.cuda()[:3], residual_rows=5)   # table shape
+
+
 @pytest.mark.parametrize('planes,rel', [(1, 6e-3), (2, 4e-5), (16, 8e-4)])
 def test_gemm_bf16_split_reduced_planes(planes, rel):
     """1 plane = plain bf16 operands (round to nearest), 2 planes ~ 16 significand bits: the error
