@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 3
+#define PAVE_ABI_VERSION 4
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -256,6 +256,17 @@ int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_p
                             const float* bias, const float* residual, long long residual_rows,
                             float* out, float* out2, int n_split, long long M, int K, int N,
                             int relu, int nplanes, void* stream);
+
+/*
+ * out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta  (3 bf16 planes, N == 256): the
+ * attention / FFN output Linear, its residual add and the post-norm of a BaseTransformerLayer
+ * (third_party/mmcv/mmcv/cnn/bricks/transformer.py:1316-1353) in ONE launch -- a 128 x 256 block
+ * tile owns whole rows, the row statistics are completed across its waves through LDS (two-pass
+ * mean / centred variance).  residual may be NULL or alias out.  K %% 64 == 0.
+ */
+int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
+                            const float* residual, const float* gamma, const float* beta, float eps,
+                            float* out, long long M, int K, int N, void* stream);
 
 /*
  * 3x3 / pad 1 / stride 1|2 convolution, NHWC fp32 in and out, as an implicit GEMM through the same

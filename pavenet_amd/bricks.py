@@ -113,7 +113,7 @@ def _fusable(*tensors):
 # measured SLOWER on the bench workload (122.4 vs 121.1 ms/step: the extra 640 MB store costs more
 # than the broadcast add it saves), so it is off unless PAVE_POS_FUSION=1.
 FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
-_GEMM = {'mode': 'native', 'min_rows': 8192}
+_GEMM = {'mode': 'native', 'min_rows': 8192, 'ln_fused': True}
 
 
 _PLANES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'fp16': 16}   # 16 = ops.PLANES_FP16
@@ -225,6 +225,15 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
         from . import ops
         idt2 = identity_bf.reshape(-1, C_out)
         x2 = x_bf.reshape(-1, x_bf.shape[-1])
+        if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and post_norm is not None
+                and pos_rows is None and C_out == 256 and tuple(post_norm.normalized_shape) == (256,)
+                and post_norm.weight is not None and post_norm.bias is not None
+                and split_gemm_ok(x2, linear.weight)):
+            # Linear + bias + residual + LayerNorm as ONE launch (the block tile owns whole rows)
+            t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, idt2,
+                                   post_norm.weight, post_norm.bias, post_norm.eps,
+                                   out=idt2 if inplace else None)
+            return t.view(identity_bf.shape)
         if split_gemm_ok(x2, linear.weight):
             t = linear_rows(x2, linear.weight, None, residual=idt2, inplace_residual=inplace)
         elif inplace:  # caller guarantees nobody else reads identity: no copy of C into D

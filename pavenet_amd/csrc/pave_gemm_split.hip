@@ -90,29 +90,42 @@ struct OutSplit {
   int res_rows;
 };
 
+// LayerNorm over the output row fused into the epilogue (LNORM forms: the block tile spans the
+// whole row, N == BN): out = LN(acc + bias + residual) * gamma + beta.
+struct LnArgs {
+  const float* gamma;
+  const float* beta;
+  float eps;
+};
+
 // Software pipeline (one wave per SIMD, so nothing else hides latency):
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
 //   slab s's MFMAs, into a second fragment register set.
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, int WGN, bool LNORM>
 __device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
-  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  constexpr int NT = 128 * WGN, NW = 2 * WGN;                  // threads, waves (2 x WGN grid)
+  constexpr int BM = 2 * TM * 32, BN = WGN * TN * 32;
   constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
   constexpr int BUF = P * (A_PLANE + W_PLANE);                 // one LDS buffer
-  constexpr int SMEM = (2 * BUF > 4 * 32 * (TN * 32 + 4) * 4) ? 2 * BUF : 4 * 32 * (TN * 32 + 4) * 4;
-  constexpr int APASS = BM / 64;   // float4 loads of A per thread per slab (4 threads per row)
+  constexpr int EPI = NW * 32 * (TN * 32 + 4) * 4 + (LNORM ? 2 * BM * WGN * 4 : 0);
+  constexpr int SMEM = (2 * BUF > EPI) ? 2 * BUF : EPI;
+  constexpr int AROWS = NT / 4;           // A rows staged per pass (4 threads per row)
+  constexpr int APASS = BM / AROWS;       // float4 loads of A per thread per slab
   constexpr int WN = P * BN * 2;          // uint4 loads of W per slab (2 per row-plane)
-  constexpr int WV = (WN + 255) / 256;    // per thread (the last round may be partial)
+  constexpr int WV = (WN + NT - 1) / NT;  // per thread (the last round may be partial)
+  static_assert(BM % AROWS == 0 && APASS >= 1, "A staging: whole passes");
+  static_assert(!LNORM || (!CONV && !F16), "LayerNorm epilogue: plain row GEMM only");
   static_assert(!(CONV && ABIAS), "the convolution form has no A-side bias");
   static_assert(!F16 || P == 1, "fp16 operands: single plane only");
   static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, kh = lane >> 5;
   const int ntiles = N / BN;
   // XCD-aware bijective remap: the hardware deals workgroups round-robin over the 8 XCDs; give
@@ -131,7 +144,7 @@ __device__ __forceinline__ void gemm_split_body(
   int iy0[APASS], ix0[APASS];   // CONV: top-left input pixel of the row's 3x3 window
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
-    long long r = m0 + (tid >> 2) + 64 * q;
+    long long r = m0 + (tid >> 2) + AROWS * q;
     if (r >= M) r = M - 1;  // clamp: rows past M are computed on stand-in data, never stored
     if (CONV) {
       const unsigned ur = (unsigned)r, gy = ur / (unsigned)g.Wo;
@@ -146,12 +159,12 @@ __device__ __forceinline__ void gemm_split_body(
     }
   }
   // W operand, slab-major [K/16][3][N][16] bf16 (host layout: one slab of a column tile is 3
-  // contiguous 4-KiB runs): uint4 index v = tid + 256*q -> plane, row, 16-byte half
+  // contiguous 4-KiB runs): uint4 index v = tid + NT*q -> plane, row, 16-byte half
   const uint16_t* w_ptr[WV];
   int w_dst[WV];
 #pragma unroll
   for (int q = 0; q < WV; ++q) {
-    const int v = (tid + 256 * q) < WN ? tid + 256 * q : 0;   // spare threads of a partial round
+    const int v = (tid + NT * q) < WN ? tid + NT * q : 0;   // spare threads of a partial round
     const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);   // repeat item 0
     w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * P*N*16
     w_dst[q] = P * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
@@ -221,7 +234,7 @@ __device__ __forceinline__ void gemm_split_body(
       }
       uint2 pl[P];
       split4<P, F16>(t, pl);
-      const int d = ((tid >> 2) + 64 * q) * RST + a_seg * 8;
+      const int d = ((tid >> 2) + AROWS * q) * RST + a_seg * 8;
 #pragma unroll
       for (int t2 = 0; t2 < P; ++t2) *reinterpret_cast<uint2*>(buf + t2 * A_PLANE + d) = pl[t2];
     }
@@ -311,7 +324,7 @@ __device__ __forceinline__ void gemm_split_body(
   constexpr int RV = CW / 4;             // float4 per chunk row
   constexpr int RPP = 64 / RV;           // rows per pass of the wave
   constexpr int NPASS = 32 / RPP;
-  static_assert(4 * 32 * CST * 4 <= SMEM, "epilogue chunks must fit the operand buffers");
+  static_assert(NW * 32 * CST * 4 <= SMEM, "epilogue chunks must fit the operand buffers");
   __syncthreads();  // operand tiles fully consumed by every wave
   float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * CST;
   const int c4 = lane % RV;
@@ -343,6 +356,65 @@ __device__ __forceinline__ void gemm_split_body(
                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    if constexpr (LNORM) {
+      // v = acc + bias + residual for this wave's 64-column share of 32 rows; the row statistics
+      // are completed across the WGN waves of the row through LDS (two passes: mean, then the
+      // centred sum of squares -- no E[x^2] - mean^2 cancellation)
+      float* st1 = reinterpret_cast<float*>(smem) + NW * 32 * CST;   // [BM][WGN] partial sums
+      float* st2 = st1 + BM * WGN;                                     // [BM][WGN] partial M2
+      const float4 g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
+      const float4 be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
+      float4 v[NPASS];
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int lrow = ps * RPP + lane / RV;
+        const long long gm = m0 + wm * TM * 32 + i * 32 + lrow;
+        float4 t = *reinterpret_cast<const float4*>(Cs + lrow * CST + c4 * 4);
+        t.x += b4.x, t.y += b4.y, t.z += b4.z, t.w += b4.w;
+        if (residual) t.x += res[ps].x, t.y += res[ps].y, t.z += res[ps].z, t.w += res[ps].w;
+        if (gm >= M) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[ps] = t;
+        float sm = (t.x + t.y) + (t.z + t.w);
+#pragma unroll
+        for (int o = RV / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        if (c4 == 0) st1[(wm * TM * 32 + i * 32 + lrow) * WGN + wn] = sm;
+      }
+      __syncthreads();
+      float mean[NPASS];
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int brow = wm * TM * 32 + i * 32 + ps * RPP + lane / RV;
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGN; ++w) sm += st1[brow * WGN + w];
+        mean[ps] = sm * (1.f / (float)BN);
+        float4& t = v[ps];
+        t.x -= mean[ps], t.y -= mean[ps], t.z -= mean[ps], t.w -= mean[ps];
+        float q = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+#pragma unroll
+        for (int o = RV / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (c4 == 0) st2[brow * WGN + wn] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int lrow = ps * RPP + lane / RV;
+        const int brow = wm * TM * 32 + i * 32 + lrow;
+        const long long gm = m0 + brow;
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGN; ++w) q += st2[brow * WGN + w];
+        const float rstd = rsqrtf(q * (1.f / (float)BN) + ln.eps);
+        if (gm < M) {
+          float4 t = v[ps];
+          t.x = fmaf(t.x * rstd, g4.x, be4.x);
+          t.y = fmaf(t.y * rstd, g4.y, be4.y);
+          t.z = fmaf(t.z * rstd, g4.z, be4.z);
+          t.w = fmaf(t.w * rstd, g4.w, be4.w);
+          *reinterpret_cast<float4*>(out + gm * N + ncol) = t;
+        }
+      }
+    } else
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int lrow = ps * RPP + lane / RV;
@@ -379,15 +451,28 @@ template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                         a_bias, g, os, ln);
 }
 template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                         a_bias, g, os, ln);
+}
+// 128 x 256 block tile, 8 waves (2 x 4), one workgroup per CU at two waves per SIMD: the A tile
+// is split (VALU) and staged once for twice the MFMA work of the 128 x 128 form, and with N == 256
+// the block owns whole output rows, so LayerNorm can run in the epilogue (LNORM).
+template <int TM, int TN, bool ABIAS, int P, bool CONV, bool LNORM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_w8(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, false, CONV, 4, LNORM>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                           a_bias, g, os, ln);
 }
 
 // fp32 [n] -> nplanes bf16 planes [nplanes][n]: truncation terms, the last one rounded to
@@ -409,22 +494,37 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   }
 }
 
-int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms
+int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
+                         // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never
 
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, bool OCC2 = (P == 1)>
+// Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
+bool use_w8(long long M, int K, int N) {
+  if (N % 256 != 0 || g_diag_variant == 4 || g_diag_variant == 2) return false;
+  if (g_diag_variant == 3) return true;
+  (void)M;
+  (void)K;
+  return false;
+}
+
+template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, bool OCC2 = (P == 1), int WGN = 2,
+          bool LNORM = false>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,
                 hipStream_t st, const ConvGeom g = ConvGeom{0, 0, 0, 0, 0, 0},
-                const OutSplit os = OutSplit{nullptr, 0, 0}) {
-  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-  constexpr int SMEM = (2 * P * (BM + BN) * RST > 4 * 32 * (TN * 32 + 4) * 4)
-                           ? 2 * P * (BM + BN) * RST : 4 * 32 * (TN * 32 + 4) * 4;
+                const OutSplit os = OutSplit{nullptr, 0, 0},
+                const LnArgs ln = LnArgs{nullptr, nullptr, 0.f}) {
+  constexpr int NT = 128 * WGN, NW = 2 * WGN;
+  constexpr int BM = 2 * TM * 32, BN = WGN * TN * 32;
+  constexpr int EPI = NW * 32 * (TN * 32 + 4) * 4 + (LNORM ? 2 * BM * WGN * 4 : 0);
+  constexpr int SMEM = (2 * P * (BM + BN) * RST > EPI) ? 2 * P * (BM + BN) * RST : EPI;
+  static_assert(WGN == 2 || (WGN == 4 && !F16), "wave grids: 2 x 2 or 2 x 4");
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
   using kern_t = void (*)(const float*, const uint16_t*, const float*, const float*, float*, int, int,
-                          int, int, const float*, ConvGeom, OutSplit);
+                          int, int, const float*, ConvGeom, OutSplit, LnArgs);
   kern_t kern;
-  if constexpr (OCC2) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV>;
+  if constexpr (WGN == 4) kern = gemm_bf16x3_kernel_w8<TM, TN, ABIAS, P, CONV, LNORM>;
+  else if constexpr (OCC2) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV>;
   else kern = gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -433,8 +533,8 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_bf16x3: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), SMEM, st, a, w, bias, residual, out,
-                     (int)M, K, N, relu, a_bias, g, os);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NT), SMEM, st, a, w, bias, residual, out,
+                     (int)M, K, N, relu, a_bias, g, os, ln);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -500,6 +600,12 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
   // (VALU) and LDS traffic overlap the other's MFMAs: 12-25 % faster than the 256 x 128 tile at
   // one wave per SIMD on every shape of the model (tools/bench_gemm_shapes.py)
   const ConvGeom g0{0, 0, 0, 0, 0, 0};
+  // 128 x 256 tile on 8 waves where the shape allows it and it wins (see use_w8)
+  if (nplanes == 3 && use_w8(M, K, N) && (!os.out2 || os.nsplit % 256 == 0)) {
+    if (a_bias)
+      return launch_gemm<2, 2, true, 3, false, false, true, 4>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os);
+    return launch_gemm<2, 2, false, 3, false, false, true, 4>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os);
+  }
 #define PAVE_GO(AB, P) \
   return (P == 3 && g_diag_variant != 2) \
       ? launch_gemm<2, 2, AB, P, false, false, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g0, os) \
@@ -517,6 +623,21 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
   if (nplanes == 2) PAVE_GO(false, 2);
   PAVE_GO(false, 1);
 #undef PAVE_GO
+}
+
+int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
+                            const float* residual, const float* gamma, const float* beta, float eps,
+                            float* out, long long M, int K, int N, void* stream) {
+  if (!a || !w_planes || !out || !gamma || !beta)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: null pointer");
+  if (M <= 0 || K <= 0 || M >= (1ll << 31))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: bad sizes (0 < M < 2^31)");
+  if (K % 64 != 0 || N != 256)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_ln: K %% 64 == 0 and N == 256 required");
+  return launch_gemm<2, 2, false, 3, false, false, true, 4, true>(
+      a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, nullptr,
+      reinterpret_cast<hipStream_t>(stream), ConvGeom{0, 0, 0, 0, 0, 0}, OutSplit{nullptr, 0, 0},
+      LnArgs{gamma, beta, eps});
 }
 
 void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tools/)

@@ -519,6 +519,41 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
+    """out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta in ONE launch (3 bf16
+    planes; the 128 x 256 block tile owns whole rows).  `residual` may be None or the tensor given
+    as `out`."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3
+             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+             'gemm_bf16x3_ln: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3, 3 planes)')
+    M, K = a.shape
+    N = w_planes.shape[2]
+    _require(N == 256, 'gemm_bf16x3_ln: N == 256')
+    for t, nm in ((bias, 'bias'), (gamma, 'gamma'), (beta, 'beta')):
+        if t is not None:
+            _dev(t, nm, torch.float32)
+            _require(t.numel() == N, f'gemm_bf16x3_ln: {nm} has {t.numel()} elements, expected {N}')
+    _require(gamma is not None and beta is not None, 'gemm_bf16x3_ln: gamma and beta are required')
+    if residual is not None:
+        _dev(residual, 'residual', torch.float32)
+        _require(tuple(residual.shape) == (M, N), 'gemm_bf16x3_ln: residual [M,N]')
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _dev(out, 'out', torch.float32)
+        _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_ln: out [M,N]')
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln'):
+        st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
+                                         gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                         out.data_ptr(), M, K, N, _stream_ptr())
+    native.check(st, 'gemm_bf16x3_ln')
+    return out
+
+
 def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_split=0, relu=False,
                    a_bias=None, fp16=False):
     """gemm_bf16x3 with a row-periodic residual table (`residual` [residual_rows, N], row m adds

@@ -525,6 +525,67 @@ def test_gemm_bf16x3_ex_row_table_and_two_outputs(M, K, N, rows, nsplit):
         gemm_bf16x3_ex(a.cuda(), wp, None, r.cuda()[:3], residual_rows=5)   # table shape
 
 
+@pytest.mark.parametrize('M,K', [(1000, 256), (257, 1024), (5, 64), (4100, 256)])
+def test_gemm_bf16x3_layernorm_epilogue_vs_fp64(M, K):
+    """pave_gemm_bf16x3_ln_f32 = LayerNorm(a W^T + bias + residual) gamma + beta in one launch,
+    against the fp64 formulation; also in place over the residual, and without a residual."""
+    from pavenet_amd.ops import gemm_bf16x3_ln, split_weight_bf16x3
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) * 2 + 0.5          # non-zero row means
+    gam, bet = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    wp = split_weight_bf16x3(w.cuda())
+    pre = a.double() @ w.double().t() + b.double() + r.double()
+    exp = torch.nn.functional.layer_norm(pre, (N,), gam.double(), bet.double(), 1e-5)
+    out = gemm_bf16x3_ln(a.cuda(), wp, b.cuda(), r.cuda(), gam.cuda(), bet.cuda(), 1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+    idt = r.cuda()
+    out = gemm_bf16x3_ln(a.cuda(), wp, b.cuda(), idt, gam.cuda(), bet.cuda(), 1e-5, out=idt)
+    assert out.data_ptr() == idt.data_ptr()
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+    pre = a.double() @ w.double().t()
+    exp = torch.nn.functional.layer_norm(pre, (N,), gam.double(), bet.double(), 1e-3)
+    out = gemm_bf16x3_ln(a.cuda(), wp, None, None, gam.cuda(), bet.cuda(), 1e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        gemm_bf16x3_ln(a.cuda(), split_weight_bf16x3(torch.randn(128, K).cuda()), None, None,
+                       gam.cuda()[:128], bet.cuda()[:128], 1e-5)     # N != 256
+
+
+@pytest.mark.parametrize('M,K,N', [(1000, 256, 1024), (300, 1024, 256), (129, 64, 512)])
+def test_gemm_bf16x3_eight_wave_tile_equals_four_wave_tile(M, K, N):
+    """The 128 x 256 / 8-wave tile form (tools switch) gives the same numbers as the 128 x 128
+    form: same products, same accumulation order per output element -> bit-identical."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import gemm_bf16x3, gemm_bf16x3_ex, split_weight_bf16x3
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K**0.5).cuda()
+    b, r, ab = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda(), \
+        torch.randn(K, generator=g).cuda()
+    wp = split_weight_bf16x3(w)
+    lib = native.load()
+    try:
+        lib.pave_diag_gemm_variant(4)
+        ref = gemm_bf16x3(a, wp, b, r, relu=True, a_bias=ab)
+        ref2 = gemm_bf16x3_ex(a, wp, b, r[:7].contiguous(), residual_rows=7, n_split=256) \
+            if N > 256 else None
+        lib.pave_diag_gemm_variant(3)
+        got = gemm_bf16x3(a, wp, b, r, relu=True, a_bias=ab)
+        got2 = gemm_bf16x3_ex(a, wp, b, r[:7].contiguous(), residual_rows=7, n_split=256) \
+            if N > 256 else None
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    assert torch.equal(ref, got)
+    if ref2 is not None:
+        assert torch.equal(ref2[0], got2[0]) and torch.equal(ref2[1], got2[1])
+    exact = torch.relu(torch.relu(a + ab).double() @ w.double().t() + b.double() + r.double())
+    np.testing.assert_allclose(got.cpu().numpy(), exact.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('planes,rel', [(1, 6e-3), (2, 4e-5), (16, 8e-4)])
 def test_gemm_bf16_split_reduced_planes(planes, rel):
     """1 plane = plain bf16 operands (round to nearest), 2 planes ~ 16 significand bits: the error

@@ -73,10 +73,22 @@ def main():
             from pavenet_amd import native
             native.load().pave_diag_gemm_variant(2)
             ms3b = timed(f3)
+            ms8 = float('nan')
+            if N % 256 == 0:
+                native.load().pave_diag_gemm_variant(3)
+                ms8 = timed(f3)
             native.load().pave_diag_gemm_variant(0)
             print(f'   {label}: library {ms:.3f} ms ({2.0 * M * K * N / ms / 1e9:.0f} TF/s)   '
                   f'bf16x3 split {ms3:.3f} ms ({2.0 * M * K * N / ms3 / 1e9:.0f} TF/s)   '
-                  f'256-row tile, 1 wave/SIMD {ms3b:.3f} ms ({2.0 * M * K * N / ms3b / 1e9:.0f} TF/s)')
+                  f'256-row tile, 1 wave/SIMD {ms3b:.3f} ms ({2.0 * M * K * N / ms3b / 1e9:.0f} TF/s)   '
+                  f'128x256 tile, 8 waves {ms8:.3f} ms ({2.0 * M * K * N / ms8 / 1e9:.0f} TF/s)')
+            if N == 256 and kind == 'res':
+                gam, bet = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+                sep = timed(lambda: ops.bias_add_layernorm(
+                    ops.gemm_bf16x3(a, wp, None, c, relu=False, out=c), bias, None, gam, bet, 1e-5))
+                fus = timed(lambda: ops.gemm_bf16x3_ln(a, wp, bias, c, gam, bet, 1e-5, out=c))
+                print(f'   {label}: split GEMM + LayerNorm pass {sep:.3f} ms   '
+                      f'LayerNorm in the GEMM epilogue {fus:.3f} ms')
         own = float('nan')
         if kind == 'res' and 'conv3' in label:
             wkn = wt.t().contiguous()
