@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 4
+#define PAVE_ABI_VERSION 6
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -256,6 +256,29 @@ int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_p
                             const float* bias, const float* residual, long long residual_rows,
                             float* out, float* out2, int n_split, long long M, int K, int N,
                             int relu, int nplanes, void* stream);
+
+/*
+ * out[i] = sigmoid(tmp[i] + inverse_sigmoid(ref[i])), inverse_sigmoid(x) = log(max(clamp(x, 0, 1),
+ * eps) / max(1 - clamp(x, 0, 1), eps)): the per-layer reference-point update of the pose / joint
+ * decoders (opera/models/utils/transformer.py:6733-6735,
+ * third_party/mmdetection/mmdet/models/utils/transformer.py:865-866) as one launch.
+ */
+int pave_ref_update_f32(const float* tmp, const float* ref, float* out, long long n, float eps,
+                        void* stream);
+
+/*
+ * GroupNorm of an NHWC map x [N, HW, C] (G groups of C/G consecutive channels), y = GN(x) * gamma +
+ * beta written to y + n * y_batch_stride + (hw * C + c): the destination may be a slice of a larger
+ * [N, S, C] token buffer (the neck's conv -> GN levels land directly in the transformer's flattened
+ * multi-level feature, third_party/mmdetection/mmdet/models/necks/channel_mapper.py:90-100 +
+ * opera/models/utils/transformer.py:21312-21331).  Statistics are accumulated in fp64 in a fixed
+ * order (bit-reproducible).  Scratch supplied by the caller: partial [N * nchunks * G * 2] doubles
+ * (nchunks = number of row chunks the statistics pass is cut into), ab [N * 2 * C] floats.
+ * C %% 4 == 0, (C / G) %% 4 == 0, C / 4 divides 256.
+ */
+int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y,
+                            long long y_batch_stride, int N, int HW, int C, int G, float eps,
+                            double* partial, int nchunks, float* ab, void* stream);
 
 /*
  * out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta  (3 bf16 planes, N == 256): the

@@ -33,6 +33,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned load
 
 constexpr int BK = 16;          // K slab = one MFMA k-step
 constexpr int RST = 48;         // LDS row stride in bytes: 32 B of bf16 + 16 B pad (the 16 lanes
@@ -102,7 +103,7 @@ struct LnArgs {
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
 //   slab s's MFMAs, into a second fragment register set.
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, int WGN, bool LNORM>
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, int WGN, bool LNORM>
 __device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -118,8 +119,8 @@ __device__ __forceinline__ void gemm_split_body(
   constexpr int WN = P * BN * 2;          // uint4 loads of W per slab (2 per row-plane)
   constexpr int WV = (WN + NT - 1) / NT;  // per thread (the last round may be partial)
   static_assert(BM % AROWS == 0 && APASS >= 1, "A staging: whole passes");
-  static_assert(!LNORM || (!CONV && !F16), "LayerNorm epilogue: plain row GEMM only");
-  static_assert(!(CONV && ABIAS), "the convolution form has no A-side bias");
+  static_assert(!LNORM || (CONV == 0 && !F16), "LayerNorm epilogue: plain row GEMM only");
+  static_assert(!(CONV != 0 && ABIAS), "the convolution forms have no A-side bias");
   static_assert(!F16 || P == 1, "fp16 operands: single plane only");
   static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -146,14 +147,15 @@ __device__ __forceinline__ void gemm_split_body(
   for (int q = 0; q < APASS; ++q) {
     long long r = m0 + (tid >> 2) + AROWS * q;
     if (r >= M) r = M - 1;  // clamp: rows past M are computed on stand-in data, never stored
-    if (CONV) {
+    if (CONV != 0) {
       const unsigned ur = (unsigned)r, gy = ur / (unsigned)g.Wo;
       const int ox = (int)(ur - gy * (unsigned)g.Wo);
       const int n = (int)(gy / (unsigned)g.Ho);
       const int oy = (int)(gy - (unsigned)n * (unsigned)g.Ho);
-      iy0[q] = oy * g.stride - 1;
-      ix0[q] = ox * g.stride - 1;
-      a_ptr[q] = A + (long long)n * g.H * g.W * g.Cin + a_seg * 4;   // image base
+      const int pad = CONV == 2 ? 3 : 1;
+      iy0[q] = oy * g.stride - pad;
+      ix0[q] = ox * g.stride - pad;
+      a_ptr[q] = A + (long long)n * g.H * g.W * g.Cin + (CONV == 2 ? 0 : a_seg * 4);   // image base
     } else {
       a_ptr[q] = A + r * K + a_seg * 4;
     }
@@ -190,7 +192,35 @@ __device__ __forceinline__ void gemm_split_body(
   auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rw)[2][WV], f32x4 (&rb)[2]) {
     const int pp = pair < npairs ? pair : npairs - 1;  // past the end: repeat (never consumed)
     const int k0 = pp * 2 * BK;
-    if (CONV) {
+    if (CONV == 2) {
+      // 7x7 / stride 2 / pad 3 stem on the NCHW image: K axis = (c, ky, kx padded 7 -> 8), i.e. 24
+      // rows of 8 (21 real); a thread's float4 is one half of such a row: 4 consecutive input
+      // pixels of channel c, row iy -- an unaligned 16-byte load (per-element guarded at the edges)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k4 = k0 + h * BK + a_seg * 4;
+        const int rowid = k4 >> 3, xh = (k4 >> 2) & 1;
+        const int c = (rowid * 37) >> 8;          // rowid / 7 for rowid < 32
+        const int ky = rowid - 7 * c;
+#pragma unroll
+        for (int q = 0; q < APASS; ++q) {
+          const int iy = iy0[q] + ky, ix = ix0[q] + 4 * xh;
+          const bool rowok = rowid < 21 && iy >= 0 && iy < g.H;
+          const float* src = a_ptr[q] + ((long long)(c * g.H + iy) * g.W + ix);
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (rowok && ix >= 0 && ix + 4 <= g.W) {
+            t = *reinterpret_cast<const f32x4_u*>(src);
+          } else if (rowok) {
+            if (ix + 0 >= 0 && ix + 0 < g.W) t.x = src[0];
+            if (ix + 1 >= 0 && ix + 1 < g.W) t.y = src[1];
+            if (ix + 2 >= 0 && ix + 2 < g.W) t.z = src[2];
+            if (ix + 3 >= 0 && ix + 3 < g.W) t.w = src[3];
+          }
+          if (xh) t.w = 0.f;                      // kx = 7: the pad column of the 8-wide row
+          ra[h][q] = t;
+        }
+      }
+    } else if (CONV == 1) {
       const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // a pair (32 k) lies inside one tap
       const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
@@ -447,7 +477,7 @@ __device__ __forceinline__ void gemm_split_body(
 
 // P = 3 needs the whole register file of a SIMD (one wave each); with fewer planes two workgroups
 // fit a CU, which the bandwidth-bound P = 1 form wants.
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false>(A, Wp, bias, residual, out, M, K, N, relu,
                                                          a_bias, g, os, ln);
 }
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV>
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -466,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 128 x 256 block tile, 8 waves (2 x 4), one workgroup per CU at two waves per SIMD: the A tile
 // is split (VALU) and staged once for twice the MFMA work of the 128 x 128 form, and with N == 256
 // the block owns whole output rows, so LayerNorm can run in the epilogue (LNORM).
-template <int TM, int TN, bool ABIAS, int P, bool CONV, bool LNORM>
+template <int TM, int TN, bool ABIAS, int P, int CONV, bool LNORM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_w8(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -506,7 +536,7 @@ bool use_w8(long long M, int K, int N) {
   return false;
 }
 
-template <int TM, int TN, bool ABIAS, int P, bool F16, bool CONV, bool OCC2 = (P == 1), int WGN = 2,
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, bool OCC2 = (P == 1), int WGN = 2,
           bool LNORM = false>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,

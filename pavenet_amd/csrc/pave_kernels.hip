@@ -1318,6 +1318,119 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// GroupNorm over an NHWC map (the ChannelMapper neck: conv -> GN(32), necks/channel_mapper.py:
+// 90-100, mmcv ConvModule), written straight into a row-strided destination (the transformer's
+// flattened multi-level buffer).  Three launches, all deterministic: (1) per (image, row chunk)
+// partial sums / sums of squares per group, accumulated in fp64; (2) per image: mean / rstd per
+// group -> per-channel scale a = rstd * gamma and shift b = beta - mean * a; (3) y = x * a + b.
+// HBM-bound: the map is read twice and written once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(
+    const float* __restrict__ x, double* __restrict__ partial, const int HW, const int C,
+    const int G, const int nchunks) {
+  __shared__ double sh[256][2];
+  const int tpr = C >> 2;                 // threads per row (one float4 each)
+  const int rpp = 256 / tpr;              // rows per pass
+  const int c4 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int rows_per_chunk = (HW + nchunks - 1) / nchunks;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(HW, rbeg + rows_per_chunk);
+  const float* xb = x + (long long)n * HW * C + c4 * 4;
+  double s = 0.0, q = 0.0;
+  if (r0 < rpp)
+    for (int r = rbeg + r0; r < rend; r += rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (long long)r * C);
+      s += (double)((v.x + v.y) + (v.z + v.w));
+      q += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    }
+  sh[threadIdx.x][0] = (r0 < rpp) ? s : 0.0;
+  sh[threadIdx.x][1] = (r0 < rpp) ? q : 0.0;
+  __syncthreads();
+  if (threadIdx.x < G) {                  // fixed summation order: bit-reproducible
+    const int tpg = (C / G) >> 2;         // float4 lanes per group
+    double ts = 0.0, tq = 0.0;
+    for (int r = 0; r < rpp; ++r)
+      for (int j = 0; j < tpg; ++j) {
+        const int t = r * tpr + threadIdx.x * tpg + j;
+        ts += sh[t][0];
+        tq += sh[t][1];
+      }
+    double* o = partial + (((long long)n * nchunks + chunk) * G + threadIdx.x) * 2;
+    o[0] = ts;
+    o[1] = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(
+    const double* __restrict__ partial, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ ab, const int HW, const int C, const int G,
+    const int nchunks, const float eps) {
+  __shared__ float mean_s[256], rstd_s[256];
+  const int n = blockIdx.x;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double ts = 0.0, tq = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const double* o = partial + (((long long)n * nchunks + ch) * G + g) * 2;
+      ts += o[0];
+      tq += o[1];
+    }
+    const double cnt = (double)HW * (double)(C / G);
+    const double mean = ts / cnt;
+    double var = tq / cnt - mean * mean;  // fp64: no visible cancellation at fp32 data
+    var = var < 0.0 ? 0.0 : var;
+    mean_s[g] = (float)mean;
+    rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / (C / G);
+    const float a = rstd_s[g] * gamma[c];
+    ab[((long long)n * 2) * C + c] = a;
+    ab[((long long)n * 2 + 1) * C + c] = beta[c] - mean_s[g] * a;
+  }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ ab, float* __restrict__ y,
+    const long long y_batch_stride, const int N, const int HW, const int C) {
+  const int tpr = C >> 2;
+  const long long total = (long long)N * HW * tpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % tpr);
+    const long long row = i / tpr;
+    const int n = (int)(row / HW);
+    const long long r = row - (long long)n * HW;
+    const float4 v = *reinterpret_cast<const float4*>(x + row * C + c4 * 4);
+    const float4 a = *reinterpret_cast<const float4*>(ab + ((long long)n * 2) * C + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(ab + ((long long)n * 2 + 1) * C + c4 * 4);
+    float4 o;
+    o.x = fmaf(v.x, a.x, b.x);
+    o.y = fmaf(v.y, a.y, b.y);
+    o.z = fmaf(v.z, a.z, b.z);
+    o.w = fmaf(v.w, a.w, b.w);
+    *reinterpret_cast<float4*>(y + (long long)n * y_batch_stride + r * C + c4 * 4) = o;
+  }
+}
+
+// out = sigmoid(tmp + inverse_sigmoid(ref)): the reference-point update after every decoder layer
+// (OT:6733-6735, MT:865-866 with mmdet's inverse_sigmoid, eps = 1e-5) -- seven elementwise
+// launches of the PyTorch formulation in one; same operation order in fp32.
+__global__ __launch_bounds__(256) void ref_update_kernel(const float* __restrict__ tmp,
+                                                         const float* __restrict__ ref,
+                                                         float* __restrict__ out, const long long n,
+                                                         const float eps) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (long long)gridDim.x * 256) {
+    float x = fminf(fmaxf(ref[i], 0.f), 1.f);
+    const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+    const float v = tmp[i] + logf(x1 / x2);
+    out[i] = 1.f / (1.f + expf(-v));
+  }
+}
+
 }  // namespace
 
 int pave_internal_fail(int code, const char* msg) { return fail(code, msg); }
@@ -1607,6 +1720,44 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
   const long long nb = std::min<long long>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)nb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, bias, y, N, H, W, C, Ho, Wo);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y,
+                            long long y_batch_stride, int N, int HW, int C, int G, float eps,
+                            double* partial, int nchunks, float* ab, void* stream) {
+  if (!x || !gamma || !beta || !y || !partial || !ab)
+    return fail(PAVE_E_ARG, "groupnorm_nhwc: null pointer");
+  if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || nchunks <= 0 || nchunks > 65535 || N > 65535)
+    return fail(PAVE_E_ARG, "groupnorm_nhwc: sizes must be positive (N, nchunks <= 65535)");
+  if (C % 4 != 0 || C > 1024 || C % G != 0 || (C / G) % 4 != 0 || G > 256 || 256 % (C / 4) != 0)
+    return fail(PAVE_E_UNSUPPORTED,
+                "groupnorm_nhwc: C %% 4 == 0, (C / G) %% 4 == 0, C / 4 divides 256, G <= 256");
+  if (y_batch_stride < (long long)HW * C)
+    return fail(PAVE_E_ARG, "groupnorm_nhwc: y_batch_stride smaller than one image");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)nchunks, (unsigned)N), dim3(256), 0, st,
+                     x, partial, HW, C, G, nchunks);
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((unsigned)N), dim3(256), 0, st, partial, gamma,
+                     beta, ab, HW, C, G, nchunks, eps);
+  const long long total = (long long)N * HW * (C / 4);
+  const long long nb = std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ab, y,
+                     y_batch_stride, N, HW, C);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_ref_update_f32(const float* tmp, const float* ref, float* out, long long n, float eps,
+                        void* stream) {
+  if (!tmp || !ref || !out) return fail(PAVE_E_ARG, "ref_update: null pointer");
+  if (n <= 0) return fail(PAVE_E_ARG, "ref_update: n must be positive");
+  const long long nb = std::min<long long>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(ref_update_kernel, dim3((unsigned)nb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), tmp, ref, out, n, eps);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -104,11 +104,17 @@ class ChannelMapper(BaseModule):
             G = gn.num_groups
             h, w = y.shape[2:]
             rows = y.permute(0, 2, 3, 1).reshape(n, h * w, C)          # view of the NHWC storage
+            dst = buf[:, st:st + h * w]
+            if C % 4 == 0 and (C // G) % 4 == 0 and 256 % (C // 4) == 0 and gn.affine:
+                from . import ops
+                ops.groupnorm_nhwc_into(rows, gn.weight, gn.bias, G, gn.eps, dst)   # HIP, 3 launches
+                outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))
+                st += h * w
+                continue
             var, mean = torch.var_mean(rows.view(n, h * w, G, C // G), dim=(1, 3), unbiased=False)
             rstd = torch.rsqrt(var + gn.eps)[:, :, None]                # [n, G, 1]
             a = rstd * gn.weight.view(1, G, -1)
             b = gn.bias.view(1, G, -1) - mean[:, :, None] * a
-            dst = buf[:, st:st + h * w]
             torch.addcmul(b.reshape(n, 1, C), rows, a.reshape(n, 1, C), out=dst)
             outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))
             st += h * w

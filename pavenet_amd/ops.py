@@ -519,6 +519,48 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def ref_update(tmp, ref, eps=1e-5):
+    """sigmoid(tmp + inverse_sigmoid(ref)) in one launch (decoder reference-point update)."""
+    lib = native.load()
+    _require(tmp.is_cuda and tmp.dtype == torch.float32 and ref.dtype == torch.float32
+             and tuple(tmp.shape) == tuple(ref.shape), 'ref_update: fp32 device tensors, same shape')
+    tmp, ref = tmp.contiguous(), ref.contiguous()
+    out = torch.empty_like(tmp)
+    if tmp.numel() == 0:
+        return out
+    with torch.cuda.device(tmp.device), _Timed('ref_update'):
+        st = lib.pave_ref_update_f32(tmp.data_ptr(), ref.data_ptr(), out.data_ptr(), tmp.numel(),
+                                     float(eps), _stream_ptr())
+    native.check(st, 'ref_update')
+    return out
+
+
+def groupnorm_nhwc_into(x_rows, gamma, beta, num_groups, eps, dst):
+    """GroupNorm of an NHWC map given as rows x_rows [N, HW, C] (dense), written into dst
+    [N, HW, C] whose batch stride may be larger than HW * C (a slice of a [N, S, C] token buffer).
+    fp64 statistics in a fixed order."""
+    lib = native.load()
+    _dev(x_rows, 'x', torch.float32)
+    _require(x_rows.dim() == 3, 'groupnorm_nhwc_into: x [N, HW, C]')
+    N, HW, C = x_rows.shape
+    _dev(gamma, 'gamma', torch.float32)
+    _dev(beta, 'beta', torch.float32)
+    _require(gamma.numel() == C and beta.numel() == C, 'groupnorm_nhwc_into: gamma / beta [C]')
+    _require(dst.is_cuda and dst.dtype == torch.float32 and tuple(dst.shape) == (N, HW, C)
+             and dst.stride(2) == 1 and dst.stride(1) == C and (N == 1 or dst.stride(0) >= HW * C),
+             'groupnorm_nhwc_into: dst [N, HW, C] with dense rows')
+    nchunks = max(1, min(128, (HW + 63) // 64))
+    partial = torch.empty((N, nchunks, num_groups, 2), dtype=torch.float64, device=x_rows.device)
+    ab = torch.empty((N, 2, C), dtype=torch.float32, device=x_rows.device)
+    with torch.cuda.device(x_rows.device), _Timed('groupnorm'):
+        st = lib.pave_groupnorm_nhwc_f32(x_rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         dst.data_ptr(), dst.stride(0) if N > 1 else HW * C, N, HW,
+                                         C, int(num_groups), float(eps), partial.data_ptr(), nchunks,
+                                         ab.data_ptr(), _stream_ptr())
+    native.check(st, 'groupnorm_nhwc_into')
+    return dst
+
+
 def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     """out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta in ONE launch (3 bf16
     planes; the 128 x 256 block tile owns whole rows).  `residual` may be None or the tensor given

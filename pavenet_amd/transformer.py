@@ -48,6 +48,62 @@ def _collect_frame_branches(T, kwargs, suffix):
     return out
 
 
+def _ref_update(tmp, ref):
+    """(tmp + inverse_sigmoid(ref)).sigmoid(): one HIP launch on the device."""
+    if tmp.is_cuda and tmp.dtype == torch.float32 and not torch.is_grad_enabled() \
+            and tmp.shape == ref.shape:
+        from . import ops
+        return ops.ref_update(tmp, ref)
+    return (tmp + inverse_sigmoid(ref)).sigmoid()
+
+
+def _frame_branches(branches, lid, x, cat_dim):
+    """torch.cat([b[lid](x) for b in branches], dim=cat_dim) for T per-frame MLPs of identical
+    structure (Linear / ReLU chains, OT:6728-6732, MT:861-864).  On the device the T first Linears
+    run as ONE GEMM over the row-concatenated weights and the following per-frame Linears as
+    batched GEMMs (T x fewer launches in the launch-bound decoders); same arithmetic per element."""
+    mods = [b[lid] for b in branches]
+    T = len(mods)
+    m0 = mods[0]
+    ok = (T > 1 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+          and x.dim() == 3 and isinstance(m0, nn.Sequential) and len(m0) >= 3 and len(m0) % 2 == 1
+          and all(isinstance(m, nn.Sequential) and len(m) == len(m0) for m in mods)
+          and all(isinstance(m[i], nn.Linear if i % 2 == 0 else nn.ReLU)
+                  and (i % 2 == 1 or (m[i].weight.shape == m0[i].weight.shape
+                                      and m[i].bias is not None))
+                  for m in mods for i in range(len(m0))))
+    if not ok:
+        return torch.cat([m(x) for m in mods], dim=cat_dim)
+    lins = [[m[i] for m in mods] for i in range(0, len(m0), 2)]      # [layer][frame]
+    srcs = [p for layer in lins for l in layer for p in (l.weight, l.bias)]
+    key = tuple((p.data_ptr(), p._version) for p in srcs)
+    cache = m0.__dict__.get('_pave_stacked')
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w1 = torch.cat([l.weight for l in lins[0]], 0).t().contiguous()          # [C, T*h]
+            b1 = torch.cat([l.bias for l in lins[0]], 0).contiguous()
+            rest = [(torch.stack([l.weight.t() for l in layer], 0).contiguous(),   # [T, in, out]
+                     torch.stack([l.bias for l in layer], 0)[:, None].contiguous())
+                    for layer in lins[1:]]
+        cache = (key, w1, b1, rest)
+        m0.__dict__['_pave_stacked'] = cache
+    _, w1, b1, rest = cache
+    lead = x.shape[:-1]
+    rows = x.reshape(-1, x.shape[-1])
+    R = rows.shape[0]
+    y = torch._addmm_activation(b1, rows, w1)                    # relu(x W1^T + b1), all frames
+    y = y.view(R, T, -1).transpose(0, 1)                          # [T, R, h]
+    for li, (w, b) in enumerate(rest):
+        y = torch.baddbmm(b, y, w)
+        if li + 1 < len(rest):
+            y = torch.relu_(y)
+    y = y.view((T,) + tuple(lead) + (y.shape[-1],))               # [T, d0, d1, out]
+    if cat_dim == 0:
+        return y.reshape((T * lead[0],) + tuple(lead[1:]) + (y.shape[-1],))
+    assert cat_dim == 1
+    return y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], y.shape[-1])
+
+
 # ---------------------------------------------------------------------------
 class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
     """Pose decoder, any odd T (generalises OT:6661-6753 and 6757-6852)."""
@@ -76,9 +132,9 @@ class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if branches is not None:
-                tmps = torch.cat([b[lid](output) for b in branches], dim=1)  # OT:6728-6732
+                tmps = _frame_branches(branches, lid, output, 1)  # OT:6728-6732
                 if reference_points.shape[-1] == K * 2:
-                    reference_points = (tmps + inverse_sigmoid(reference_points)).sigmoid()
+                    reference_points = _ref_update(tmps, reference_points)
                 else:
                     raise NotImplementedError
             output = output.permute(1, 0, 2)
@@ -125,9 +181,9 @@ class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if branches is not None:
-                tmps = torch.cat([b[lid](output) for b in branches], dim=0)  # MT:861-864
+                tmps = _frame_branches(branches, lid, output, 0)  # MT:861-864
                 assert reference_points.shape[-1] == 2
-                reference_points = (tmps + inverse_sigmoid(reference_points)).sigmoid()
+                reference_points = _ref_update(tmps, reference_points)
             output = output.permute(1, 0, 2)
             if self.return_intermediate:
                 intermediate.append(output)

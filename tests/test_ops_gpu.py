@@ -324,7 +324,7 @@ def test_enc_tile_kernel_rejects_non_pyramid_and_survives_non_finite():
     assert torch.isfinite(out.cpu()[clean]).all()
 
 
-@pytest.mark.parametrize('D', [4, 30, 32, 64, 71])
+@pytest.mark.parametrize('D', [4, 30, 32, 64, 71, 1025])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
 def test_backward_vs_autograd_of_reference_formulation(D, dtype):
     """ms_deform_attn_backward against autograd through the reference's own PyTorch formulation
@@ -416,6 +416,39 @@ def test_rows_gemm_bias_res_act_vs_torch(M, K, N):
     assert out.data_ptr() == idt.data_ptr()
     np.testing.assert_allclose(out.cpu().numpy(), torch.relu(exp + r.double()).numpy(),
                                rtol=1e-4, atol=1e-4)
+
+
+def test_ref_update_vs_torch_formulation():
+    from pavenet_amd.bricks import inverse_sigmoid
+    from pavenet_amd.ops import ref_update
+    g = torch.Generator().manual_seed(3)
+    ref = torch.rand(4, 300, 30, generator=g) * 1.2 - 0.1       # some outside [0, 1]
+    ref[0, 0, :4] = torch.tensor([0.0, 1.0, 1e-7, 1 - 1e-7])
+    tmp = torch.randn(4, 300, 30, generator=g) * 3
+    exp = (tmp.double() + inverse_sigmoid(ref.double())).sigmoid()
+    got = ref_update(tmp.cuda(), ref.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('N,HW,C,G', [(3, 1000, 256, 32), (2, 35, 256, 32), (1, 7, 64, 8),
+                                      (2, 4100, 128, 32)])
+def test_groupnorm_nhwc_into_vs_torch_fp64(N, HW, C, G):
+    """pave_groupnorm_nhwc_f32 against nn.functional.group_norm in fp64, writing into a slice of
+    a larger token buffer (the rest of the buffer stays untouched); bit-reproducible."""
+    from pavenet_amd.ops import groupnorm_nhwc_into
+    g = torch.Generator().manual_seed(HW + C)
+    x = torch.randn(N, HW, C, generator=g) * 3 + 1.5         # non-zero mean
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    exp = torch.nn.functional.group_norm(x.double().permute(0, 2, 1), G, gam.double(), bet.double(),
+                                         1e-5).permute(0, 2, 1)
+    buf = torch.full((N, HW + 13, C), 7.0).cuda()
+    dst = buf[:, 5:5 + HW]
+    groupnorm_nhwc_into(x.cuda(), gam.cuda(), bet.cuda(), G, 1e-5, dst)
+    np.testing.assert_allclose(dst.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    assert float(buf[:, :5].min()) == 7.0 and float(buf[:, 5 + HW:].max()) == 7.0
+    buf2 = torch.full((N, HW + 13, C), 7.0).cuda()
+    groupnorm_nhwc_into(x.cuda(), gam.cuda(), bet.cuda(), G, 1e-5, buf2[:, 5:5 + HW])
+    assert torch.equal(buf, buf2)
 
 
 @pytest.mark.parametrize('N,H,W,C', [(2, 16, 24, 64), (1, 15, 9, 64), (3, 7, 8, 32)])
