@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 6
+#define PAVE_ABI_VERSION 7
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -302,6 +302,17 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                            int N, int H, int W, int Cin, int Cout, int stride, int relu,
                            int nplanes, void* stream);
+
+/*
+ * The ResNet / HRNet stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; folded BatchNorm as
+ * `bias`; third_party/mmdetection/mmdet/models/backbones/resnet.py:632-640) read straight from the
+ * NCHW fp32 image batch x [N, 3, H, W], as an implicit GEMM through the 3-plane split kernel:
+ * K axis = (c, ky, kx) with kx padded 7 -> 8 and (c, ky) padded 21 -> 24 rows = 192; w_planes =
+ * the weight laid out [64, 192] that way and split like pave_gemm_bf16x3_f32's operand.
+ * y [N, Ho, Wo, 64] NHWC, Ho = (H - 1) / 2 + 1.
+ */
+int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                                  int N, int H, int W, int Cout, int relu, void* stream);
 
 /* x[n] fp32 -> planes[nplanes][n] bf16: truncation terms, the last rounded to nearest even
  * (nplanes = 3: x = p0 + p1 + p2 exactly). */

@@ -178,6 +178,19 @@ class ResNet(BaseModule):
         return f
 
     @staticmethod
+    def _stem_split(x_nchw, w):
+        """7x7 / stride 2 stem through the hand-written 3-plane split kernel, read straight from
+        the NCHW image batch (bf16x3 GEMM mode); None when the mode / shape does not take it."""
+        from . import ops
+        from .bricks import _split_cached, get_gemm_mode
+        if get_gemm_mode() != 'bf16x3' or torch.is_grad_enabled() or not x_nchw.is_cuda \
+                or x_nchw.dtype != torch.float32 or tuple(w.shape) != (64, 3, 7, 7) \
+                or x_nchw.shape[1] != 3 or x_nchw.shape[3] < 8 or not x_nchw.is_contiguous():
+            return None
+        wp = _split_cached(w, 'stem7x7', lambda planes: ops.split_stem7x7_weight(w.detach()))
+        return ops.conv7x7s2_nchw_split(x_nchw, wp)
+
+    @staticmethod
     def _ds_bias(f, name, bi):
         """b3 + bd of a downsample block, summed once per folded parameter set."""
         key = (name, bi, 'ds_b3')
@@ -285,15 +298,18 @@ class ResNet(BaseModule):
             x = x.flatten(0, 1)  # [B, T, C, H, W] -> [B*T, C, H, W]  (resnet.py:634-639)
         assert not self.training, 'pavenet_amd.ResNet is an inference (frozen BN) backbone'
         f = self._build_folded()
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
         gemm_path = (self.channels_last and x.is_cuda and x.dtype == torch.float32
                      and self.style == 'pytorch')
         w, b = f['stem']
+        y = self._stem_split(x, w) if gemm_path else None             # reads the NCHW batch as is
+        if y is None and self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         if gemm_path:
             from . import ops
+            if y is None:
+                y = F.conv2d(x, w, None, 2, 3)                       # MIOpen
             # bn1 + relu + maxpool in one pass over the stem map
-            x = ops.bias_relu_maxpool_nhwc(F.conv2d(x, w, None, 2, 3), b)
+            x = ops.bias_relu_maxpool_nhwc(y, b)
         else:
             x = self.maxpool(F.relu_(F.conv2d(x, w, b, 2, 3)))
         outs = []

@@ -707,4 +707,20 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
 #undef PAVE_CV
 }
 
+int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                                  int N, int H, int W, int Cout, int relu, void* stream) {
+  if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: null pointer");
+  if (N <= 0 || H <= 0 || W < 8) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: bad sizes (W >= 8)");
+  if (Cout != 64)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: Cout == 64 (the ResNet / HRNet stem)");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long M = (long long)N * Ho * Wo;
+  if (M >= (1ll << 31) || (long long)N * 3 * H * W >= (1ll << 40))
+    return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: tensor too large");
+  const ConvGeom g{H, W, 3, Ho, Wo, 2};
+  return launch_gemm<2, 1, false, 3, false, 2, true>(x, static_cast<const uint16_t*>(w_planes), bias,
+                                                     nullptr, y, M, 192, Cout, relu, nullptr,
+                                                     reinterpret_cast<hipStream_t>(stream), g);
+}
+
 }  // extern "C"

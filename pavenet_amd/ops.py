@@ -519,6 +519,40 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def split_stem7x7_weight(weight):
+    """Stem weight [64, 3, 7, 7] -> operand of conv7x7s2_nchw_split: K axis (c, ky, kx) with kx
+    padded to 8 and the 21 (c, ky) rows padded to 24 (K = 192), split into 3 bf16 planes."""
+    _require(tuple(weight.shape[1:]) == (3, 7, 7), 'split_stem7x7_weight: weight [Cout, 3, 7, 7]')
+    co = weight.shape[0]
+    w = torch.zeros((co, 24, 8), dtype=torch.float32, device=weight.device)
+    w[:, :21, :7] = weight.reshape(co, 21, 7)
+    return split_weight_bf16x3(w.reshape(co, 192).contiguous(), 3)
+
+
+def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
+    """7x7 / stride 2 / pad 3 stem convolution of the NCHW image batch x [N, 3, H, W] through the
+    3-plane split kernel -> [N, 64, Ho, Wo] channels_last."""
+    lib = native.load()
+    _dev(x, 'x', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(x.dim() == 4 and x.shape[1] == 3, 'conv7x7s2_nchw_split: x [N, 3, H, W] (NCHW, dense)')
+    _require(w_planes.dim() == 4 and tuple(w_planes.shape[:2]) == (12, 3) and w_planes.shape[3] == 16,
+             'conv7x7s2_nchw_split: w_planes from split_stem7x7_weight')
+    N, _, H, W = x.shape
+    Cout = w_planes.shape[2]
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == Cout, 'conv7x7s2_nchw_split: bias [Cout]')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _Timed('conv7x7_stem'):
+        st = lib.pave_conv7x7s2_nchw_split_f32(
+            x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+            y.data_ptr(), N, H, W, Cout, int(bool(relu)), _stream_ptr())
+    native.check(st, 'conv7x7s2_nchw_split')
+    return y.permute(0, 3, 1, 2)
+
+
 def ref_update(tmp, ref, eps=1e-5):
     """sigmoid(tmp + inverse_sigmoid(ref)) in one launch (decoder reference-point update)."""
     lib = native.load()

@@ -418,6 +418,31 @@ def test_rows_gemm_bias_res_act_vs_torch(M, K, N):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 37, 53, ), (1, 64, 96), (3, 16, 8), (1, 21, 130)])
+def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
+    """pave_conv7x7s2_nchw_split_f32 (7x7 / stride 2 / pad 3 stem read from the NCHW batch) against
+    torch's convolution in fp64, incl. odd sizes and the edge columns."""
+    from pavenet_amd.ops import conv7x7s2_nchw_split, split_stem7x7_weight
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    exp = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 3)
+    wp = split_stem7x7_weight(w.cuda())
+    y = conv7x7s2_nchw_split(x.cuda(), wp, b.cuda())
+    assert tuple(y.shape) == tuple(exp.shape) and y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    y = conv7x7s2_nchw_split(x.cuda(), wp, None, relu=True)
+    exp = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 3))
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    xn = x.clone()
+    xn[0, 1, 3, 4] = float('nan')                     # a NaN pixel poisons only its own windows
+    y = conv7x7s2_nchw_split(xn.cuda(), wp, None)
+    bad = torch.isnan(y[0]).any(0).cpu()
+    expn = torch.isnan(torch.nn.functional.conv2d(xn, w, None, 2, 3)[0]).any(0)
+    assert torch.equal(bad, expn)
+
+
 def test_ref_update_vs_torch_formulation():
     from pavenet_amd.bricks import inverse_sigmoid
     from pavenet_amd.ops import ref_update
