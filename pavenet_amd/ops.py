@@ -164,7 +164,13 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
 
     value [n_clips*T, S, 8, 32]; proj [n_units, >= T*8*16*3]; ref [T, n_units, 4, 2]
     -> out [n_units, 256] (+ (max, sum) [n_units, 8] if return_stats).
+    Differentiable in value / proj / ref (pavenet_amd/fused_autograd.py).
     """
+    if torch.is_grad_enabled() and not return_stats and \
+            (value.requires_grad or proj.requires_grad or ref.requires_grad):
+        from .fused_autograd import GridFusedFunction
+        return GridFusedFunction.apply(value, spatial_shapes, level_start_index, proj, ref, T,
+                                       n_clips, units_per_clip, unit_clip, order)
     lib = native.load()
     f32 = torch.float32
     _dev(value, 'value', f32)
@@ -214,7 +220,13 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
 
     value [n_clips*T, S, 8, 32]; proj [n_clips*Q, >= T*8*L*K*3];
     ref [n_clips, T*Q, L, 2K] -> out [n_clips*Q, 256].
+    Differentiable in value / proj / ref (pavenet_amd/fused_autograd.py).
     """
+    if torch.is_grad_enabled() and not return_stats and \
+            (value.requires_grad or proj.requires_grad or ref.requires_grad):
+        from .fused_autograd import PoseFusedFunction
+        return PoseFusedFunction.apply(value, spatial_shapes, level_start_index, proj, ref, T,
+                                       n_clips, int(num_query), int(num_keypoints))
     lib = native.load()
     f32 = torch.float32
     _dev(value, 'value', f32)
@@ -346,7 +358,10 @@ def enc_tile_supported(levels_hw):
 def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0):
     """Encoder deformable attention ([R2], T = 1) with LDS-staged value windows per image tile.
     value [F, S, 8, 32]; proj [F*S, >= 384]; ref [.., F*S, 4, 2] -> out [F*S, 256].
-    Same results as ``deform_attn_grid_fused(..., T=1)``."""
+    Same results as ``deform_attn_grid_fused(..., T=1)``.  Differentiable (fused_autograd.py)."""
+    if torch.is_grad_enabled() and (value.requires_grad or proj.requires_grad or ref.requires_grad):
+        from .fused_autograd import EncTileFunction
+        return EncTileFunction.apply(value, proj, ref, levels_hw, variant)
     lib = native.load()
     f32 = torch.float32
     _dev(value, 'value', f32)

@@ -352,6 +352,67 @@ def test_backward_vs_autograd_of_reference_formulation(D, dtype):
         np.testing.assert_allclose(a.grad.double().cpu().numpy(), b.grad.numpy(), **tol)
 
 
+@pytest.mark.parametrize('kind,T', [('grid', 1), ('grid', 3), ('grid_clips', 2), ('pose', 3),
+                                    ('pose', 1), ('tile', 1)])
+def test_fused_backward_vs_autograd_of_reference_formulation(kind, T):
+    """Gradients of the fused T-frame launches (forward = the fused HIP kernel, backward =
+    pavenet_amd/fused_autograd.py on the col2im kernel) against fp64 autograd through the oracle's
+    un-fused formulation (per-frame softmax, Z_t re-weighting, grid_sample sampler:
+    tests/fused_expected.py, MO:1484-1578 / OT:1737-1858)."""
+    from pavenet_amd import ops
+    levels = [(8, 12), (4, 6), (2, 3), (1, 2)]
+    shapes, lsi, sd, ld = _levels(levels)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(T + len(kind))
+    old_sampler, R.SAMPLER = R.SAMPLER, 'torch'      # differentiable CPU sampler (MO:92-149)
+    try:
+        if kind == 'pose':
+            clips, Q, K = 2, 5, 15
+            value = torch.randn(clips * T, S, 8, 32, generator=g)
+            proj = torch.randn(clips * Q, T * 8 * 4 * K * 3, generator=g)
+            ref = torch.sigmoid(torch.randn(clips, T * Q, 4, 2 * K, generator=g))
+            exp_in = [t.double().requires_grad_(True) for t in (value, proj, ref)]
+            exp = pose_expected(exp_in[0], shapes, lsi, exp_in[1], exp_in[2], T, clips, Q, K)
+            dev_in = [t.cuda().requires_grad_(True) for t in (value, proj, ref)]
+            out = ops.deform_attn_pose_fused(dev_in[0], sd, ld, dev_in[1], dev_in[2], T=T,
+                                             n_clips=clips, num_query=Q, num_keypoints=K)
+        else:
+            clips = 2 if kind != 'grid' else 1
+            U = (S if kind == 'tile' else 21) * clips
+            value = torch.randn(clips * T, S, 8, 32, generator=g)
+            proj = torch.randn(U, T * 8 * 16 * 3, generator=g)
+            proj[:, :T * 256] *= 1.5
+            if kind == 'tile':      # encoder self-attention: the reference grid of every token
+                ys = torch.cat([((torch.arange(h * w) // w).float() + 0.5) / h for h, w in levels])
+                xs = torch.cat([((torch.arange(h * w) % w).float() + 0.5) / w for h, w in levels])
+                ref = torch.stack([xs, ys], -1)[None, :, None, :].expand(clips, -1, 4, 2)
+                ref = (ref.reshape(1, U, 4, 2) + 0.01 * torch.randn(1, U, 4, 2, generator=g)).contiguous()
+                unit_clip = torch.arange(clips).repeat_interleave(S)
+            else:
+                ref = torch.rand(T, U, 4, 2, generator=g) * 0.9 + 0.05
+                unit_clip = torch.arange(U) % clips if kind == 'grid_clips' else torch.zeros(U).long()
+            exp_in = [t.double().requires_grad_(True) for t in (value, proj, ref)]
+            exp = grid_expected(exp_in[0], shapes, lsi, exp_in[1], exp_in[2], T, unit_clip.long())
+            dev_in = [t.cuda().requires_grad_(True) for t in (value, proj, ref)]
+            if kind == 'tile':
+                out = ops.deform_attn_enc_tile(dev_in[0], dev_in[1], dev_in[2], levels_hw=levels)
+            else:
+                out = ops.deform_attn_grid_fused(
+                    dev_in[0], sd, ld, dev_in[1], dev_in[2], T=T, n_clips=clips,
+                    units_per_clip=U // clips,
+                    unit_clip=unit_clip.to(torch.int32).cuda() if kind == 'grid_clips' else None)
+        gout = torch.randn(exp.shape, generator=g)
+        exp.backward(gout.double())
+        out.backward(gout.cuda())
+    finally:
+        R.SAMPLER = old_sampler
+    np.testing.assert_allclose(out.detach().cpu().numpy(), exp.detach().numpy(), rtol=1e-4, atol=1e-4)
+    for a, b, nm in zip(dev_in, exp_in, ('value', 'proj', 'ref')):
+        scale = float(b.grad.abs().max())
+        np.testing.assert_allclose(a.grad.cpu().double().numpy(), b.grad.numpy(), rtol=2e-3,
+                                   atol=2e-5 * max(scale, 1.0), err_msg=nm)
+
+
 @pytest.mark.parametrize('dtype', [torch.uint8, torch.float32])
 @pytest.mark.parametrize('hw,div', [((270, 480), 1), ((97, 61), 32), ((120, 160), 32)])
 def test_preprocess_clip_vs_oracle_resize_kernel_unpinned_no_cv2(dtype, hw, div):
