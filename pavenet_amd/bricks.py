@@ -186,7 +186,8 @@ def split_gemm_ok(x2, weight):
     return (_GEMM['mode'] in _PLANES and x2.is_cuda and x2.dtype == torch.float32
             and x2.dim() == 2 and x2.is_contiguous() and weight.dtype == torch.float32
             and weight.shape[1] % 64 == 0
-            and weight.shape[0] % 128 == 0 and x2.shape[0] >= _GEMM['min_rows']
+            and (weight.shape[0] % 128 == 0 or (weight.shape[0] == 64 and _GEMM['mode'] == 'bf16x3'))
+            and x2.shape[0] >= _GEMM['min_rows']
             and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
 
 

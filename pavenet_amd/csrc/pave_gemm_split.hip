@@ -39,6 +39,11 @@ constexpr int BK = 16;          // K slab = one MFMA k-step
 constexpr int RST = 48;         // LDS row stride in bytes: 32 B of bf16 + 16 B pad (the 16 lanes
                                 // of a ds_read_b128 phase then fall on 16 distinct bank quads)
 
+// bijection on the low 3 bits: 0 1 2 3 4 5 6 7 -> 0 2 4 6 1 3 5 7
+__device__ __forceinline__ int stage_row_perm(int r) {
+  return (r & ~7) | ((r & 3) << 1) | ((r >> 2) & 1);
+}
+
 __device__ __forceinline__ unsigned hi16(float x) { return __float_as_uint(x) & 0xffff0000u; }
 // pack the bf16 (= high halves) of two fp32 bit patterns: lo -> bits 0..15, hi -> bits 16..31
 __device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) {
@@ -141,11 +146,16 @@ __device__ __forceinline__ void gemm_split_body(
   // ---- staging roles
   // A: thread -> (row = tid>>2 + 64*q, 16-byte segment seg = tid&3 of the row's 64-byte slab)
   const int a_seg = tid & 3;
+  // LDS stores are banked mod 32 dwords and serviced per 16 (b64) / 8 (b128) CONTIGUOUS lanes, i.e.
+  // per 4 consecutive staging rows; at the 12-dword row stride rows r and r + 3 share 4 banks.
+  // Staging rows are therefore permuted inside each block of 8 so that the 4 rows of a store
+  // group are 2 apart (offsets 0, 24, 16, 8 mod 32: conflict-free); global addresses follow.
+  const int a_row = stage_row_perm(tid >> 2);
   const float* a_ptr[APASS];
   int iy0[APASS], ix0[APASS];   // CONV: top-left input pixel of the row's 3x3 window
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
-    long long r = m0 + (tid >> 2) + AROWS * q;
+    long long r = m0 + a_row + AROWS * q;
     if (r >= M) r = M - 1;  // clamp: rows past M are computed on stand-in data, never stored
     if (CONV != 0) {
       const unsigned ur = (unsigned)r, gy = ur / (unsigned)g.Wo;
@@ -167,7 +177,7 @@ __device__ __forceinline__ void gemm_split_body(
 #pragma unroll
   for (int q = 0; q < WV; ++q) {
     const int v = (tid + NT * q) < WN ? tid + NT * q : 0;   // spare threads of a partial round
-    const int seg = v & 1, row = (v >> 1) % BN, plane = v / (2 * BN);   // repeat item 0
+    const int seg = v & 1, row = stage_row_perm((v >> 1) % BN), plane = v / (2 * BN);   // repeat item 0
     w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * P*N*16
     w_dst[q] = P * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
   }
@@ -264,7 +274,7 @@ __device__ __forceinline__ void gemm_split_body(
       }
       uint2 pl[P];
       split4<P, F16>(t, pl);
-      const int d = ((tid >> 2) + AROWS * q) * RST + a_seg * 8;
+      const int d = (a_row + AROWS * q) * RST + a_seg * 8;
 #pragma unroll
       for (int t2 = 0; t2 < P; ++t2) *reinterpret_cast<uint2*>(buf + t2 * A_PLANE + d) = pl[t2];
     }
@@ -292,23 +302,24 @@ __device__ __forceinline__ void gemm_split_body(
   // products kept: all (pa, pb) with pa + pb < P  (P = 3: six, error <= 2^-23; P = 2: three,
   // ~2^-16; P = 1: plain bf16), smallest terms first
   auto mma = [&](const u32x4 (&fa)[P][TH], const u32x4 (&fb)[P][TN], int i0) {
+    // products outermost, tiles innermost: consecutive MFMAs write different accumulators (the
+    // per-accumulator order of the six products is unchanged)
 #pragma unroll
-    for (int i = 0; i < TH; ++i)
+    for (int o = P - 1; o >= 0; --o)       // order o = pa + pb
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i0 + i][j];
+      for (int pa = 0; pa <= o; ++pa)
 #pragma unroll
-        for (int o = P - 1; o >= 0; --o)       // order o = pa + pb
+        for (int i = 0; i < TH; ++i)
 #pragma unroll
-          for (int pa = 0; pa <= o; ++pa)
-            c = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                          __builtin_bit_cast(f16x8, fa[pa][i]),
-                          __builtin_bit_cast(f16x8, fb[o - pa][j]), c, 0, 0, 0)
-                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                          __builtin_bit_cast(bf16x8, fa[pa][i]),
-                          __builtin_bit_cast(bf16x8, fb[o - pa][j]), c, 0, 0, 0);
-        acc[i0 + i][j] = c;
-      }
+          for (int j = 0; j < TN; ++j) {
+            const f32x16 c = acc[i0 + i][j];
+            acc[i0 + i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                       __builtin_bit_cast(f16x8, fa[pa][i]),
+                                       __builtin_bit_cast(f16x8, fb[o - pa][j]), c, 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                       __builtin_bit_cast(bf16x8, fa[pa][i]),
+                                       __builtin_bit_cast(bf16x8, fb[o - pa][j]), c, 0, 0, 0);
+          }
   };
 
   // fragment registers: the two A halves of the current slab, the current and the next W set
@@ -620,12 +631,19 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
-  if (K % 64 != 0 || N % 128 != 0)
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 required");
+  if (K % 64 != 0 || (N % 128 != 0 && !(N == 64 && nplanes == 3 && !os.out2)))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 (or N == 64 "
+                                          "with 3 planes) required");
   if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
+  if (N == 64) {  // 128 x 64 tiles (the ResNet layer1 1x1 reductions): HBM-bound, A read once
+    const ConvGeom gz{0, 0, 0, 0, 0, 0};
+    if (a_bias)
+      return launch_gemm<2, 1, true, 3, false, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, gz, os);
+    return launch_gemm<2, 1, false, 3, false, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, gz, os);
+  }
   // P = 3: 128 x 128 tiles, two workgroups (8 waves) per CU -- one workgroup's operand split
   // (VALU) and LDS traffic overlap the other's MFMAs: 12-25 % faster than the 256 x 128 tile at
   // one wave per SIMD on every shape of the model (tools/bench_gemm_shapes.py)

@@ -511,7 +511,8 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
              'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
     N = w_planes.shape[2]
-    _require(N % 128 == 0, 'gemm_bf16x3: N % 128 == 0')
+    _require(N % 128 == 0 or (N == 64 and w_planes.shape[1] == 3),
+             'gemm_bf16x3: N % 128 == 0 (or N == 64 with 3 planes)')
     for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
         if t is not None:
             _dev(t, nm, torch.float32)

@@ -583,7 +583,8 @@ def test_split_bf16x3_is_exact():
     assert torch.equal(parts[0].double() + parts[1].double() + parts[2].double(), x.double())
 
 
-@pytest.mark.parametrize('M,K,N', [(1000, 256, 1024), (257, 1024, 256), (5, 64, 128), (3000, 128, 256)])
+@pytest.mark.parametrize('M,K,N', [(1000, 256, 1024), (257, 1024, 256), (5, 64, 128), (3000, 128, 256),
+                                   (1300, 256, 64)])
 def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
     """The split-bf16 GEMM is as accurate as an fp32 GEMM: its error against fp64 is within 4x of
     torch's fp32 matmul error on the same data (and far below bf16 / tf32 levels)."""
