@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 7
+#define PAVE_ABI_VERSION 8
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -302,6 +302,16 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                            int N, int H, int W, int Cin, int Cout, int stride, int relu,
                            int nplanes, void* stream);
+
+/*
+ * 1x1 convolution with a stride on an NHWC map (the ResNet downsample branch,
+ * third_party/mmdetection/mmdet/models/backbones/resnet.py:258-262 `self.downsample(x)`): the row
+ * GEMM pave_gemm_bf16x3_f32 (3 planes) whose A row m is the input pixel (oy * stride, ox * stride)
+ * of image n -- no strided-slice copy.  x [N, H, W, Cin], y [N, Ho, Wo, Cout], Ho = (H - 1)/stride + 1.
+ */
+int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                                   int N, int H, int W, int Cin, int Cout, int stride, int relu,
+                                   void* stream);
 
 /*
  * The ResNet / HRNet stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; folded BatchNorm as

@@ -251,9 +251,25 @@ class ResNet(BaseModule):
         if blk.downsample is not None:
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
+            tail = f.get((name, bi, 'tail_ds_kn'))
+            from .bricks import _split_weight, get_gemm_mode
+            if (s > 1 and tail is None and get_gemm_mode() == 'bf16x3' and not torch.is_grad_enabled()
+                    and wd.shape[0] % 128 == 0 and wd.shape[1] % 64 == 0
+                    and yrows.shape[0] >= 8192
+                    and (w3_kn is not None or split_gemm_ok(yrows, w3.flatten(1)))):
+                # stride-2 downsample: the GEMM reads the strided pixels itself (no slice copy)
+                idt = ops.conv1x1_strided_split(x, _split_weight(wd.flatten(1)),
+                                                self._ds_bias(f, name, bi), stride=s)
+                idt, _ = self._as_rows(idt)
+                if split_gemm_ok(yrows, w3.flatten(1)):
+                    out = linear_rows(yrows, w3.flatten(1), None, relu=True, residual=idt,
+                                      inplace_residual=True, a_bias=b2)
+                else:
+                    out = ops.rows_gemm_bias_res_act(yrows, w3_kn, None, idt, relu=True, out=idt,
+                                                     a_bias=b2)
+                return self._as_map(out, onhw)
             xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
             xrows, _ = self._as_rows(xs)
-            tail = f.get((name, bi, 'tail_ds_kn'))
             if tail is not None:
                 # relu([relu(y + b2) | x] @ [W3; Wd] + b3 + bd): the whole tail in one kernel
                 out = ops.rows_gemm_bias_res_act(yrows, tail[0], tail[1], None, relu=True,

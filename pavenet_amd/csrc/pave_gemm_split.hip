@@ -166,6 +166,14 @@ __device__ __forceinline__ void gemm_split_body(
       iy0[q] = oy * g.stride - pad;
       ix0[q] = ox * g.stride - pad;
       a_ptr[q] = A + (long long)n * g.H * g.W * g.Cin + (CONV == 2 ? 0 : a_seg * 4);   // image base
+    } else if (g.H > 0) {
+      // 1x1 convolution with a stride on the NHWC map (ResNet downsample): row = output pixel,
+      // its A row is the input pixel (oy * stride, ox * stride) -- no strided-slice copy
+      const unsigned ur = (unsigned)r, gy = ur / (unsigned)g.Wo;
+      const int ox = (int)(ur - gy * (unsigned)g.Wo);
+      const int n = (int)(gy / (unsigned)g.Ho);
+      const int oy = (int)(gy - (unsigned)n * (unsigned)g.Ho);
+      a_ptr[q] = A + (((long long)n * g.H + oy * g.stride) * g.W + ox * g.stride) * K + a_seg * 4;
     } else {
       a_ptr[q] = A + r * K + a_seg * 4;
     }
@@ -723,6 +731,24 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
   if (nplanes == 2) PAVE_CV(1, 2, false);
   PAVE_CV(1, 1, false);
 #undef PAVE_CV
+}
+
+int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
+                                   int N, int H, int W, int Cin, int Cout, int stride, int relu,
+                                   void* stream) {
+  if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || stride < 1 || stride > 4)
+    return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: bad sizes (1 <= stride <= 4)");
+  if (Cin % 64 != 0 || Cout % 128 != 0 || Cin <= 0 || Cout <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: Cin %% 64 == 0 and Cout %% 128 == 0 required");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
+    return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: tensor too large");
+  const ConvGeom g{H, W, Cin, Ho, Wo, stride};
+  return launch_gemm<2, 2, false, 3, false, 0, true>(x, static_cast<const uint16_t*>(w_planes), bias,
+                                                     nullptr, y, M, Cin, Cout, relu, nullptr,
+                                                     reinterpret_cast<hipStream_t>(stream), g);
 }
 
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,

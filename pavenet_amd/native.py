@@ -38,6 +38,7 @@ SIGNATURES = {
                                 _c_int, _vp, _vp],
     'pave_ref_update_f32': [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_float, _vp],
     'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 5 + [_vp],
+    'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
@@ -46,7 +47,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
 
 _lib = None
-ABI_VERSION = 7  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 8  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

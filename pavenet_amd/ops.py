@@ -535,6 +535,32 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
+    """1x1 convolution with a stride on a channels_last map through the 3-plane split GEMM (the A
+    rows are the strided input pixels: no slice copy).  x [N, Cin, H, W] channels_last;
+    w_planes = split_weight_bf16x3(weight [Cout, Cin]) -> [N, Cout, Ho, Wo] channels_last."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv1x1_strided_split: fp32 4-D')
+    _require(x.is_contiguous(memory_format=torch.channels_last),
+             'conv1x1_strided_split: channels_last input')
+    _dev(w_planes, 'w_planes', torch.int16)
+    N, Cin, H, W = x.shape
+    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == Cin and w_planes.shape[1] == 3
+             and w_planes.shape[3] == 16, 'conv1x1_strided_split: w_planes [Cin/16, 3, Cout, 16]')
+    Cout = w_planes.shape[2]
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == Cout, 'conv1x1_strided_split: bias [Cout]')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _Timed('conv1x1_strided'):
+        st = lib.pave_conv1x1_strided_split_f32(
+            x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), _stream_ptr())
+    native.check(st, 'conv1x1_strided_split')
+    return y.permute(0, 3, 1, 2)
+
+
 def split_stem7x7_weight(weight):
     """Stem weight [64, 3, 7, 7] -> operand of conv7x7s2_nchw_split: K axis (c, ky, kx) with kx
     padded to 8 and the 21 (c, ky) rows padded to 24 (K = 192), split into 3 bf16 planes."""

@@ -504,6 +504,21 @@ def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
     assert torch.equal(bad, expn)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 256, 512, 2), (1, 20, 9, 64, 128, 2),
+                                                   (3, 8, 8, 128, 256, 1)])
+def test_conv1x1_strided_split_vs_torch_fp64(N, H, W, Cin, Cout, stride):
+    from pavenet_amd.ops import conv1x1_strided_split, split_weight_bf16x3
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) / Cin**0.5
+    b = torch.randn(Cout, generator=g)
+    exp = torch.nn.functional.conv2d(x.double(), w.double()[:, :, None, None], b.double(), stride)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    y = conv1x1_strided_split(xd, split_weight_bf16x3(w.cuda()), b.cuda(), stride=stride)
+    assert tuple(y.shape) == tuple(exp.shape)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_ref_update_vs_torch_formulation():
     from pavenet_amd.bricks import inverse_sigmoid
     from pavenet_amd.ops import ref_update
