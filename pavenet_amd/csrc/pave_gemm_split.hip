@@ -134,19 +134,14 @@ __device__ __forceinline__ void gemm_split_body(
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, kh = lane >> 5;
   const int ntiles = N / BN;
-  // Persistent workgroups: the grid is at most what the chip holds at once (two workgroups per
-  // CU); each walks a list of tiles.  XCD-aware: the hardware deals workgroups round-robin over
-  // the 8 XCDs; XCD x owns one contiguous run of logical tiles (column tile fastest) and its
-  // resident workgroups ("slots") take consecutive tiles of that run, so the column tiles of one
-  // row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once.
-  const int total = (int)(((long long)M + BM - 1) / BM) * ntiles;
-  const int per = total >> 3, rem = total & 7;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int nslots = ((int)gridDim.x - xcd + 7) >> 3;          // workgroups of this grid on my XCD
-  const int tile_end = xcd * per + (xcd < rem ? xcd : rem) + per + (xcd < rem ? 1 : 0);
-  int tile = xcd * per + (xcd < rem ? xcd : rem) + slot;
-  long long m0 = 0;
-  int n0 = 0;
+  // XCD-aware bijective remap: the hardware deals workgroups round-robin over the 8 XCDs; give
+  // each XCD a contiguous run of logical tiles (column tile fastest) so that the column tiles of
+  // one row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once.
+  const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  const long long m0 = (long long)(lb / ntiles) * BM;
+  const int n0 = (lb % ntiles) * BN;
 
   // ---- staging roles
   // A: thread -> (row = tid>>2 + 64*q, 16-byte segment seg = tid&3 of the row's 64-byte slab)
@@ -158,11 +153,6 @@ __device__ __forceinline__ void gemm_split_body(
   const int a_row = stage_row_perm(tid >> 2);
   const float* a_ptr[APASS];
   int iy0[APASS], ix0[APASS];   // CONV: top-left input pixel of the row's 3x3 window
-  const uint16_t* w_ptr[WV];
-  int w_dst[WV];
-  auto setup = [&](int t) {     // staging roles of logical tile t
-  m0 = (long long)(t / ntiles) * BM;
-  n0 = (t % ntiles) * BN;
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
     long long r = m0 + a_row + AROWS * q;
@@ -190,6 +180,8 @@ __device__ __forceinline__ void gemm_split_body(
   }
   // W operand, slab-major [K/16][3][N][16] bf16 (host layout: one slab of a column tile is 3
   // contiguous 4-KiB runs): uint4 index v = tid + NT*q -> plane, row, 16-byte half
+  const uint16_t* w_ptr[WV];
+  int w_dst[WV];
 #pragma unroll
   for (int q = 0; q < WV; ++q) {
     const int v = (tid + NT * q) < WN ? tid + NT * q : 0;   // spare threads of a partial round
@@ -197,10 +189,15 @@ __device__ __forceinline__ void gemm_split_body(
     w_ptr[q] = Wp + ((long long)plane * N + n0 + row) * 16 + seg * 8;   // + slab * P*N*16
     w_dst[q] = P * A_PLANE + plane * W_PLANE + row * RST + seg * 16;
   }
-  };
   const long long w_slab = (long long)P * N * 16;
 
   f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // global -> register sets.  A set holds a PAIR of slabs (32 k): the two float4 a thread loads
   // per row are the halves of one 128-byte line, so every line crosses L2 -> L1 once.  Two sets
@@ -210,12 +207,8 @@ __device__ __forceinline__ void gemm_split_body(
   f32x4 rb0[2], rb1[2];
   const int nslabs = K / BK;
   const int npairs = nslabs / 2;
-  bool more = false;            // this workgroup has another tile (valid from the last trip on)
   auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rw)[2][WV], f32x4 (&rb)[2]) {
-    // past the end of this tile: the staging roles already point at the NEXT tile (set up at the
-    // top of the last trip), so these loads are its pairs 0 and 1 -- they land under the last
-    // slabs and the epilogue.  No next tile: repeat the last pair (never consumed).
-    const int pp = pair < npairs ? pair : (more ? pair - npairs : npairs - 1);
+    const int pp = pair < npairs ? pair : npairs - 1;  // past the end: repeat (never consumed)
     const int k0 = pp * 2 * BK;
     if (CONV == 2) {
       // 7x7 / stride 2 / pad 3 stem on the NCHW image: K axis = (c, ky, kx padded 7 -> 8), i.e. 24
@@ -341,21 +334,9 @@ __device__ __forceinline__ void gemm_split_body(
   u32x4 faL[P][TH], faH[P][TH], fbA[P][TN], fbB[P][TN];
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + BUF;
-  if (tile >= tile_end) return;   // (a grid larger than the tile list: never launched that way)
-  setup(tile);
+  // prologue: pairs 0 and 1 in registers, slab 0 staged, its first fragments read
   gload(0, ra0, rw0, rb0);
   gload(1, ra1, rw1, rb1);
-  long long em0 = 0;              // tile whose accumulators the epilogue writes
-  int en0 = 0;
-  for (;;) {
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // prologue: pairs 0 and 1 are in registers / on their way (a later tile's were loaded under the
-  // previous tile's last slabs); slab 0 staged, its first fragments read
   stage(buf0, ra0[0], rw0[0], rb0[0]);
   __syncthreads();
   fread_a(buf0, faL, 0);
@@ -379,12 +360,6 @@ __device__ __forceinline__ void gemm_split_body(
   // reloaded with the pair two ahead right after its second slab has been staged.
   for (int s = 0; s < nslabs; s += 4) {
     const int pr = s >> 1;
-    if (s + 4 >= nslabs) {   // last trip: every load of this tile has been issued
-      em0 = m0;
-      en0 = n0;
-      more = tile + nslots < tile_end;
-      if (more) setup(tile + nslots);
-    }
     PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rw0[1], rb0[1]), gload(pr + 2, ra0, rw0, rb0))
     PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra1[0], rw1[0], rb1[0]), (void)0)
     PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rw1[1], rb1[1]), gload(pr + 3, ra1, rw1, rb1))
@@ -402,11 +377,11 @@ __device__ __forceinline__ void gemm_split_body(
   __syncthreads();  // operand tiles fully consumed by every wave
   float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * CST;
   const int c4 = lane % RV;
-  const int ncol = en0 + wn * CW + c4 * 4;
+  const int ncol = n0 + wn * CW + c4 * 4;
   const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
   // output segment of this column tile (block-uniform)
-  const bool seg2 = os.out2 != nullptr && en0 >= os.nsplit;
+  const bool seg2 = os.out2 != nullptr && n0 >= os.nsplit;
   float* const obase = seg2 ? os.out2 : out;
   const int ldo = os.out2 == nullptr ? N : (seg2 ? N - os.nsplit : os.nsplit);
   const int ocol = seg2 ? ncol - os.nsplit : ncol;
@@ -424,7 +399,7 @@ __device__ __forceinline__ void gemm_split_body(
     if (residual) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        const long long gm = em0 + wm * TM * 32 + i * 32 + ps * RPP + lane / RV;
+        const long long gm = m0 + wm * TM * 32 + i * 32 + ps * RPP + lane / RV;
         const long long rr = os.res_rows ? (long long)((unsigned)gm % (unsigned)os.res_rows) : gm;
         res[ps] = gm < M ? *reinterpret_cast<const float4*>(residual + rr * N + ncol)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -442,7 +417,7 @@ __device__ __forceinline__ void gemm_split_body(
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int lrow = ps * RPP + lane / RV;
-        const long long gm = em0 + wm * TM * 32 + i * 32 + lrow;
+        const long long gm = m0 + wm * TM * 32 + i * 32 + lrow;
         float4 t = *reinterpret_cast<const float4*>(Cs + lrow * CST + c4 * 4);
         t.x += b4.x, t.y += b4.y, t.z += b4.z, t.w += b4.w;
         if (residual) t.x += res[ps].x, t.y += res[ps].y, t.z += res[ps].z, t.w += res[ps].w;
@@ -474,7 +449,7 @@ __device__ __forceinline__ void gemm_split_body(
       for (int ps = 0; ps < NPASS; ++ps) {
         const int lrow = ps * RPP + lane / RV;
         const int brow = wm * TM * 32 + i * 32 + lrow;
-        const long long gm = em0 + brow;
+        const long long gm = m0 + brow;
         float q = 0.f;
 #pragma unroll
         for (int w = 0; w < WGN; ++w) q += st2[brow * WGN + w];
@@ -492,7 +467,7 @@ __device__ __forceinline__ void gemm_split_body(
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int lrow = ps * RPP + lane / RV;
-      const long long gm = em0 + wm * TM * 32 + i * 32 + lrow;
+      const long long gm = m0 + wm * TM * 32 + i * 32 + lrow;
       if (gm < M) {
         float4 v = *reinterpret_cast<const float4*>(Cs + lrow * CST + c4 * 4);
         v.x += b4.x;
@@ -517,10 +492,6 @@ __device__ __forceinline__ void gemm_split_body(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-    if (!more) break;
-    tile += nslots;
-    __syncthreads();   // the epilogue's LDS chunks are done before the next tile is staged
-  }   // persistent tile loop
 }
 
 // P = 3 needs the whole register file of a SIMD (one wave each); with fewer planes two workgroups
@@ -573,20 +544,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
-                         // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never,
-                         // 5 = non-persistent grid (one tile per workgroup)
-
-int compute_units() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;   // MI355X
-    cus = n & ~7 ? n & ~7 : 8;   // whole XCD multiples keep the slot arithmetic uniform
-  }
-  return cus;
-}
+                         // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {
@@ -609,14 +567,8 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
   constexpr int EPI = NW * 32 * (TN * 32 + 4) * 4 + (LNORM ? 2 * BM * WGN * 4 : 0);
   constexpr int SMEM = (2 * P * (BM + BN) * RST > EPI) ? 2 * P * (BM + BN) * RST : EPI;
   static_assert(WGN == 2 || (WGN == 4 && !F16), "wave grids: 2 x 2 or 2 x 4");
-  const long long tiles = ((M + BM - 1) / BM) * (N / BN);
-  if (tiles >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: too many tiles");
-  // persistent grid: what the chip holds at once (LDS and the waves-per-SIMD bound of the kernel)
-  constexpr int kWavesPerSimd = (WGN == 4 || OCC2) ? 2 : 1;
-  constexpr int kByLds = 163840 / SMEM, kByWaves = (kWavesPerSimd * 4) / NW;
-  constexpr int kPerCu = kByLds < kByWaves ? (kByLds < 1 ? 1 : kByLds) : (kByWaves < 1 ? 1 : kByWaves);
-  const long long cap = (long long)compute_units() * kPerCu;
-  const long long gx = (g_diag_variant == 5 || tiles < cap) ? tiles : cap;   // 5: one tile per workgroup
+  const long long gx = ((M + BM - 1) / BM) * (N / BN);
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
   using kern_t = void (*)(const float*, const uint16_t*, const float*, const float*, float*, int, int,
                           int, int, const float*, ConvGeom, OutSplit, LnArgs);
   kern_t kern;

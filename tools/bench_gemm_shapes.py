@@ -77,10 +77,7 @@ def main():
             if N % 256 == 0:
                 native.load().pave_diag_gemm_variant(3)
                 ms8 = timed(f3)
-            native.load().pave_diag_gemm_variant(5)
-            ms1 = timed(f3)
             native.load().pave_diag_gemm_variant(0)
-            print(f'   {label}: one tile per workgroup {ms1:.3f} ms   persistent (default) {ms3:.3f} ms')
             print(f'   {label}: library {ms:.3f} ms ({2.0 * M * K * N / ms / 1e9:.0f} TF/s)   '
                   f'bf16x3 split {ms3:.3f} ms ({2.0 * M * K * N / ms3 / 1e9:.0f} TF/s)   '
                   f'256-row tile, 1 wave/SIMD {ms3b:.3f} ms ({2.0 * M * K * N / ms3b / 1e9:.0f} TF/s)   '
