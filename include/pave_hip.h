@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 8
+#define PAVE_ABI_VERSION 9
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -149,14 +149,19 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
  *   value [n_frames, S, 8, 32]; proj [n_frames*S, proj_stride] (offsets [8][4][4][2], then
  *   logits [8][4][4]); ref [n_frames*S, 4, 2]; out [n_frames*S, 256]
  *   levels_hw   HOST array of 8 ints (h0, w0, ..., h3, w3), levels in flattening order
- *   variant     0: windows of -3 .. +3 px (3 workgroups per CU), 1: -4 .. +4 px (2 per CU)
+ *   variant     0: windows of -4 .. +3 px (3 workgroups per CU), 1: -4 .. +4 px (1 per CU)
+ *   window_shift  NULL, or a HOST array [8 heads][4 levels][2] of (dx, dy) in level pixels that
+ *               moves the LDS window of (tile, head, level): a head's points sit around
+ *               reference + its mean learnt offset (the reference initialises them on a ray 1..4 px
+ *               out, MO:227-240), so centring the window there keeps them in LDS.  Speed only.
  * Returns PAVE_E_UNSUPPORTED (nothing launched) unless every level l satisfies
  * H_l <= (8 >> l) * ceil(H_0 / 8) and W_l likewise (a halving pyramid): callers then use
  * pave_deform_attn_grid_fused_f32.
  */
 int pave_enc_deform_attn_tile_f32(const float* value, const float* proj, const float* ref,
                                   float* out, int n_frames, int S, const int* levels_hw,
-                                  int proj_stride, int variant, void* stream);
+                                  int proj_stride, int variant, const int* window_shift,
+                                  void* stream);
 
 /*
  * [R1] backward: void ms_deform_attn_backward(value, spatial_shapes, level_start_index,

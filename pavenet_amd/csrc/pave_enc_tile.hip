@@ -50,6 +50,10 @@ struct TileParams {
   // per-level constants each lane fetches by its level k = lane & 3 (one 32-byte kernarg row):
   // H, W, first token, window side, first LDS row of the window, 1/W, 1/H (float bits), unused
   int tab[4][8];
+  // window origin shift per (head, level): (dx, dy) in level pixels.  A head's sampling points sit
+  // around reference + its learnt mean offset (the reference initialises them on a ray, 1..4 px
+  // out, MO:227-240), so the LDS window of (tile, head) is centred there instead of on the tile.
+  int shift[kHeads][4][2];
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -285,10 +289,15 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const int4* tab = reinterpret_cast<const int4*>(
       (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileParams, tab)) + k * 2;
   const int4 tabA = tab[0], tabB = tab[1];
+  const int* shp = reinterpret_cast<const int*>(
+      (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileParams, shift)) + head * 8;
+  const int2 my_shift = *reinterpret_cast<const int2*>(shp + k * 2);   // lane k <-> level k
 
   // ---- stage the four windows (LDS-DMA) and the two zero rows
-  const int ox0 = tx * 8 - MB0, oy0 = ty * 8 - MB0, ox1 = tx * 4 - MB1, oy1 = ty * 4 - MB1;
-  const int ox2 = tx * 2 - MB2, oy2 = ty * 2 - MB2, ox3 = tx - MB3, oy3 = ty - MB3;
+  const int ox0 = tx * 8 - MB0 + shp[0], oy0 = ty * 8 - MB0 + shp[1];
+  const int ox1 = tx * 4 - MB1 + shp[2], oy1 = ty * 4 - MB1 + shp[3];
+  const int ox2 = tx * 2 - MB2 + shp[4], oy2 = ty * 2 - MB2 + shp[5];
+  const int ox3 = tx - MB3 + shp[6], oy3 = ty - MB3 + shp[7];
   const char* vhead = reinterpret_cast<const char*>(p.value) + (size_t)ubase * kRowBytes + head * 128;
   if (!(ABL & 1)) {
     stage_level<W0, kWaves>(lds + G::B0 * 128, vhead, wave, lane, ox0, oy0, p.Hs[0], p.Ws[0], p.St[0]);
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   // ---- my level's constants (lane k <-> level k): one vector load of the kernarg table row
   // instead of seven 4-way select chains
   static_assert(MB0 == MB1 && MB1 == MB2 && MB2 == MB3, "one window margin for all levels");
-  const int ox = ((tx * 8) >> k) - MB0, oy = ((ty * 8) >> k) - MB0;
+  const int ox = ((tx * 8) >> k) - MB0 + my_shift.x, oy = ((ty * 8) >> k) - MB0 + my_shift.y;
   const int H = tabA.x, W = tabA.y, st = tabA.z, ww = tabA.w, wbase = tabB.x;
   const float fW = (float)W, fH = (float)H;
   const float rW = __int_as_float(tabB.y), rH = __int_as_float(tabB.z);
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
 template <int ABL>
 static int enc_tile_launch(const float* value, const float* proj, const float* ref, float* out,
                            int n_frames, int S, const int* levels_hw, int proj_stride, int variant,
-                           void* stream) {
+                           const int* window_shift, void* stream) {
   if (!value || !proj || !ref || !out || !levels_hw)
     return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: null pointer");
   if (n_frames <= 0 || S <= 0) return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: sizes must be positive");
@@ -391,6 +400,12 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
   p.out = out;
   p.S = S;
   p.proj_stride = proj_stride;
+  if (window_shift)
+    for (int i = 0; i < kHeads * 8; ++i) {
+      if (window_shift[i] < -64 || window_shift[i] > 64)
+        return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: |window_shift| <= 64");
+      (&p.shift[0][0][0])[i] = window_shift[i];
+    }
   long long start = 0;
   for (int l = 0; l < 4; ++l) {
     if (levels_hw[2 * l] <= 0 || levels_hw[2 * l + 1] <= 0)
@@ -438,9 +453,9 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
 extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* proj,
                                               const float* ref, float* out, int n_frames, int S,
                                               const int* levels_hw, int proj_stride, int variant,
-                                              void* stream) {
+                                              const int* window_shift, void* stream) {
   return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant,
-                            stream);
+                            window_shift, stream);
 }
 
 // Timing-only ablations for tools/bench_kernels.py (not part of the C ABI, outputs are wrong):
@@ -449,9 +464,9 @@ extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, 
                                          float* out, int n_frames, int S, const int* levels_hw,
                                          int proj_stride, int variant, int ablate, void* stream) {
   switch (ablate) {
-    case 1: return enc_tile_launch<1>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
-    case 2: return enc_tile_launch<2>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
-    case 3: return enc_tile_launch<3>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
-    default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, stream);
+    case 1: return enc_tile_launch<1>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
+    case 2: return enc_tile_launch<2>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
+    case 3: return enc_tile_launch<3>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
+    default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
   }
 }

@@ -174,6 +174,17 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
     supports_post_norm = True
     supports_query_plus_pos = True
 
+    def _tile_shift(self):
+        """Per-(head, level) LDS-window shift of the tile kernel = the rounded mean of the
+        sampling-offset bias over the 4 points (the reference initialises that bias on a ray,
+        MO:227-240); host ints, re-read only when the bias changes."""
+        b = self.sampling_offsets.bias
+        key = (b.data_ptr(), b._version)
+        if getattr(self, '_tile_shift_key', None) != key:
+            self._tile_shift_val = ops.enc_tile_window_shift(b)
+            self._tile_shift_key = key
+        return self._tile_shift_val
+
     def _merged_proj(self):
         """[value_proj ; sampling_offsets ; attention_weights] as one [640, 256] operand (and the
         [384, 256] offsets / logits part alone), rebuilt when a source parameter changes."""
@@ -206,7 +217,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         if not ref.is_contiguous():
             ref = ref.contiguous()
         out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), proj, ref,
-                                       levels_hw=tile_levels)
+                                       levels_hw=tile_levels, window_shift=self._tile_shift())
         return out.view(bs, S, self.embed_dims)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
@@ -263,7 +274,8 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                 unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
             if tile_levels is not None and clip_index is None and num_query == num_value:
                 # encoder self-attention over a halving pyramid: LDS-tile kernel
-                out = ops.deform_attn_enc_tile(v, proj, ref, levels_hw=tile_levels)
+                out = ops.deform_attn_enc_tile(v, proj, ref, levels_hw=tile_levels,
+                                               window_shift=self._tile_shift())
             else:
                 out = ops.deform_attn_grid_fused(
                     v, spatial_shapes, level_start_index, proj, ref, T=1, n_clips=v.shape[0],

@@ -23,7 +23,7 @@ SIGNATURES = {
     'pave_bias_add_layernorm_f32': [_vp] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _vp],
     'pave_bias_add_layernorm_pos_f32': [_vp] * 7 + [ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int,
                                         ctypes.c_float, _vp],
-    'pave_enc_deform_attn_tile_f32': [_vp] * 4 + [_c_int, _c_int, _vp, _c_int, _c_int, _vp],
+    'pave_enc_deform_attn_tile_f32': [_vp] * 4 + [_c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp],
     'pave_ms_deform_attn_backward_f32': [_vp] * 9 + [_c_int] * 8 + [_vp],
     'pave_ms_deform_attn_backward_f64': [_vp] * 9 + [_c_int] * 8 + [_vp],
     'pave_preprocess_frames': [_vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp, _c_int, _vp],
@@ -47,7 +47,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
 
 _lib = None
-ABI_VERSION = 8  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 9  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

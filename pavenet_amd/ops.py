@@ -355,10 +355,20 @@ def enc_tile_supported(levels_hw):
                for l, (h, w) in enumerate(levels_hw))
 
 
-def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0):
+def enc_tile_window_shift(offset_bias):
+    """Window shift table for `deform_attn_enc_tile` from a `sampling_offsets.bias` [8*4*4*2]: the
+    mean offset of each (head, level) over its 4 points, rounded -> tuple of 64 ints (host values:
+    one device read, cache it per bias version)."""
+    m = offset_bias.detach().float().view(8, 4, 4, 2).mean(2).round().clamp_(-16, 16)
+    return tuple(int(v) for v in m.flatten().tolist())
+
+
+def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift=None):
     """Encoder deformable attention ([R2], T = 1) with LDS-staged value windows per image tile.
     value [F, S, 8, 32]; proj [F*S, >= 384]; ref [.., F*S, 4, 2] -> out [F*S, 256].
-    Same results as ``deform_attn_grid_fused(..., T=1)``.  Differentiable (fused_autograd.py)."""
+    Same results as ``deform_attn_grid_fused(..., T=1)``.  Differentiable (fused_autograd.py).
+    window_shift: optional 64 host ints [8 heads][4 levels][(dx, dy)] (`enc_tile_window_shift`):
+    moves each head's LDS window onto its mean sampling offset -- speed only, same results."""
     if torch.is_grad_enabled() and (value.requires_grad or proj.requires_grad or ref.requires_grad):
         from .fused_autograd import EncTileFunction
         return EncTileFunction.apply(value, proj, ref, levels_hw, variant)
@@ -376,11 +386,16 @@ def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0):
     import ctypes
     flat = [int(v) for hw in levels_hw for v in hw]
     hw_arr = (ctypes.c_int * 8)(*flat)
+    sh_arr = None
+    if window_shift is not None:
+        _require(len(window_shift) == 64, 'deform_attn_enc_tile: window_shift has 64 entries')
+        sh_arr = (ctypes.c_int * 64)(*[int(v) for v in window_shift])
     out = torch.empty((F_ * S, 256), dtype=f32, device=value.device)
     with torch.cuda.device(value.device), _Timed('enc_tile'):
         st = lib.pave_enc_deform_attn_tile_f32(
             value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), F_, S,
-            ctypes.cast(hw_arr, ctypes.c_void_p), proj.stride(0), int(variant), _stream_ptr())
+            ctypes.cast(hw_arr, ctypes.c_void_p), proj.stride(0), int(variant),
+            ctypes.cast(sh_arr, ctypes.c_void_p) if sh_arr is not None else None, _stream_ptr())
     native.check(st, 'deform_attn_enc_tile')
     return out
 

@@ -1,4 +1,5 @@
 """HIP kernels (through the C ABI) vs golden vectors and the oracle.  Needs an MI355X."""
+import math
 import os
 
 import numpy as np
@@ -296,6 +297,41 @@ def test_enc_tile_kernel_equals_direct_and_oracle(levels, sigma, gr, variant):
     idx = torch.arange(0, F * S, 7)
     exp = grid_expected(value, shapes, lsi, proj[idx], ref[:, idx], 1, idx // S)
     np.testing.assert_allclose(a.cpu()[idx].numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_enc_tile_window_shift_changes_nothing_but_speed(variant):
+    """Per-(head, level) window shifts (incl. shifts that push whole windows off the map) give
+    the same results (up to the summation order of the two passes): the window only decides which
+    corners come from LDS."""
+    from pavenet_amd.ops import deform_attn_enc_tile, enc_tile_window_shift
+    levels = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    S = sum(h * w for h, w in levels)
+    F = 2
+    g = torch.Generator().manual_seed(11)
+    value = torch.randn(F, S, 8, 32, generator=g).cuda()
+    proj = torch.randn(F * S, 384, generator=g)
+    bias = torch.zeros(8, 4, 4, 2)
+    for h in range(8):                       # the reference's ray initialisation, MO:227-240
+        d = torch.tensor([math.cos(h * math.pi / 4), math.sin(h * math.pi / 4)])
+        d = d / d.abs().max()
+        for i in range(4):
+            bias[h, :, i] = d * (i + 1)
+    proj[:, :256] = proj[:, :256] * 0.5 + bias.reshape(1, 256)
+    proj = proj.cuda()
+    ys = torch.cat([((torch.arange(h * w) // w).float() + 0.5) / h for h, w in levels])
+    xs = torch.cat([((torch.arange(h * w) % w).float() + 0.5) / w for h, w in levels])
+    ref = torch.stack([xs, ys], -1)[None, :, None, :].expand(F, S, 4, 2).reshape(1, F * S, 4, 2)
+    ref = ref.contiguous().cuda()
+    base = deform_attn_enc_tile(value, proj, ref, levels_hw=levels, variant=variant)
+    ray = enc_tile_window_shift(bias.reshape(-1).cuda())
+    assert len(ray) == 64 and 2 <= max(abs(v) for v in ray) <= 3     # mean of 1..4 px on the ray
+    for shift in (ray, tuple((-1) ** i * (i % 9) for i in range(64)), (60,) * 64):
+        out = deform_attn_enc_tile(value, proj, ref, levels_hw=levels, variant=variant,
+                                   window_shift=shift)
+        np.testing.assert_allclose(out.cpu().numpy(), base.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        deform_attn_enc_tile(value, proj, ref, levels_hw=levels, window_shift=(100,) * 64)
 
 
 def test_enc_tile_kernel_rejects_non_pyramid_and_survives_non_finite():

@@ -39,6 +39,9 @@ def main():
     ap.add_argument('--order', default='none')
     ap.add_argument('--enc-only', action='store_true')
     ap.add_argument('--ablate', action='store_true')
+    ap.add_argument('--ray', type=float, default=0.0,
+                    help='add the reference init pattern to the offsets: head h, point i at (i + 1) '
+                         '* ray * dir(h) px (MO:227-240 uses ray = 1)')
     args = ap.parse_args()
     dev = 'cuda'
     shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
@@ -51,6 +54,16 @@ def main():
     proj = torch.randn(U, 384, device=dev, generator=g)
     proj[:, :256] *= args.sigma
     ref = grid_refs(F, dev)
+    shift = None
+    if args.ray:
+        import math
+        th = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+        gi = torch.stack([th.cos(), th.sin()], -1)
+        gi = (gi / gi.abs().max(-1, keepdim=True)[0]).view(8, 1, 1, 2).repeat(1, 4, 4, 1)
+        for i in range(4):
+            gi[:, :, i, :] *= (i + 1) * args.ray
+        proj[:, :256] += gi.reshape(1, 256).to(dev)
+        shift = ops.enc_tile_window_shift(gi.reshape(-1))
     order = None
     if args.order != 'none':
         from pavenet_amd.locality import encoder_unit_order
@@ -63,8 +76,13 @@ def main():
     for variant in (0, 1):
         us = timeit(lambda: ops.deform_attn_enc_tile(value, proj, ref, levels_hw=LEVELS,
                                                      variant=variant))
-        print(f'enc_tile v{variant} frames={F} sigma={args.sigma}: {us:9.1f} us  {us / F:8.1f} us/frame  '
+        print(f'enc_tile v{variant} frames={F} sigma={args.sigma} ray={args.ray}: {us:9.1f} us  {us / F:8.1f} us/frame  '
               f'alg {alg / us / 1e3:7.1f} GB/s = {alg / us / 1e3 / 8000:.3f} of 8 TB/s')
+        if shift is not None:
+            us = timeit(lambda: ops.deform_attn_enc_tile(value, proj, ref, levels_hw=LEVELS,
+                                                         variant=variant, window_shift=shift))
+            print(f'enc_tile v{variant} ... with the per-head window shift: {us:9.1f} us  '
+                  f'= {alg / us / 1e3 / 8000:.3f} of 8 TB/s')
     if args.ablate:
         import ctypes
         from pavenet_amd import native
