@@ -19,8 +19,9 @@ import torch.nn.functional as F
 
 from . import ops
 from .bricks import (BaseModule, Linear, bias_init_with_prob, build_activation_layer,
-                     constant_init, inverse_sigmoid)
+                     constant_init)
 from .deform_attn import frame_prefixes
+from .transformer import _ref_update
 from .registry import HEADS, LOSSES, MMDET_MODELS, build_positional_encoding, build_transformer
 
 OKS_SIGMAS_POSETRACK15 = [.26, .79, .79, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87,
@@ -268,12 +269,12 @@ class VideoPoseHeadMulFrames(BaseModule):
                     br = fp
                     if T == 5 and t == 4:
                         br = 'next_'  # HEAD:503: next_next pose decoded with next_kpt_branches
-                    ref_t = inverse_sigmoid(reference[:, t * Q:(t + 1) * Q])
-                    aux_poses.append((getattr(self, br + 'kpt_branches')[lvl](hs[lvl]) + ref_t).sigmoid())
-            ref_c = inverse_sigmoid(reference[:, c * Q:(c + 1) * Q])
+                    aux_poses.append(_ref_update(getattr(self, br + 'kpt_branches')[lvl](hs[lvl]),
+                                                 reference[:, t * Q:(t + 1) * Q]))
             outputs_class = self.cls_branches[lvl](hs[lvl])
-            tmp_kpt = self.kpt_branches[lvl](hs[lvl]) + ref_c
-            outputs_kpt = tmp_kpt.sigmoid()
+            # (tmp + inverse_sigmoid(reference)).sigmoid(): one launch on the device
+            outputs_kpt = _ref_update(self.kpt_branches[lvl](hs[lvl]),
+                                      reference[:, c * Q:(c + 1) * Q])
             output_sigma = self.dec_fc_sigma_branches[lvl](hs[lvl]).sigmoid()
             outputs_classes.append(outputs_class)
             outputs_kpts.append(outputs_kpt)
@@ -308,11 +309,10 @@ class VideoPoseHeadMulFrames(BaseModule):
         for lvl in range(hs.shape[0]):
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             n = reference.shape[0] // T
-            reference = inverse_sigmoid(reference[c * n:(c + 1) * n])
             tmp_kpt = self.refine_kpt_branches[lvl](hs[lvl])
             tmp_sigma = self.refine_fc_sigma_branches[lvl](hs[lvl]).sigmoid()
             outs_score.append(torch.mean(1 - tmp_sigma, dim=2, keepdim=True))
-            outs_kpt.append((tmp_kpt + reference).sigmoid())
+            outs_kpt.append(_ref_update(tmp_kpt, reference[c * n:(c + 1) * n]))
             outs_sigma.append(tmp_sigma)
         return torch.stack(outs_kpt), torch.stack(outs_score), torch.stack(outs_sigma), hs
 
