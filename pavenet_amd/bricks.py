@@ -104,14 +104,17 @@ def _fusable(*tensors):
     return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
-# Dense projections (nn.Linear on [M, K] rows).  'native': hipBLASLt fp32 (v_mfma_f32_*_f32,
-# 157 TFLOP/s peak).  'bf16x3': the hand-written split GEMM (pave_gemm_bf16x3_f32): both operands
-# split EXACTLY into three bf16 terms, six bf16 MFMAs per product tile, fp32 accumulate -- fp32-level
-# accuracy (tests/test_ops_gpu.py::test_gemm_bf16x3_accuracy_vs_fp64) at 1.05-1.45x hipBLASLt's
-# fp32 rate on the K >= 256 shapes of this model.  Opt-in: the default bench number is 'native'.
+# Dense projections (nn.Linear on [M, K] rows).  'native' (the library default): hipBLASLt fp32
+# (v_mfma_f32_*_f32, 157 TFLOP/s peak).  'bf16x3' (bench.py's default, the headline mode): the
+# hand-written split GEMM (pave_gemm_bf16x3_f32): both operands split EXACTLY into three bf16 terms,
+# six bf16 MFMAs per product tile, fp32 accumulate -- fp32-level accuracy
+# (tests/test_ops_gpu.py::test_gemm_bf16x3_accuracy_vs_fp64) at 1.25-1.7x hipBLASLt's fp32 rate on
+# the shapes of this model (profiles/r02_gemm_shapes.txt); the whole golden / oracle GPU suite runs
+# in both modes at the same tolerances.
 # Layer i's closing LayerNorm can also emit `out + query_pos` for layer i+1 (one pass less);
-# measured SLOWER on the bench workload (122.4 vs 121.1 ms/step: the extra 640 MB store costs more
-# than the broadcast add it saves), so it is off unless PAVE_POS_FUSION=1.
+# measured SLOWER on the bench workload (the extra 640 MB store costs more than the broadcast add
+# it saves) and superseded by folding the positional term into the merged projection GEMM
+# (deform_attn._forward_merged), so it is off unless PAVE_POS_FUSION=1.
 FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
 _GEMM = {'mode': 'native', 'min_rows': 8192, 'ln_fused': True}
 
