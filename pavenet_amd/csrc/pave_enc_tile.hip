@@ -203,21 +203,44 @@ __device__ __forceinline__ void gather_level(float4& accA, float4& accB, const c
   }
 }
 
-// second pass: points of level LVL whose footprint is not in the LDS window, straight from global
-// memory, one point (8 x 16-byte loads per lane in flight) at a time
-template <int LVL>
-__device__ __forceinline__ void far_level(float4& accA, float4& accB, const char* vlane,
-                                          const PointDesc (&d)[4], int flags, int W, int S) {
-  const int fl = qbi<LVL>(flags);
+// second pass: points whose footprint is not in the LDS window, straight from global memory.
+// Each quad (= one (query, head) pair) walks ITS OWN far points -- a 16-bit mask, lane k's four
+// points at bits 4k .. 4k + 3, lowest first, i.e. in (level, point) order -- so a wave runs
+// max-over-its-pairs rounds instead of one round per (level, point) that ANY pair needs.  The
+// round's descriptor (token, 4 weights, visiting-order bits) is selected by point in the owning
+// lane and broadcast inside the quad with ds_bpermute (the source lane is data dependent).
+__device__ __forceinline__ int sel4i(int x0, int x1, int x2, int x3, int q) {
+  const int lo = (q & 1) ? x1 : x0, hi = (q & 1) ? x3 : x2;
+  return (q & 2) ? hi : lo;
+}
+__device__ __forceinline__ float sel4f(float x0, float x1, float x2, float x3, int q) {
+  const float lo = (q & 1) ? x1 : x0, hi = (q & 1) ? x3 : x2;
+  return (q & 2) ? hi : lo;
+}
+__device__ __forceinline__ void far_quad_loop(float4& accA, float4& accB, const char* vlane,
+                                              const PointDesc (&d)[4], int flags, int lane,
+                                              int W0, int W1, int W2, int W3, int S) {
+  const int fm = (flags & 1) | ((flags >> 2) & 2) | ((flags >> 4) & 4) | ((flags >> 6) & 8);
+  int M = qbi<0>(fm) | (qbi<1>(fm) << 4) | (qbi<2>(fm) << 8) | (qbi<3>(fm) << 12);
+  const int quad_base = (lane & ~3) << 2;   // byte address of the quad's lane 0 for ds_bpermute
+  while (__builtin_amdgcn_ballot_w64(M != 0) != 0ull) {
+    const bool act = M != 0;
+    const int j = act ? __builtin_ctz(M) : 0;
+    M &= M - 1;
+    const int src = j >> 2, pt = j & 3;
+    const int addr = quad_base + (src << 2);
+    // the owning lane's descriptor of point pt (every lane selects from its own, lane src's counts)
+    const int t00 = __builtin_amdgcn_ds_bpermute(
+        addr, sel4i(d[0].tok00, d[1].tok00, d[2].tok00, d[3].tok00, pt));
+    const int fb = __builtin_amdgcn_ds_bpermute(addr, (flags >> (3 * pt)) & 7);
+    float w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f = fl >> (3 * i);
-    if (__builtin_amdgcn_ballot_w64((f & 1) != 0) == 0ull) continue;
-    const int t00 = qbi<LVL>(d[i].tok00);
-    const float w0 = qbf<LVL>(d[i].w[0]), w1 = qbf<LVL>(d[i].w[1]), w2 = qbf<LVL>(d[i].w[2]),
-                w3 = qbf<LVL>(d[i].w[3]);
-    if (f & 1) {
-      const int e = (f >> 1) & 1, eb = (f >> 2) & 1;
+    for (int c = 0; c < 4; ++c)
+      w[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                 addr, __builtin_bit_cast(int, sel4f(d[0].w[c], d[1].w[c], d[2].w[c], d[3].w[c], pt))));
+    const int W = sel4i(W0, W1, W2, W3, src);   // lane src <-> level src
+    if (act) {
+      const int e = (fb >> 1) & 1, eb = (fb >> 2) & 1;
       // a corner outside the map has weight 0 and may have any token: clamp, never mask by value
       const int t0 = min(max(t00 + e, 0), S - 1), t1 = min(max(t00 + 1 - e, 0), S - 1);
       const int t2 = min(max(t00 + W + eb, 0), S - 1), t3 = min(max(t00 + W + 1 - eb, 0), S - 1);
@@ -227,14 +250,14 @@ __device__ __forceinline__ void far_level(float4& accA, float4& accB, const char
       const float4* r3 = reinterpret_cast<const float4*>(vlane + (size_t)t3 * kRowBytes);
       const float4 a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
       const float4 a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
-      fma4(accA, w0, a0);
-      fma4(accB, w0, b0);
-      fma4(accA, w1, a1);
-      fma4(accB, w1, b1);
-      fma4(accA, w2, a2);
-      fma4(accB, w2, b2);
-      fma4(accA, w3, a3);
-      fma4(accB, w3, b3);
+      fma4(accA, w[0], a0);
+      fma4(accB, w[0], b0);
+      fma4(accA, w[1], a1);
+      fma4(accB, w[1], b1);
+      fma4(accA, w[2], a2);
+      fma4(accB, w[2], b2);
+      fma4(accA, w[3], a3);
+      fma4(accB, w[3], b3);
     }
   }
 }
@@ -365,10 +388,7 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
     // memory order inside the lane's 32 bytes: chunk 2k (flo), then 2k + 1 (fhi)
     float4 flo = make_float4(0.f, 0.f, 0.f, 0.f), fhi = flo;
     const char* vlane = vhead + k * 32;
-    far_level<0>(flo, fhi, vlane, d, flags, p.Ws[0], p.S);
-    far_level<1>(flo, fhi, vlane, d, flags, p.Ws[1], p.S);
-    far_level<2>(flo, fhi, vlane, d, flags, p.Ws[2], p.S);
-    far_level<3>(flo, fhi, vlane, d, flags, p.Ws[3], p.S);
+    far_quad_loop(flo, fhi, vlane, d, flags, lane, p.Ws[0], p.Ws[1], p.Ws[2], p.Ws[3], p.S);
     const float4 fa = setr ? fhi : flo, fb = setr ? flo : fhi;  // accA holds the chunk at offA
     accA.x += fa.x, accA.y += fa.y, accA.z += fa.z, accA.w += fa.w;
     accB.x += fb.x, accB.y += fb.y, accB.z += fb.z, accB.w += fb.w;
