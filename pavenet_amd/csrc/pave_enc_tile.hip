@@ -217,6 +217,48 @@ __device__ __forceinline__ float sel4f(float x0, float x1, float x2, float x3, i
   const float lo = (q & 1) ? x1 : x0, hi = (q & 1) ? x3 : x2;
   return (q & 2) ? hi : lo;
 }
+// one far point of the quad: descriptor of entry j (lane j >> 2, point j & 3) broadcast, the 8 loads
+struct FarPoint {
+  float w[4];
+  float4 a[4], b[4];
+};
+__device__ __forceinline__ void far_fetch(FarPoint& f, bool act, int j, const char* vlane,
+                                          const PointDesc (&d)[4], int flags, int quad_base, int W0,
+                                          int W1, int W2, int W3, int S) {
+  const int src = j >> 2, pt = j & 3;
+  const int addr = quad_base + (src << 2);
+  // the owning lane's descriptor of point pt (every lane selects from its own, lane src's counts)
+  const int t00 = __builtin_amdgcn_ds_bpermute(
+      addr, sel4i(d[0].tok00, d[1].tok00, d[2].tok00, d[3].tok00, pt));
+  const int fb = __builtin_amdgcn_ds_bpermute(addr, (flags >> (3 * pt)) & 7);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    f.w[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+                 addr, __builtin_bit_cast(int, sel4f(d[0].w[c], d[1].w[c], d[2].w[c], d[3].w[c], pt))));
+  const int W = sel4i(W0, W1, W2, W3, src);   // lane src <-> level src
+  if (act) {
+    const int e = (fb >> 1) & 1, eb = (fb >> 2) & 1;
+    // a corner outside the map has weight 0 and may have any token: clamp, never mask by value
+    const int t0 = min(max(t00 + e, 0), S - 1), t1 = min(max(t00 + 1 - e, 0), S - 1);
+    const int t2 = min(max(t00 + W + eb, 0), S - 1), t3 = min(max(t00 + W + 1 - eb, 0), S - 1);
+    const int t[4] = {t0, t1, t2, t3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4* r = reinterpret_cast<const float4*>(vlane + (size_t)t[c] * kRowBytes);
+      f.a[c] = r[0];
+      f.b[c] = r[1];
+    }
+  }
+}
+__device__ __forceinline__ void far_accumulate(float4& accA, float4& accB, const FarPoint& f) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    fma4(accA, f.w[c], f.a[c]);
+    fma4(accB, f.w[c], f.b[c]);
+  }
+}
+
+template <int PER_ROUND>
 __device__ __forceinline__ void far_quad_loop(float4& accA, float4& accB, const char* vlane,
                                               const PointDesc (&d)[4], int flags, int lane,
                                               int W0, int W1, int W2, int W3, int S) {
@@ -224,46 +266,25 @@ __device__ __forceinline__ void far_quad_loop(float4& accA, float4& accB, const 
   int M = qbi<0>(fm) | (qbi<1>(fm) << 4) | (qbi<2>(fm) << 8) | (qbi<3>(fm) << 12);
   const int quad_base = (lane & ~3) << 2;   // byte address of the quad's lane 0 for ds_bpermute
   while (__builtin_amdgcn_ballot_w64(M != 0) != 0ull) {
-    const bool act = M != 0;
-    const int j = act ? __builtin_ctz(M) : 0;
-    M &= M - 1;
-    const int src = j >> 2, pt = j & 3;
-    const int addr = quad_base + (src << 2);
-    // the owning lane's descriptor of point pt (every lane selects from its own, lane src's counts)
-    const int t00 = __builtin_amdgcn_ds_bpermute(
-        addr, sel4i(d[0].tok00, d[1].tok00, d[2].tok00, d[3].tok00, pt));
-    const int fb = __builtin_amdgcn_ds_bpermute(addr, (flags >> (3 * pt)) & 7);
-    float w[4];
+    FarPoint f[PER_ROUND];
+    bool act[PER_ROUND];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      w[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
-                 addr, __builtin_bit_cast(int, sel4f(d[0].w[c], d[1].w[c], d[2].w[c], d[3].w[c], pt))));
-    const int W = sel4i(W0, W1, W2, W3, src);   // lane src <-> level src
-    if (act) {
-      const int e = (fb >> 1) & 1, eb = (fb >> 2) & 1;
-      // a corner outside the map has weight 0 and may have any token: clamp, never mask by value
-      const int t0 = min(max(t00 + e, 0), S - 1), t1 = min(max(t00 + 1 - e, 0), S - 1);
-      const int t2 = min(max(t00 + W + eb, 0), S - 1), t3 = min(max(t00 + W + 1 - eb, 0), S - 1);
-      const float4* r0 = reinterpret_cast<const float4*>(vlane + (size_t)t0 * kRowBytes);
-      const float4* r1 = reinterpret_cast<const float4*>(vlane + (size_t)t1 * kRowBytes);
-      const float4* r2 = reinterpret_cast<const float4*>(vlane + (size_t)t2 * kRowBytes);
-      const float4* r3 = reinterpret_cast<const float4*>(vlane + (size_t)t3 * kRowBytes);
-      const float4 a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
-      const float4 a2 = r2[0], b2 = r2[1], a3 = r3[0], b3 = r3[1];
-      fma4(accA, w[0], a0);
-      fma4(accB, w[0], b0);
-      fma4(accA, w[1], a1);
-      fma4(accB, w[1], b1);
-      fma4(accA, w[2], a2);
-      fma4(accB, w[2], b2);
-      fma4(accA, w[3], a3);
-      fma4(accB, w[3], b3);
+    for (int u = 0; u < PER_ROUND; ++u) {   // all loads of the round in flight before the first FMA
+      act[u] = M != 0;
+      const int j = act[u] ? __builtin_ctz(M) : 0;
+      M &= M - 1;
+      far_fetch(f[u], act[u], j, vlane, d, flags, quad_base, W0, W1, W2, W3, S);
     }
+#pragma unroll
+    for (int u = 0; u < PER_ROUND; ++u)     // (level, point) order within the pair, as always
+      if (act[u]) far_accumulate(accA, accB, f[u]);
   }
 }
 
 // TILE = 8: 64 + 16 + 4 + 1 = 85 queries -> 96 pair slots = 6 waves of 16 pairs
 // ABL: timing-only ablations for tools/ (1: no window staging, 2: no gather loop); 0 in the product
+constexpr int FAR_PER_ROUND = 1;   // far points of a pair fetched per round of the second pass (2: spills at 96 VGPRs, 2-3x slower)
+
 template <int W0, int W1, int W2, int W3, int MB0, int MB1, int MB2, int MB3, int WPE, int ABL = 0>
 __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) {
   using G = WinGeom<W0, W1, W2, W3>;
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
     // memory order inside the lane's 32 bytes: chunk 2k (flo), then 2k + 1 (fhi)
     float4 flo = make_float4(0.f, 0.f, 0.f, 0.f), fhi = flo;
     const char* vlane = vhead + k * 32;
-    far_quad_loop(flo, fhi, vlane, d, flags, lane, p.Ws[0], p.Ws[1], p.Ws[2], p.Ws[3], p.S);
+    far_quad_loop<FAR_PER_ROUND>(flo, fhi, vlane, d, flags, lane, p.Ws[0], p.Ws[1], p.Ws[2], p.Ws[3], p.S);
     const float4 fa = setr ? fhi : flo, fb = setr ? flo : fhi;  // accA holds the chunk at offA
     accA.x += fa.x, accA.y += fa.y, accA.z += fa.z, accA.w += fa.w;
     accB.x += fb.x, accB.y += fb.y, accB.z += fb.z, accB.w += fb.w;
