@@ -252,10 +252,10 @@ class ResNet(BaseModule):
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
             tail = f.get((name, bi, 'tail_ds_kn'))
-            from .bricks import _split_weight, get_gemm_mode
+            from .bricks import _GEMM, _split_weight, get_gemm_mode
             if (s > 1 and tail is None and get_gemm_mode() == 'bf16x3' and not torch.is_grad_enabled()
                     and wd.shape[0] % 128 == 0 and wd.shape[1] % 64 == 0
-                    and yrows.shape[0] >= 8192
+                    and yrows.shape[0] >= _GEMM['min_rows']
                     and (w3_kn is not None or split_gemm_ok(yrows, w3.flatten(1)))):
                 # stride-2 downsample: the GEMM reads the strided pixels itself (no slice copy)
                 idt = ops.conv1x1_strided_split(x, _split_weight(wd.flatten(1)),
