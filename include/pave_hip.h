@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 10
+#define PAVE_ABI_VERSION 9
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -261,41 +261,6 @@ int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_p
                             const float* bias, const float* residual, long long residual_rows,
                             float* out, float* out2, int n_split, long long M, int K, int N,
                             int relu, int nplanes, void* stream);
-
-/*
- * The 3-plane split GEMM with activations handed over as bf16 PLANES between launches: a producer
- * writes its fp32 result as the exact 3-term split [3][M][N] (out_planes), the consumer reads that
- * as a_planes [3][M][K] and stages it with plain copies -- no on-the-fly split, and none of the
- * N / 128-fold re-splitting of the same A tile by every column tile.  Results are bit-identical to
- * passing the fp32 activation.  One argument block covers the forms the encoder layer chains
- * (third_party/mmcv/mmcv/cnn/bricks/transformer.py:1046-1120, 1316-1353):
- *   out_proj + identity + LayerNorm  (fp32 in,     fp32 + planes out)
- *   FFN layers.0.0 + ReLU            (planes in,   planes out)
- *   FFN layers.1 + identity + LN     (planes in,   fp32 + planes out)
- *   out = act(A W^T + bias + residual) in general; LayerNorm needs N == 256 (the block owns rows).
- */
-typedef struct pave_gemm_args {
-  const float* a;          /* [M, K] fp32, or NULL when a_planes is given */
-  const void* a_planes;    /* [3][M][K] bf16 planes (a previous call's out_planes), or NULL */
-  const float* a_bias;     /* [K] or NULL: A' = relu(A + a_bias); fp32 in / out only */
-  const void* w_planes;    /* the weight as pave_gemm_bf16x3_f32 takes it (3 planes) */
-  const float* bias;       /* [N] or NULL */
-  const float* residual;   /* [M, N], or [residual_rows, N] indexed by m % residual_rows, or NULL */
-  long long residual_rows; /* 0: residual is [M, N] */
-  float* out;              /* [M, N] fp32; may be NULL when out_planes is given (no LayerNorm) */
-  void* out_planes;        /* [3][M][N] bf16 planes, or NULL */
-  const float* ln_gamma;   /* LayerNorm over the row: gamma, beta [N], eps; NULL = none */
-  const float* ln_beta;
-  float ln_eps;
-  long long M;
-  int K, N, relu;
-} pave_gemm_args;
-int pave_gemm_bf16x3_args_f32(const pave_gemm_args* args, void* stream);
-/* pave_gemm_bf16x3_ex_f32 (row-periodic residual table, two dense outputs) with A as planes. */
-int pave_gemm_bf16x3_ex_planes_f32(const void* a_planes, const void* w_planes, const float* bias,
-                                   const float* residual, long long residual_rows, float* out,
-                                   float* out2, int n_split, long long M, int K, int N, int relu,
-                                   void* stream);
 
 /*
  * out[i] = sigmoid(tmp[i] + inverse_sigmoid(ref[i])), inverse_sigmoid(x) = log(max(clamp(x, 0, 1),

@@ -108,23 +108,11 @@ struct LnArgs {
 //   global loads run two slabs ahead (registers), LDS is double buffered with ONE barrier per
 //   slab, and the operand fragments of slab s+1 are read from LDS between the two halves of
 //   slab s's MFMAs, into a second fragment register set.
-// Activations handed from one split GEMM to the next as bf16 PLANES [3][M][K] (the exact 3-term
-// split, written by the producer's epilogue): the consumer stages them with plain 16-byte copies
-// -- no VALU split, and none of the N / BN-fold re-splitting of the same A tile by every column
-// tile.  Results are bit-identical to splitting the fp32 activation on the fly.
-struct PlaneArgs {
-  const uint16_t* a_planes;   // AIN == 1: A as planes [3][M][K] (A itself unused)
-  uint16_t* out_planes;       // OUTP >= 1: the output as planes [3][M][N]
-};
-
-// AIN: 0 = fp32 A rows split while staged, 1 = pre-split planes.  OUTP: 0 = fp32 output,
-// 1 = planes only, 2 = both.
-template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, int WGN, bool LNORM, int AIN, int OUTP>
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, int WGN, bool LNORM>
 __device__ __forceinline__ void gemm_split_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln,
-    const PlaneArgs pa) {
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
   constexpr int NT = 128 * WGN, NW = 2 * WGN;                  // threads, waves (2 x WGN grid)
   constexpr int BM = 2 * TM * 32, BN = WGN * TN * 32;
   constexpr int A_PLANE = BM * RST, W_PLANE = BN * RST;        // bytes
@@ -140,8 +128,6 @@ __device__ __forceinline__ void gemm_split_body(
   static_assert(!(CONV != 0 && ABIAS), "the convolution forms have no A-side bias");
   static_assert(!F16 || P == 1, "fp16 operands: single plane only");
   static_assert(TM % 2 == 0, "the MFMAs of a slab are issued in two halves of TM / 2 row tiles");
-  static_assert(AIN == 0 || (P == 3 && !F16 && CONV == 0 && !ABIAS), "plane input: plain 3-plane GEMM");
-  static_assert(OUTP == 0 || (P == 3 && !F16), "plane output: 3-plane forms");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,8 +152,6 @@ __device__ __forceinline__ void gemm_split_body(
   // group are 2 apart (offsets 0, 24, 16, 8 mod 32: conflict-free); global addresses follow.
   const int a_row = stage_row_perm(tid >> 2);
   const float* a_ptr[APASS];
-  const uint16_t* ap_ptr[APASS];
-  const long long a_plane_stride = (long long)M * K;
   int iy0[APASS], ix0[APASS];   // CONV: top-left input pixel of the row's 3x3 window
 #pragma unroll
   for (int q = 0; q < APASS; ++q) {
@@ -193,7 +177,6 @@ __device__ __forceinline__ void gemm_split_body(
     } else {
       a_ptr[q] = A + r * K + a_seg * 4;
     }
-    if (AIN == 1) ap_ptr[q] = pa.a_planes + r * K + a_seg * 8;   // 8 k of the 32-k slab pair
   }
   // W operand, slab-major [K/16][3][N][16] bf16 (host layout: one slab of a column tile is 3
   // contiguous 4-KiB runs): uint4 index v = tid + NT*q -> plane, row, 16-byte half
@@ -220,22 +203,14 @@ __device__ __forceinline__ void gemm_split_body(
   // per row are the halves of one 128-byte line, so every line crosses L2 -> L1 once.  Two sets
   // alternate; a pair is loaded 3 slabs before its first use.
   f32x4 ra0[2][APASS], ra1[2][APASS];
-  u32x4 rp0[APASS][3], rp1[APASS][3];   // AIN == 1: this thread's 8 k of a slab pair, per plane
   u32x4 rw0[2][WV], rw1[2][WV];
   f32x4 rb0[2], rb1[2];
   const int nslabs = K / BK;
   const int npairs = nslabs / 2;
-  auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rp)[APASS][3], u32x4 (&rw)[2][WV],
-                   f32x4 (&rb)[2]) {
+  auto gload = [&](int pair, f32x4 (&ra)[2][APASS], u32x4 (&rw)[2][WV], f32x4 (&rb)[2]) {
     const int pp = pair < npairs ? pair : npairs - 1;  // past the end: repeat (never consumed)
     const int k0 = pp * 2 * BK;
-    if (AIN == 1) {
-#pragma unroll
-      for (int q = 0; q < APASS; ++q)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          rp[q][pl] = *reinterpret_cast<const u32x4*>(ap_ptr[q] + pl * a_plane_stride + k0);
-    } else if (CONV == 2) {
+    if (CONV == 2) {
       // 7x7 / stride 2 / pad 3 stem on the NCHW image: K axis = (c, ky, kx padded 7 -> 8), i.e. 24
       // rows of 8 (21 real); a thread's float4 is one half of such a row: 4 consecutive input
       // pixels of channel c, row iy -- an unaligned 16-byte load (per-element guarded at the edges)
@@ -294,21 +269,8 @@ __device__ __forceinline__ void gemm_split_body(
       rb[1] = *reinterpret_cast<const f32x4*>(a_bias + k0 + BK + a_seg * 4);
     }
   };
-  auto stage = [&](unsigned char* buf, const f32x4 (&av)[APASS], const u32x4 (&pv)[APASS][3],
-                   const int h, const u32x4 (&wv)[WV],
+  auto stage = [&](unsigned char* buf, const f32x4 (&av)[APASS], const u32x4 (&wv)[WV],
                    const f32x4 abv) {  // registers -> LDS (A split on the way)
-    if (AIN == 1) {
-      // slab h of the pair lives in the threads whose 8 k are its half (a_seg >> 1 == h): one
-      // 16-byte store per plane (the 2 row-adjacent lanes of a store group hit distinct banks)
-      if ((a_seg >> 1) == h) {
-#pragma unroll
-        for (int q = 0; q < APASS; ++q)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            *reinterpret_cast<u32x4*>(buf + pl * A_PLANE + (a_row + AROWS * q) * RST +
-                                      (a_seg & 1) * 16) = pv[q][pl];
-      }
-    } else
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
       float4 t = make_float4(av[q].x, av[q].y, av[q].z, av[q].w);
@@ -373,9 +335,9 @@ __device__ __forceinline__ void gemm_split_body(
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + BUF;
   // prologue: pairs 0 and 1 in registers, slab 0 staged, its first fragments read
-  gload(0, ra0, rp0, rw0, rb0);
-  gload(1, ra1, rp1, rw1, rb1);
-  stage(buf0, ra0[0], rp0, 0, rw0[0], rb0[0]);
+  gload(0, ra0, rw0, rb0);
+  gload(1, ra1, rw1, rb1);
+  stage(buf0, ra0[0], rw0[0], rb0[0]);
   __syncthreads();
   fread_a(buf0, faL, 0);
   fread_w(buf0, fbA);
@@ -398,10 +360,10 @@ __device__ __forceinline__ void gemm_split_body(
   // reloaded with the pair two ahead right after its second slab has been staged.
   for (int s = 0; s < nslabs; s += 4) {
     const int pr = s >> 1;
-    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rp0, 1, rw0[1], rb0[1]), gload(pr + 2, ra0, rp0, rw0, rb0))
-    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra1[0], rp1, 0, rw1[0], rb1[0]), (void)0)
-    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rp1, 1, rw1[1], rb1[1]), gload(pr + 3, ra1, rp1, rw1, rb1))
-    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra0[0], rp0, 0, rw0[0], rb0[0]), (void)0)
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra0[1], rw0[1], rb0[1]), gload(pr + 2, ra0, rw0, rb0))
+    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra1[0], rw1[0], rb1[0]), (void)0)
+    PAVE_SLAB(buf0, buf1, fbA, fbB, stage(buf1, ra1[1], rw1[1], rb1[1]), gload(pr + 3, ra1, rw1, rb1))
+    PAVE_SLAB(buf1, buf0, fbB, fbA, stage(buf0, ra0[0], rw0[0], rb0[0]), (void)0)
   }
 #undef PAVE_SLAB
 
@@ -498,14 +460,7 @@ __device__ __forceinline__ void gemm_split_body(
           t.y = fmaf(t.y * rstd, g4.y, be4.y);
           t.z = fmaf(t.z * rstd, g4.z, be4.z);
           t.w = fmaf(t.w * rstd, g4.w, be4.w);
-          if (OUTP != 1) *reinterpret_cast<float4*>(out + gm * N + ncol) = t;
-          if (OUTP >= 1) {
-            uint2 pl[3];
-            split4<3, false>(t, pl);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              *reinterpret_cast<uint2*>(pa.out_planes + (long long)q * M * N + gm * N + ncol) = pl[q];
-          }
+          *reinterpret_cast<float4*>(out + gm * N + ncol) = t;
         }
       }
     } else
@@ -531,14 +486,7 @@ __device__ __forceinline__ void gemm_split_body(
           v.z = fmaxf(v.z, 0.f);
           v.w = fmaxf(v.w, 0.f);
         }
-        if (OUTP != 1) *reinterpret_cast<float4*>(obase + gm * ldo + ocol) = v;
-        if (OUTP >= 1) {
-          uint2 pl[3];
-          split4<3, false>(v, pl);
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            *reinterpret_cast<uint2*>(pa.out_planes + (long long)q * M * N + gm * N + ncol) = pl[q];
-        }
+        *reinterpret_cast<float4*>(obase + gm * ldo + ocol) = v;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -552,31 +500,28 @@ template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln,
-    const PlaneArgs pa) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false, 0, 0>(A, Wp, bias, residual, out, M, K, N,
-                                                               relu, a_bias, g, os, ln, pa);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                         a_bias, g, os, ln);
 }
-template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, int AIN, int OUTP>
+template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_occ2(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln,
-    const PlaneArgs pa) {
-  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false, AIN, OUTP>(A, Wp, bias, residual, out, M, K,
-                                                                    N, relu, a_bias, g, os, ln, pa);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, F16, CONV, 2, false>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                         a_bias, g, os, ln);
 }
 // 128 x 256 block tile, 8 waves (2 x 4), one workgroup per CU at two waves per SIMD: the A tile
 // is split (VALU) and staged once for twice the MFMA work of the 128 x 128 form, and with N == 256
 // the block owns whole output rows, so LayerNorm can run in the epilogue (LNORM).
-template <int TM, int TN, bool ABIAS, int P, int CONV, bool LNORM, int AIN, int OUTP>
+template <int TM, int TN, bool ABIAS, int P, int CONV, bool LNORM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x3_kernel_w8(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln,
-    const PlaneArgs pa) {
-  gemm_split_body<TM, TN, ABIAS, P, false, CONV, 4, LNORM, AIN, OUTP>(A, Wp, bias, residual, out, M,
-                                                                      K, N, relu, a_bias, g, os, ln, pa);
+    const float* __restrict__ a_bias, const ConvGeom g, const OutSplit os, const LnArgs ln) {
+  gemm_split_body<TM, TN, ABIAS, P, false, CONV, 4, LNORM>(A, Wp, bias, residual, out, M, K, N, relu,
+                                                           a_bias, g, os, ln);
 }
 
 // fp32 [n] -> nplanes bf16 planes [nplanes][n]: truncation terms, the last one rounded to
@@ -611,14 +556,12 @@ bool use_w8(long long M, int K, int N) {
 }
 
 template <int TM, int TN, bool ABIAS, int P, bool F16, int CONV, bool OCC2 = (P == 1), int WGN = 2,
-          bool LNORM = false, int AIN = 0, int OUTP = 0>
+          bool LNORM = false>
 int launch_gemm(const float* a, const uint16_t* w, const float* bias, const float* residual,
                 float* out, long long M, int K, int N, int relu, const float* a_bias,
                 hipStream_t st, const ConvGeom g = ConvGeom{0, 0, 0, 0, 0, 0},
                 const OutSplit os = OutSplit{nullptr, 0, 0},
-                const LnArgs ln = LnArgs{nullptr, nullptr, 0.f},
-                const PlaneArgs pa = PlaneArgs{nullptr, nullptr}) {
-  static_assert((AIN == 0 && OUTP == 0) || OCC2 || WGN == 4, "plane forms: two-waves-per-SIMD kernels");
+                const LnArgs ln = LnArgs{nullptr, nullptr, 0.f}) {
   constexpr int NT = 128 * WGN, NW = 2 * WGN;
   constexpr int BM = 2 * TM * 32, BN = WGN * TN * 32;
   constexpr int EPI = NW * 32 * (TN * 32 + 4) * 4 + (LNORM ? 2 * BM * WGN * 4 : 0);
@@ -627,10 +570,10 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: grid too large");
   using kern_t = void (*)(const float*, const uint16_t*, const float*, const float*, float*, int, int,
-                          int, int, const float*, ConvGeom, OutSplit, LnArgs, PlaneArgs);
+                          int, int, const float*, ConvGeom, OutSplit, LnArgs);
   kern_t kern;
-  if constexpr (WGN == 4) kern = gemm_bf16x3_kernel_w8<TM, TN, ABIAS, P, CONV, LNORM, AIN, OUTP>;
-  else if constexpr (OCC2) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV, AIN, OUTP>;
+  if constexpr (WGN == 4) kern = gemm_bf16x3_kernel_w8<TM, TN, ABIAS, P, CONV, LNORM>;
+  else if constexpr (OCC2) kern = gemm_bf16x3_kernel_occ2<TM, TN, ABIAS, P, F16, CONV>;
   else kern = gemm_bf16x3_kernel<TM, TN, ABIAS, P, F16, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -640,7 +583,7 @@ int launch_gemm(const float* a, const uint16_t* w, const float* bias, const floa
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(NT), SMEM, st, a, w, bias, residual, out,
-                     (int)M, K, N, relu, a_bias, g, os, ln, pa);
+                     (int)M, K, N, relu, a_bias, g, os, ln);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -688,25 +631,6 @@ int pave_gemm_bf16x3_ex_f32(const float* a, const float* a_bias, const void* w_p
   return gemm_split_entry(a, a_bias, w_planes, bias, residual, out, M, K, N, relu, nplanes, stream,
                           OutSplit{out2, out2 ? n_split : 0,
                                    residual_rows >= M ? 0 : (int)residual_rows});
-}
-
-int pave_gemm_bf16x3_ex_planes_f32(const void* a_planes, const void* w_planes, const float* bias,
-                                   const float* residual, long long residual_rows, float* out,
-                                   float* out2, int n_split, long long M, int K, int N, int relu,
-                                   void* stream) {
-  if (!a_planes || !w_planes || !out)
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex_planes: null pointer");
-  if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31) || K % 64 != 0 || N % 128 != 0)
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex_planes: bad sizes (K %% 64, N %% 128)");
-  if (residual_rows < 0 || residual_rows >= (1ll << 31) || (residual_rows > 0 && !residual))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex_planes: bad residual_rows");
-  if (out2 && (n_split <= 0 || n_split >= N || n_split % 128 != 0))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ex_planes: 0 < n_split < N, n_split %% 128 == 0");
-  const OutSplit os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows};
-  return launch_gemm<2, 2, false, 3, false, 0, true, 2, false, 1, 0>(
-      nullptr, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, relu, nullptr,
-      reinterpret_cast<hipStream_t>(stream), ConvGeom{0, 0, 0, 0, 0, 0}, os,
-      LnArgs{nullptr, nullptr, 0.f}, PlaneArgs{static_cast<const uint16_t*>(a_planes), nullptr});
 }
 
 static int gemm_split_entry(const float* a, const float* a_bias, const void* w_planes,
@@ -770,49 +694,6 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
       a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, nullptr,
       reinterpret_cast<hipStream_t>(stream), ConvGeom{0, 0, 0, 0, 0, 0}, OutSplit{nullptr, 0, 0},
       LnArgs{gamma, beta, eps});
-}
-
-int pave_gemm_bf16x3_args_f32(const pave_gemm_args* x, void* stream) {
-  if (!x || !x->w_planes) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: null pointer");
-  const bool ain = x->a_planes != nullptr, ln = x->ln_gamma != nullptr;
-  const int outp = x->out_planes ? (x->out ? 2 : 1) : 0;
-  if ((!x->a && !ain) || (!x->out && !x->out_planes))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: needs a or a_planes, out or out_planes");
-  if (x->M <= 0 || x->K <= 0 || x->N <= 0 || x->M >= (1ll << 31))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: bad sizes (0 < M < 2^31)");
-  if (x->K % 64 != 0 || x->N % 128 != 0)
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: K %% 64 == 0 and N %% 128 == 0 required");
-  if (ln && (x->N != 256 || !x->ln_beta || x->relu))
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_args: LayerNorm needs N == 256, beta, no ReLU");
-  if (x->residual_rows < 0 || x->residual_rows >= (1ll << 31) || (x->residual_rows > 0 && !x->residual))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: bad residual_rows");
-  if (x->a_bias && (ain || outp || ln))
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_args: a_bias only with fp32 in / out, no LayerNorm");
-  if (x->residual_rows > 0 && (outp || ln))
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_args: residual table only with fp32 output, no LayerNorm");
-  if (outp == 1 && x->residual && x->residual == x->out)
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_args: in-place residual needs the fp32 output");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const uint16_t* w = static_cast<const uint16_t*>(x->w_planes);
-  const ConvGeom g0{0, 0, 0, 0, 0, 0};
-  const OutSplit os{nullptr, 0, x->residual_rows >= x->M ? 0 : (int)x->residual_rows};
-  const LnArgs la{x->ln_gamma, x->ln_beta, x->ln_eps};
-  const PlaneArgs pa{static_cast<const uint16_t*>(x->a_planes), static_cast<uint16_t*>(x->out_planes)};
-#define PAVE_ARGS x->a, w, x->bias, x->residual, x->out, x->M, x->K, x->N, x->relu, x->a_bias, st, g0, os, la, pa
-  if (ln) {   // 128 x 256 tile on 8 waves, LayerNorm in the epilogue
-    if (!ain && outp == 0) return launch_gemm<2, 2, false, 3, false, 0, true, 4, true, 0, 0>(PAVE_ARGS);
-    if (ain && outp == 0) return launch_gemm<2, 2, false, 3, false, 0, true, 4, true, 1, 0>(PAVE_ARGS);
-    if (!ain && outp == 2) return launch_gemm<2, 2, false, 3, false, 0, true, 4, true, 0, 2>(PAVE_ARGS);
-    if (ain && outp == 2) return launch_gemm<2, 2, false, 3, false, 0, true, 4, true, 1, 2>(PAVE_ARGS);
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_args: LayerNorm output is fp32 or fp32 + planes");
-  }
-  if (x->a_bias) return launch_gemm<2, 2, true, 3, false, 0, true>(PAVE_ARGS);
-  if (!ain && outp == 0) return launch_gemm<2, 2, false, 3, false, 0, true>(PAVE_ARGS);
-  if (!ain && outp == 1) return launch_gemm<2, 2, false, 3, false, 0, true, 2, false, 0, 1>(PAVE_ARGS);
-  if (ain && outp == 0) return launch_gemm<2, 2, false, 3, false, 0, true, 2, false, 1, 0>(PAVE_ARGS);
-  if (ain && outp == 1) return launch_gemm<2, 2, false, 3, false, 0, true, 2, false, 1, 1>(PAVE_ARGS);
-#undef PAVE_ARGS
-  return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_args: fp32 + planes output only with LayerNorm");
 }
 
 void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tools/)

@@ -39,9 +39,6 @@ SIGNATURES = {
     'pave_ref_update_f32': [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_float, _vp],
     'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 5 + [_vp],
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
-    'pave_gemm_bf16x3_args_f32': [_vp, _vp],
-    'pave_gemm_bf16x3_ex_planes_f32': [_vp] * 4 + [ctypes.c_longlong, _vp, _vp, _c_int, ctypes.c_longlong]
-                                      + [_c_int] * 3 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
@@ -49,18 +46,8 @@ SIGNATURES = {
 # every symbol include/pave_hip.h declares
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
 
-
-
-class GemmArgs(ctypes.Structure):
-    """`pave_gemm_args` of include/pave_hip.h."""
-    _fields_ = [('a', _vp), ('a_planes', _vp), ('a_bias', _vp), ('w_planes', _vp), ('bias', _vp),
-                ('residual', _vp), ('residual_rows', ctypes.c_longlong), ('out', _vp),
-                ('out_planes', _vp), ('ln_gamma', _vp), ('ln_beta', _vp), ('ln_eps', ctypes.c_float),
-                ('M', ctypes.c_longlong), ('K', _c_int), ('N', _c_int), ('relu', _c_int)]
-
-
 _lib = None
-ABI_VERSION = 10  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 9  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

@@ -687,74 +687,19 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     return out
 
 
-def gemm_bf16x3_planes(w_planes, a=None, a_planes=None, bias=None, residual=None, relu=False,
-                       ln=None, out=None, want_fp32=True, want_planes=False):
-    """3-plane split GEMM with activations handed over as bf16 planes (pave_gemm_bf16x3_args_f32).
-
-    a [M, K] fp32 OR a_planes [3, M, K] int16 (a previous call's planes) -> (out [M, N] fp32 or
-    None, out_planes [3, M, N] int16 or None).  ln = (gamma, beta, eps): LayerNorm over the row in
-    the epilogue (N == 256).  `residual` may be the tensor given as `out`.  Bit-identical to the
-    fp32 hand-over."""
-    import ctypes
-    lib = native.load()
-    _dev(w_planes, 'w_planes', torch.int16)
-    _require(w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[3] == 16,
-             'gemm_bf16x3_planes: w_planes [K/16, 3, N, 16]')
-    K, N = w_planes.shape[0] * 16, w_planes.shape[2]
-    _require((a is None) != (a_planes is None), 'gemm_bf16x3_planes: exactly one of a / a_planes')
-    if a is not None:
-        _dev(a, 'a', torch.float32)
-        _require(a.dim() == 2 and a.shape[1] == K, 'gemm_bf16x3_planes: a [M, K]')
-        M = a.shape[0]
-    else:
-        _dev(a_planes, 'a_planes', torch.int16)
-        _require(a_planes.dim() == 3 and a_planes.shape[0] == 3 and a_planes.shape[2] == K,
-                 'gemm_bf16x3_planes: a_planes [3, M, K]')
-        M = a_planes.shape[1]
-    _require(want_fp32 or want_planes, 'gemm_bf16x3_planes: nothing to write')
-    for t, nm in ((bias, 'bias'),) + (((ln[0], 'gamma'), (ln[1], 'beta')) if ln is not None else ()):
-        if t is not None:
-            _dev(t, nm, torch.float32)
-            _require(t.numel() == N, f'gemm_bf16x3_planes: {nm} has {t.numel()} elements, expected {N}')
-    if residual is not None:
-        _dev(residual, 'residual', torch.float32)
-        _require(tuple(residual.shape) == (M, N), 'gemm_bf16x3_planes: residual [M, N]')
-    o32 = None
-    if want_fp32:
-        o32 = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=w_planes.device)
-        _dev(o32, 'out', torch.float32)
-        _require(tuple(o32.shape) == (M, N), 'gemm_bf16x3_planes: out [M, N]')
-    opl = torch.empty((3, M, N), dtype=torch.int16, device=w_planes.device) if want_planes else None
-    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    args = native.GemmArgs(ptr(a), ptr(a_planes), None, w_planes.data_ptr(), ptr(bias), ptr(residual), 0,
-                           ptr(o32), ptr(opl), ptr(ln[0]) if ln is not None else None,
-                           ptr(ln[1]) if ln is not None else None,
-                           float(ln[2]) if ln is not None else 0.0, M, K, N, int(bool(relu)))
-    with torch.cuda.device(w_planes.device), _Timed('gemm_bf16x3'):
-        st = lib.pave_gemm_bf16x3_args_f32(ctypes.byref(args), _stream_ptr())
-    native.check(st, 'gemm_bf16x3_planes')
-    return o32, opl
-
-
 def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_split=0, relu=False,
                    a_bias=None, fp16=False):
     """gemm_bf16x3 with a row-periodic residual table (`residual` [residual_rows, N], row m adds
     residual[m % residual_rows]) and / or the output cut at column `n_split` into two dense
     matrices -> out [M, n_split], out2 [M, N - n_split] (n_split = 0: one output, out2 = None)."""
     lib = native.load()
-    planes_in = a.dtype == torch.int16      # a = [3, M, K] planes of a previous launch
-    _dev(a, 'a', torch.int16 if planes_in else torch.float32)
+    _dev(a, 'a', torch.float32)
     _dev(w_planes, 'w_planes', torch.int16)
     _require(not fp16 or w_planes.shape[1] == 1, 'gemm_bf16x3_ex: fp16 takes a single plane')
-    if planes_in:
-        _require(a.dim() == 3 and a.shape[0] == 3 and w_planes.shape[1] == 3 and a_bias is None
-                 and w_planes.shape[0] * 16 == a.shape[2], 'gemm_bf16x3_ex: a_planes [3, M, K]')
-        M, K = a.shape[1], a.shape[2]
-    else:
-        _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
-                 and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
-                 'gemm_bf16x3_ex: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
-        M, K = a.shape
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
+             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+             'gemm_bf16x3_ex: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
+    M, K = a.shape
     N = w_planes.shape[2]
     _require(N % 128 == 0, 'gemm_bf16x3_ex: N % 128 == 0')
     for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
@@ -775,16 +720,11 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
-        if planes_in:
-            st = lib.pave_gemm_bf16x3_ex_planes_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias),
-                                                    ptr(residual), rr, out.data_ptr(), ptr(out2),
-                                                    n_split, M, K, N, int(bool(relu)), _stream_ptr())
-        else:
-            st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
-                                             ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
-                                             M, K, N, int(bool(relu)),
-                                             PLANES_FP16 if fp16 else int(w_planes.shape[1]),
-                                             _stream_ptr())
+        st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
+                                         ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
+                                         M, K, N, int(bool(relu)),
+                                         PLANES_FP16 if fp16 else int(w_planes.shape[1]),
+                                         _stream_ptr())
     native.check(st, 'gemm_bf16x3_ex')
     return out, out2
 

@@ -726,51 +726,6 @@ def test_gemm_bf16x3_layernorm_epilogue_vs_fp64(M, K):
                        gam.cuda()[:128], bet.cuda()[:128], 1e-5)     # N != 256
 
 
-@pytest.mark.parametrize('M', [1000, 129, 4100])
-def test_gemm_plane_handover_is_bit_identical_to_fp32_handover(M):
-    """The encoder chain out_proj+LN -> FFN1+ReLU -> FFN2+LN with the activations handed over as
-    bf16 planes (pave_gemm_bf16x3_args_f32 / _ex_planes_f32) gives bit-identical results to the
-    fp32 hand-over: the planes ARE the exact 3-term split the consumer would make itself."""
-    from pavenet_amd.ops import (gemm_bf16x3, gemm_bf16x3_ex, gemm_bf16x3_ln, gemm_bf16x3_planes,
-                                 split_bf16x3, split_weight_bf16x3)
-    g = torch.Generator().manual_seed(M)
-    C, H = 256, 1024
-    attn = torch.randn(M, C, generator=g).cuda()
-    idt = torch.randn(M, C, generator=g).cuda()
-    wo, w1, w2 = [(torch.randn(n, k, generator=g) / k**0.5).cuda() for n, k in ((C, C), (H, C), (C, H))]
-    wm = (torch.randn(640, C, generator=g) / C**0.5).cuda()
-    bo, b1, b2 = [torch.randn(n, generator=g).cuda() for n in (C, H, C)]
-    g1, be1, g2, be2 = [torch.randn(C, generator=g).cuda() for _ in range(4)]
-    table = torch.randn(7, 640, generator=g).cuda()
-    po, p1, p2, pm = [split_weight_bf16x3(w) for w in (wo, w1, w2, wm)]
-    # fp32 hand-over (the path of the earlier tests)
-    x1 = gemm_bf16x3_ln(attn, po, bo, idt, g1, be1, 1e-5)
-    h = gemm_bf16x3(x1, p1, b1, relu=True)
-    x2 = gemm_bf16x3_ln(h, p2, b2, x1, g2, be2, 1e-5)
-    v, pr = gemm_bf16x3_ex(x2, pm, None, table, residual_rows=7, n_split=256)
-    # plane hand-over
-    y1, y1p = gemm_bf16x3_planes(po, a=attn, bias=bo, residual=idt, ln=(g1, be1, 1e-5),
-                                 want_planes=True)
-    assert torch.equal(y1, x1)
-    assert torch.equal(y1p, split_bf16x3(x1, 3).view(3, M, C))        # planes == the exact split
-    none, hp = gemm_bf16x3_planes(p1, a_planes=y1p, bias=b1, relu=True, want_fp32=False,
-                                  want_planes=True)
-    assert none is None and torch.equal(hp, split_bf16x3(h, 3).view(3, M, H))
-    _, hp2 = gemm_bf16x3_planes(p1, a=x1, bias=b1, relu=True, want_fp32=False, want_planes=True)
-    assert torch.equal(hp2, hp)
-    y2, y2p = gemm_bf16x3_planes(p2, a_planes=hp, bias=b2, residual=y1, ln=(g2, be2, 1e-5),
-                                 want_planes=True)
-    assert torch.equal(y2, x2)
-    y2b, none = gemm_bf16x3_planes(p2, a_planes=hp, bias=b2, residual=y1, ln=(g2, be2, 1e-5))
-    assert none is None and torch.equal(y2b, x2)
-    y2c, _ = gemm_bf16x3_planes(p2, a_planes=hp, bias=b2, residual=y1)         # no LayerNorm
-    assert torch.equal(y2c, gemm_bf16x3(h, p2, b2, x1))
-    v2, pr2 = gemm_bf16x3_ex(y2p, pm, None, table, residual_rows=7, n_split=256)
-    assert torch.equal(v2, v) and torch.equal(pr2, pr)
-    with pytest.raises(RuntimeError):
-        gemm_bf16x3_planes(p1, a=x1, a_planes=y1p)                    # both inputs
-
-
 @pytest.mark.parametrize('M,K,N', [(1000, 256, 1024), (300, 1024, 256), (129, 64, 512)])
 def test_gemm_bf16x3_eight_wave_tile_equals_four_wave_tile(M, K, N):
     """The 128 x 256 / 8-wave tile form (tools switch) gives the same numbers as the 128 x 128
