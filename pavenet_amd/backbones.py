@@ -140,8 +140,8 @@ class ResNet(BaseModule):
 
     # -- folded inference path ----------------------------------------------
     def _params_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        from .bricks import SourceKey
+        return SourceKey(list(self.parameters()) + list(self.buffers()))
 
     def _build_folded(self):
         key = self._params_key()

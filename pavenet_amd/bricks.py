@@ -135,6 +135,29 @@ def get_gemm_mode():
     return _GEMM['mode']
 
 
+class SourceKey:
+    """Identity + version of the tensors a derived cache was built from.  Holds the tensors
+    themselves (an address is no identity: the caching allocator hands a freed parameter's address
+    to its replacement with _version 0 again), so `key == SourceKey(srcs)` is true only for the
+    very same, unmodified tensor objects."""
+
+    def __init__(self, tensors, extra=None):
+        self.tensors = tuple(tensors)
+        self.versions = tuple(t._version for t in self.tensors)
+        self.extra = extra
+
+    def __eq__(self, other):
+        return (isinstance(other, SourceKey) and self.extra == other.extra
+                and len(self.tensors) == len(other.tensors)
+                and all(a is b for a, b in zip(self.tensors, other.tensors))
+                and self.versions == other.versions)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
 def _split_slots(weight):
     """Cache dict that LIVES ON the tensor owning the storage (the Parameter, or the folded-BN
     weight kept in ResNet._folded / on the conv module): it dies with that tensor.  An address is

@@ -27,8 +27,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .bricks import (BaseModule, batch_first, constant_init, linear_residual_norm, linear_rows,
-                     seq_first_view, xavier_init)
+from .bricks import (BaseModule, SourceKey, batch_first, constant_init, linear_residual_norm,
+                     linear_rows, seq_first_view, xavier_init)
 from .registry import ATTENTION, MMCV_ATTENTION
 
 
@@ -63,7 +63,7 @@ class _CatProj:
         if frames is not None:
             offs, logits = [offs[t] for t in frames], [logits[t] for t in frames]
         srcs = [m.weight for m in offs + logits] + [m.bias for m in offs + logits]
-        key = (frames,) + tuple((p.data_ptr(), p._version) for p in srcs)
+        key = SourceKey(srcs, frames)
         if getattr(self, '_cat_key', None) != key:
             with torch.no_grad():
                 self._cat_w = torch.cat([m.weight for m in offs + logits], 0).contiguous()
@@ -98,7 +98,7 @@ def project_values_hoisted(attns, value_bf, key_padding_mask=None):
                 and a.value_proj.out_features % 128 == 0 \
                 and split_gemm_ok(rows, a.value_proj.weight):
             srcs = (a.value_proj.weight, a.value_proj.bias, b.value_proj.weight, b.value_proj.bias)
-            key = tuple((p.data_ptr(), p._version) for p in srcs)
+            key = SourceKey(srcs)
             if getattr(a, '_pair_key', None) != key:
                 with torch.no_grad():
                     a._pair_w = torch.cat([a.value_proj.weight, b.value_proj.weight], 0).contiguous()
@@ -179,7 +179,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         sampling-offset bias over the 4 points (the reference initialises that bias on a ray,
         MO:227-240); host ints, re-read only when the bias changes."""
         b = self.sampling_offsets.bias
-        key = (b.data_ptr(), b._version)
+        key = SourceKey((b,))
         if getattr(self, '_tile_shift_key', None) != key:
             self._tile_shift_val = ops.enc_tile_window_shift(b)
             self._tile_shift_key = key
@@ -190,7 +190,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         [384, 256] offsets / logits part alone), rebuilt when a source parameter changes."""
         w_cat, b_cat = self._cat_proj()
         srcs = (self.value_proj.weight, self.value_proj.bias, w_cat, b_cat)
-        key = tuple((p.data_ptr(), p._version) for p in srcs)
+        key = SourceKey(srcs)
         if getattr(self, '_merged_key', None) != key:
             with torch.no_grad():
                 self._merged_w = torch.cat([self.value_proj.weight, w_cat], 0).contiguous()

@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .bricks import (BaseModule, TransformerLayerSequence, batch_first, inverse_sigmoid,
+from .bricks import (BaseModule, SourceKey, TransformerLayerSequence, batch_first, inverse_sigmoid,
                      layer_norm_any_layout, seq_first_view, xavier_init)
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
@@ -76,7 +76,7 @@ def _frame_branches(branches, lid, x, cat_dim):
         return torch.cat([m(x) for m in mods], dim=cat_dim)
     lins = [[m[i] for m in mods] for i in range(0, len(m0), 2)]      # [layer][frame]
     srcs = [p for layer in lins for l in layer for p in (l.weight, l.bias)]
-    key = tuple((p.data_ptr(), p._version) for p in srcs)
+    key = SourceKey(srcs)
     cache = m0.__dict__.get('_pave_stacked')
     if cache is None or cache[0] != key:
         with torch.no_grad():
