@@ -347,9 +347,6 @@ class VideoPoseTransformerMulFrames(Transformer):
         self.init_layers()
         self._geom = {}
         self.hoist_value_proj = True
-        # decoder value projections on a side stream, under the launch-bound stages (see
-        # _start_value_projections); False = in line, right before each decoder
-        self.overlap_value_proj = True
         self.xcd_unit_order = True
         # encoder sampling through the LDS-tile kernel (pave_enc_tile.hip); False = head-major
         # direct-gather kernel (also the path for pyramids the tile kernel does not cover)
@@ -526,7 +523,6 @@ class VideoPoseTransformerMulFrames(Transformer):
         attn_mask = mask_flatten if has_padding else None
         if attn_mask is not None and attn_mask.shape[0] != bs:
             attn_mask = attn_mask.expand(bs, -1)
-        early = self._start_value_projections(memory, attn_mask)
         c = memory.shape[-1]
         n_clips = bs // Tl
         if frame_shard is None:
@@ -584,10 +580,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_kpt_branches'] = branches
         if frame_shard is not None:
             dec_kwargs['frame_shard'] = frame_shard
-        if early is not None:
-            torch.cuda.current_stream().wait_event(early['ev_pose'])   # projected on the side stream
-            dec_kwargs['values_projected'] = early['pose']
-        elif self.hoist_value_proj and all(
+        if self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
                 for l in self.decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(
@@ -603,42 +596,6 @@ class VideoPoseTransformerMulFrames(Transformer):
             return inter_states, init_reference_out, inter_references, enc_outputs_class, \
                 enc_outputs_kpt_unact, enc_outputs_sigma_unact, None, memory_out
         return inter_states, init_reference_out, inter_references, None, None, None, None, None, None
-
-    def _start_value_projections(self, memory, attn_mask):
-        """The decoders' `value_proj` GEMMs depend only on the encoder memory, while the stages
-        that run before each decoder (two-stage proposals, top-k, self-attention, branch MLPs) are
-        hundreds of tiny launches that leave the chip mostly idle.  On the device, un-padded
-        batches: project the values of ALL decoder layers (pose + joint) on a side stream right
-        after the encoder, so the large GEMMs run under those launch-bound stages; each decoder
-        waits on its event.  -> {'pose': [...], 'ev_pose': event} (+ the joint part stashed for
-        `forward_refine` of the same step), or None."""
-        self.__dict__.pop('_early_joint', None)
-        if not (self.overlap_value_proj and self.hoist_value_proj and memory.is_cuda
-                and attn_mask is None and not torch.is_grad_enabled() and memory.is_contiguous()):
-            return None
-        pose = [l.attentions[-1] for l in self.decoder.layers]
-        joint = [l.attentions[-1] for l in self.refine_decoder.layers]
-        if not (all(isinstance(a, MulFramesMultiScaleDeformablePoseAttention) for a in pose)
-                and all(isinstance(a, MulFramesMultiScaleDeformableAttention) for a in joint)):
-            return None
-        main = torch.cuda.current_stream()
-        side = self.__dict__.get('_side_stream')
-        if side is None or side.device != memory.device:
-            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=memory.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            vp = project_values_hoisted(pose, memory, None)
-            ev_pose = torch.cuda.Event()
-            ev_pose.record(side)
-            vj = project_values_hoisted(joint, memory.unsqueeze(0), None)   # [1, B*T, S, C] form
-            ev_joint = torch.cuda.Event()
-            ev_joint.record(side)
-        for v in vp + vj:
-            v.record_stream(main)        # consumed on the main stream
-        self.__dict__['_early_joint'] = dict(values=vj, ev=ev_joint,
-                                             storage=memory.untyped_storage().data_ptr(),
-                                             rows=memory.shape[0] * memory.shape[1])
-        return dict(pose=vp, ev_pose=ev_pose)
 
     # -- a9: forward_refine (OT:21458-21536) ---------------------------------
     def forward_refine(self, mlvl_masks, memory, reference_points_pose, img_inds,
@@ -676,14 +633,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_shard'] = frame_shard
         mem_bt = memory.permute(1, 2, 0, 3)                                   # [B, T, S, C]
         attn_mask = mask_bt if has_padding else None
-        early = self.__dict__.pop('_early_joint', None)
-        if early is not None and attn_mask is None and mem_bt.is_contiguous() and \
-                early['storage'] == mem_bt.untyped_storage().data_ptr() and \
-                early['rows'] == mem_bt.shape[0] * mem_bt.shape[1] * mem_bt.shape[2]:
-            # projected under the pose decoder, on the side stream, by `forward` of this step
-            torch.cuda.current_stream().wait_event(early['ev'])
-            dec_kwargs['values_projected'] = early['values']
-        elif self.hoist_value_proj and all(
+        if self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformableAttention)
                 for l in self.refine_decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(
