@@ -316,6 +316,9 @@ class _LevelGeometry:
         self.level_start_index = torch.as_tensor(starts, dtype=torch.long, device=device)
         self.S = sum(h * w for h, w in self.hw)
         self._order = {}
+        # un-padded batches: tensors that depend only on the level sizes and the batch size
+        # (valid ratios = 1, encoder reference grid, two-stage proposal grid), built once
+        self.unpadded = {}
 
     def unit_order(self, n_frames, device):
         if n_frames not in self._order:
@@ -384,6 +387,14 @@ class VideoPoseTransformerMulFrames(Transformer):
     def gen_encoder_output_proposals(self, memory, memory_padding_mask, geom):
         N, S, C = memory.shape
         dev = memory.device
+        cached = None
+        if memory_padding_mask is None and memory.is_cuda and not torch.is_grad_enabled():
+            cached = geom.unpadded.get(('proposals', N))
+            if cached is not None:   # the grid depends on the level sizes only
+                output_proposals, valid = cached
+                output_memory = memory.masked_fill(~valid, float(0))
+                output_memory = self.enc_output_norm(self.enc_output(output_memory))
+                return output_memory, output_proposals
         proposals = []
         _cur = 0
         for lvl, (H, W) in enumerate(geom.hw):
@@ -409,6 +420,8 @@ class VideoPoseTransformerMulFrames(Transformer):
             output_proposals = output_proposals.masked_fill(
                 memory_padding_mask.unsqueeze(-1), float('inf'))
         output_proposals = output_proposals.masked_fill(~valid, float('inf'))
+        if memory_padding_mask is None and memory.is_cuda and not torch.is_grad_enabled():
+            geom.unpadded[('proposals', N)] = (output_proposals, valid)
         output_memory = memory
         if memory_padding_mask is not None:
             output_memory = output_memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
@@ -478,10 +491,17 @@ class VideoPoseTransformerMulFrames(Transformer):
         if lvl_pos_embed_flatten.shape[0] != feat_flatten.shape[0]:    # shared across frames
             lvl_pos_embed_flatten = lvl_pos_embed_flatten.expand(feat_flatten.shape[0], -1, -1)
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
-        if valid_ratios.shape[0] != feat_flatten.shape[0]:
-            valid_ratios = valid_ratios.expand(feat_flatten.shape[0], -1, -1)
-        reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
+        nfr = feat_flatten.shape[0]
+        const = geom.unpadded.get(('refs', nfr)) if (not has_padding and feat_flatten.is_cuda) else None
+        if const is not None:       # no padding: valid ratios are exactly 1, the grid is constant
+            valid_ratios, reference_points = const
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+            if valid_ratios.shape[0] != nfr:
+                valid_ratios = valid_ratios.expand(nfr, -1, -1)
+            reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
+            if not has_padding and feat_flatten.is_cuda and not torch.is_grad_enabled():
+                geom.unpadded[('refs', nfr)] = (valid_ratios.contiguous(), reference_points)
         attn_mask = mask_flatten if has_padding else None
         if attn_mask is not None and attn_mask.shape[0] != feat_flatten.shape[0]:
             attn_mask = attn_mask.expand(feat_flatten.shape[0], -1)
