@@ -628,9 +628,16 @@ class VideoPoseTransformerMulFrames(Transformer):
         branches = self._frame_branch_lists(kwargs, 'kpt_branches')
         dev = memory.device
         geom = self.geometry([m.shape[-2:] for m in mlvl_masks], dev)
-        mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+        const = geom.unpadded.get(('refine', mlvl_masks[0].shape[0])) \
+            if (not has_padding and memory.is_cuda) else None
+        if const is not None:            # no padding: all-False masks, valid ratios exactly 1
+            mask_flatten, valid_ratios = const
+        else:
+            mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+            if not has_padding and memory.is_cuda and not torch.is_grad_enabled():
+                geom.unpadded[('refine', mlvl_masks[0].shape[0])] = (mask_flatten, valid_ratios)
         B = memory.shape[1]
         if valid_ratios.shape[0] != B * Tl:
             valid_ratios = valid_ratios.expand(B * Tl, -1, -1)
