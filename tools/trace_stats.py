@@ -33,6 +33,11 @@ def main():
     print(f'# {"ms/step":>9} {"%":>6} {"calls/step":>10} {"avg us":>10}  kernel')
     for name, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
         print(f'{t / nsteps / 1e6:10.3f} {100 * t / busy:6.2f} {n / nsteps:10.1f} {t / n / 1e3:10.1f}  {name[:110]}')
+    small = [(name, t, n) for name, (t, n) in agg.items() if t / n < 40e3]
+    print(f'# launches shorter than 40 us: {sum(n for _, _, n in small) / nsteps:.0f} per step, '
+          f'{sum(t for _, t, _ in small) / nsteps / 1e6:.2f} ms per step; by count:')
+    for name, t, n in sorted(small, key=lambda x: -x[2])[:40]:
+        print(f'{n / nsteps:10.1f} calls {t / n / 1e3:8.1f} us  {name[:130]}')
 
 
 if __name__ == '__main__':
