@@ -1,6 +1,6 @@
 """Whole-video inference with the per-frame encoder-memory cache at full size:
 every frame of an N-frame 800x1344 video gets its T-frame window result; frames/s against
-running simple_test on every window.   python tools/bench_streaming.py [n_frames=28] [T=7]"""
+running simple_test on every window.   python tools/bench_streaming.py [n_frames=28] [T=7] [gemm=bf16x3]"""
 import os
 import sys
 import time
@@ -8,6 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pavenet_amd.bricks import set_gemm_mode  # noqa: E402
 from pavenet_amd.models import build_model, videopose_r50_cfg  # noqa: E402
 from pavenet_amd.streaming import VideoPoseStream  # noqa: E402
 from pavenet_amd.weights import init_random_weights  # noqa: E402
@@ -16,6 +17,8 @@ from pavenet_amd.weights import init_random_weights  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    gemm = sys.argv[3] if len(sys.argv) > 3 else 'bf16x3'
+    set_gemm_mode(gemm)
     torch.backends.cudnn.benchmark = True
     m = init_random_weights(build_model(videopose_r50_cfg(num_frames=T, max_per_img=20)), seed=0)
     m = m.cuda().eval()
@@ -31,7 +34,7 @@ def main():
         out = stream.infer_video(video)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / reps
-    print(f'streaming: {n} frames (= {n} T={T} windows) in {dt * 1e3:.1f} ms -> {n / dt:.1f} windows/s')
+    print(f'[--gemm {gemm}] streaming: {n} frames (= {n} T={T} windows) in {dt * 1e3:.1f} ms -> {n / dt:.1f} windows/s')
     wins = stream.window_indices(n, T)
     clips = torch.stack([video[w] for w in wins[:4]], 0)
     for _ in range(2):
