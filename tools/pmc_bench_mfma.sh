@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$OUT
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_]*MFMA[A-Z_0-9]*" | sort -u > $R/gpurun_out/$OUT/mfma_counters_available.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv \
-  -d $R/gpurun_out/$OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/$OUT/p1.log 2>&1
+  -d $R/gpurun_out/$OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side "$@" > $R/gpurun_out/$OUT/p1.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 rows = []
@@ -29,7 +29,9 @@ def cls(k):
     if 'conv_nhwc_kernel' in k:
         return 'pave conv_nhwc_kernel (Bottleneck tail, fp32 MFMA)'
     if 'gemm_bf16x3' in k:
-        return 'pave gemm_bf16x3_kernel'
+        return 'pave gemm_bf16x3_kernel (split GEMM / convolutions, bf16 MFMA x 6)'
+    if 'enc_tile_kernel' in k:
+        return 'pave enc_tile_kernel (encoder sampling, no MFMA)'
     if 'grouped_conv_fwd' in k or k.startswith('igemm_fwd'):
         return 'MIOpen / CK fp32 convolution'
     if 'fused_deform_attn' in k:
