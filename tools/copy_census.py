@@ -28,11 +28,13 @@ with torch.no_grad():
 want = ('aten::copy_', 'aten::add', 'aten::add_', 'aten::clamp_min', 'aten::relu', 'aten::clamp_min_',
         'aten::cat', 'aten::mul', 'aten::sigmoid', 'aten::contiguous', 'aten::clone')
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in want and ev.stack:
-        src = next((f for f in ev.stack if 'pavenet_amd' in f or 'torch/nn/modules/activation' in f
-                    or 'torch/nn/functional' in f), None)
-        if src is not None:
-            cnt[(ev.name, src.split('pavenet_amd/')[-1][:90])] += 1
+for ka in prof.key_averages(group_by_stack_n=12):
+    if ka.key in want:
+        src = next((f for f in ka.stack if 'pavenet_amd' in f), None)
+        if src is None:
+            src = next((f for f in ka.stack if 'torch/nn/' in f), '?')
+        cnt[(ka.key, src.strip().split('pavenet_amd/')[-1][:100])] += ka.count
+if not cnt:
+    print('no stacks recorded; totals:', {ka.key: ka.count for ka in prof.key_averages() if ka.key in want})
 for (name, src), n in cnt.most_common(45):
     print(f'{n:4d}  {name:18s} {src}')
