@@ -8,7 +8,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pavenet_amd  # noqa: E402,F401
 import torch  # noqa: E402
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
 from pavenet_amd.bricks import set_gemm_mode  # noqa: E402
 from pavenet_amd.models import build_model, videopose_r50_cfg  # noqa: E402
 from pavenet_amd.weights import init_random_weights  # noqa: E402
@@ -18,23 +17,32 @@ m = init_random_weights(build_model(videopose_r50_cfg(num_frames=T, max_per_img=
 set_gemm_mode('bf16x3')
 img = torch.randn(B, T, 3, 800, 1344, device='cuda')
 metas = [dict(batch_input_shape=(800, 1344), img_shape=(800, 1344, 3), scale_factor=(1., 1., 1., 1.))] * B
+import traceback  # noqa: E402
+
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+WANT = ('copy_', 'clone', 'add', 'add_', 'relu', 'clamp_min', 'clamp_min_', 'cat', 'mul', 'sigmoid',
+        '_to_copy', 'index', 'gather', 'expand_copy', 'repeat', 'stack')
+cnt = collections.Counter()
+
+
+class Census(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split('.')[0]
+        if name in WANT:
+            fr = [f for f in traceback.extract_stack() if 'pavenet_amd/' in f.filename]
+            if fr:
+                f = fr[-1]
+                cnt[(name, f'{os.path.basename(f.filename)}:{f.lineno} {f.line[:70]}')] += 1
+        return func(*args, **(kwargs or {}))
+
+
 with torch.no_grad():
     for _ in range(3):
         m.forward_device(img, metas)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    with Census():
         m.forward_device(img, metas)
-        torch.cuda.synchronize()
-want = ('aten::copy_', 'aten::add', 'aten::add_', 'aten::clamp_min', 'aten::relu', 'aten::clamp_min_',
-        'aten::cat', 'aten::mul', 'aten::sigmoid', 'aten::contiguous', 'aten::clone')
-cnt = collections.Counter()
-for ka in prof.key_averages(group_by_stack_n=12):
-    if ka.key in want:
-        src = next((f for f in ka.stack if 'pavenet_amd' in f), None)
-        if src is None:
-            src = next((f for f in ka.stack if 'torch/nn/' in f), '?')
-        cnt[(ka.key, src.strip().split('pavenet_amd/')[-1][:100])] += ka.count
-if not cnt:
-    print('no stacks recorded; totals:', {ka.key: ka.count for ka in prof.key_averages() if ka.key in want})
-for (name, src), n in cnt.most_common(45):
-    print(f'{n:4d}  {name:18s} {src}')
+    torch.cuda.synchronize()
+for (name, src), n in cnt.most_common(60):
+    print(f'{n:4d}  {name:12s} {src}')
