@@ -21,7 +21,7 @@ from . import ops
 from .bricks import (BaseModule, Linear, bias_init_with_prob, build_activation_layer,
                      constant_init)
 from .deform_attn import frame_prefixes
-from .transformer import _ref_update
+from .transformer import _frame_branches, _ref_update
 from .registry import HEADS, LOSSES, MMDET_MODELS, build_positional_encoding, build_transformer
 
 OKS_SIGMAS_POSETRACK15 = [.26, .79, .79, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87,
@@ -140,6 +140,9 @@ class VideoPoseHeadMulFrames(BaseModule):
         self.num_keypoints = num_keypoints
         self.num_frames = num_frames
         self.frame_prefixes = frame_prefixes(num_frames)
+        # eval: run the class / key-point / sigma branches on the last decoder level only (the
+        # earlier levels feed training losses); False = the reference's full [levels, ...] stacks
+        self.eval_last_level_only = True
         if not self.as_two_stage:
             raise RuntimeError('only "as_two_stage=True" is supported.')
         transformer = copy.deepcopy(dict(transformer))
@@ -257,24 +260,25 @@ class VideoPoseHeadMulFrames(BaseModule):
         hs = hs.permute(0, 2, 1, 3)
         outputs_classes, outputs_kpts, output_sigmas = [], [], []
         aux_poses = None
-        for lvl in range(hs.shape[0]):
+        n_lvl = hs.shape[0]
+        # The class / key-point / sigma branches of the earlier decoder levels only feed training
+        # losses (HEAD:1304-1330 reads [-1]); in eval mode they are skipped unless asked for.
+        levels = range(n_lvl) if (self.training or not self.eval_last_level_only) else [n_lvl - 1]
+        for lvl in levels:
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
-            last = lvl == hs.shape[0] - 1
-            if last:
-                aux_poses = []
-                for t, fp in enumerate(self.frame_prefixes):
-                    if t == c:
-                        aux_poses.append(None)
-                        continue
-                    br = fp
-                    if T == 5 and t == 4:
-                        br = 'next_'  # HEAD:503: next_next pose decoded with next_kpt_branches
-                    aux_poses.append(_ref_update(getattr(self, br + 'kpt_branches')[lvl](hs[lvl]),
-                                                 reference[:, t * Q:(t + 1) * Q]))
+            if lvl == n_lvl - 1:
+                # all T frames' key-point branches on hs[lvl] at once (one GEMM + batched GEMMs,
+                # transformer._frame_branches), then ONE reference update over [B, T*Q, 2K]
+                brs = [getattr(self, ('next_' if (T == 5 and t == 4) else fp) + 'kpt_branches')
+                       for t, fp in enumerate(self.frame_prefixes)]   # HEAD:503 quirk kept
+                poses = _ref_update(_frame_branches(brs, lvl, hs[lvl], 1), reference)
+                aux_poses = [None if t == c else poses[:, t * Q:(t + 1) * Q] for t in range(T)]
+                outputs_kpt = poses[:, c * Q:(c + 1) * Q]
+            else:
+                # (tmp + inverse_sigmoid(reference)).sigmoid(): one launch on the device
+                outputs_kpt = _ref_update(self.kpt_branches[lvl](hs[lvl]),
+                                          reference[:, c * Q:(c + 1) * Q])
             outputs_class = self.cls_branches[lvl](hs[lvl])
-            # (tmp + inverse_sigmoid(reference)).sigmoid(): one launch on the device
-            outputs_kpt = _ref_update(self.kpt_branches[lvl](hs[lvl]),
-                                      reference[:, c * Q:(c + 1) * Q])
             output_sigma = self.dec_fc_sigma_branches[lvl](hs[lvl]).sigmoid()
             outputs_classes.append(outputs_class)
             outputs_kpts.append(outputs_kpt)
