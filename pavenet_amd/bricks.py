@@ -440,8 +440,56 @@ class MultiheadAttention(BaseModule):
         self.proj_drop = nn.Identity()
         self.dropout_layer = nn.Identity()
 
+    supports_post_norm = True
+
+    def _self_attention_fast(self, x, pos, identity, post_norm):
+        """Self-attention of the decoders on the device (query = key = x + pos, value = x, no
+        masks), seq-first [L, N, E]: one add, the q|k and v projections as two GEMMs, fused SDPA,
+        out_proj with the identity riding the GEMM, bias + LayerNorm as one pass -- 7 launches
+        instead of ~16 through nn.MultiheadAttention.  Same arithmetic per element."""
+        from . import ops
+        a = self.attn
+        L, N, E = x.shape
+        H, d = self.num_heads, E // self.num_heads
+        w, b = a.in_proj_weight, a.in_proj_bias
+        qk = F.linear(x + pos if pos is not None else x, w[:2 * E], b[:2 * E])      # [L, N, 2E]
+        v = F.linear(x, w[2 * E:], b[2 * E:])
+        q = qk[..., :E].reshape(L, N, H, d).permute(1, 2, 0, 3)                      # [N, H, L, d]
+        k = qk[..., E:].reshape(L, N, H, d).permute(1, 2, 0, 3)
+        v = v.reshape(L, N, H, d).permute(1, 2, 0, 3)
+        o = F.scaled_dot_product_attention(q, k, v)                                  # [N, H, L, d]
+        o = o.permute(2, 0, 1, 3).reshape(L * N, E)
+        idt = identity.reshape(L * N, E) if identity.is_contiguous() else \
+            identity.contiguous().view(L * N, E)
+        t = torch.addmm(idt, o, a.out_proj.weight.t())                               # + identity
+        if post_norm is not None:
+            t = ops.bias_add_layernorm(t, a.out_proj.bias, None, post_norm.weight, post_norm.bias,
+                                       post_norm.eps)
+        else:
+            t = t + a.out_proj.bias
+        return t.view(L, N, E)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
-                attn_mask=None, key_padding_mask=None, **kwargs):
+                attn_mask=None, key_padding_mask=None, post_norm=None, **kwargs):
+        a = self.attn
+        if (query.is_cuda and query.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not self.batch_first and query.dim() == 3 and attn_mask is None
+                and key_padding_mask is None and (key is None or key is query)
+                and (value is None or value is query)
+                and (key_pos is None or key_pos is query_pos)
+                and (query_pos is None or query_pos.shape == query.shape)
+                and a._qkv_same_embed_dim and a.in_proj_bias is not None
+                and a.bias_k is None and not a.add_zero_attn
+                and (post_norm is None or (isinstance(post_norm, nn.LayerNorm)
+                                           and post_norm.elementwise_affine))):
+            return self._self_attention_fast(query, query_pos,
+                                             query if identity is None else identity, post_norm)
+        out = self._forward_reference(query, key, value, identity, query_pos, key_pos, attn_mask,
+                                      key_padding_mask)
+        return layer_norm_any_layout(post_norm, out) if post_norm is not None else out
+
+    def _forward_reference(self, query, key=None, value=None, identity=None, query_pos=None,
+                           key_pos=None, attn_mask=None, key_padding_mask=None):
         if key is None:
             key = query
         if value is None:
