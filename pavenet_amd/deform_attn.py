@@ -207,9 +207,16 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         bs, S, C = q.shape
         w_all, w_cat, b_cat = self._merged_proj()
         nv = self.value_proj.out_features
-        table = torch.empty((S, w_all.shape[0]), dtype=torch.float32, device=q.device)
-        table[:, :nv] = self.value_proj.bias
-        torch.addmm(b_cat, pos_row, w_cat.t(), out=table[:, nv:])
+        # the per-token epilogue table depends on the positional table and this layer's weights only
+        src = pos_row._base if pos_row._base is not None else pos_row
+        tkey = SourceKey([src, self.value_proj.bias, w_cat, b_cat], (tuple(pos_row.shape), S))
+        if getattr(self, '_table_key', None) == tkey:
+            table = self._table
+        else:
+            table = torch.empty((S, w_all.shape[0]), dtype=torch.float32, device=q.device)
+            table[:, :nv] = self.value_proj.bias
+            torch.addmm(b_cat, pos_row, w_cat.t(), out=table[:, nv:])
+            self._table_key, self._table = tkey, table
         v, proj = ops.gemm_bf16x3_ex(q.reshape(bs * S, C), _split_weight(w_all), None, table,
                                      residual_rows=S, n_split=nv,
                                      fp16=get_gemm_mode() == 'fp16')

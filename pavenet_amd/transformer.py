@@ -478,16 +478,26 @@ class VideoPoseTransformerMulFrames(Transformer):
         -> (memory [n_frames, S, C], mask_flatten, valid_ratios [n_frames, L, 2], geometry)."""
         dev = mlvl_feats[0].device
         geom = self.geometry([f.shape[-2:] for f in mlvl_feats], dev)
-        feat_flatten, mask_flatten, lvl_pos_embed_flatten = [], [], []
-        for lvl, (feat, mask, pos_embed) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
-            feat_flatten.append(feat.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
-            pos_embed = pos_embed.flatten(2).transpose(1, 2)
-            lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
+        feat_flatten = [feat.flatten(2).transpose(1, 2) for feat in mlvl_feats]
         flat = self._flat_view(mlvl_feats) if feat_flatten[0].is_cuda else None
         feat_flatten = flat if flat is not None else torch.cat(feat_flatten, 1)  # [n, S, C]
-        mask_flatten = torch.cat(mask_flatten, 1)
-        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        # flattened masks and `pos + level_embed`: functions of the (cached) mask / sine tensors and
+        # one parameter -- rebuilt only when one of those objects changes
+        key = SourceKey(list(mlvl_masks) + list(mlvl_pos_embeds) + [self.level_embeds])
+        const = geom.unpadded.get('flat_pos') if (feat_flatten.is_cuda
+                                                   and not torch.is_grad_enabled()) else None
+        if const is not None and const[0] == key:
+            mask_flatten, lvl_pos_embed_flatten = const[1], const[2]
+        else:
+            mask_flatten, lvl_pos_embed_flatten = [], []
+            for lvl, (mask, pos_embed) in enumerate(zip(mlvl_masks, mlvl_pos_embeds)):
+                mask_flatten.append(mask.flatten(1))
+                pos_embed = pos_embed.flatten(2).transpose(1, 2)
+                lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
+            mask_flatten = torch.cat(mask_flatten, 1)
+            lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+            if feat_flatten.is_cuda and not torch.is_grad_enabled():
+                geom.unpadded['flat_pos'] = (key, mask_flatten, lvl_pos_embed_flatten)
         if lvl_pos_embed_flatten.shape[0] != feat_flatten.shape[0]:    # shared across frames
             lvl_pos_embed_flatten = lvl_pos_embed_flatten.expand(feat_flatten.shape[0], -1, -1)
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
