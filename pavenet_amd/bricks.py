@@ -452,22 +452,22 @@ class MultiheadAttention(BaseModule):
         L, N, E = x.shape
         H, d = self.num_heads, E // self.num_heads
         w, b = a.in_proj_weight, a.in_proj_bias
-        qk = F.linear(x + pos if pos is not None else x, w[:2 * E], b[:2 * E])      # [L, N, 2E]
-        v = F.linear(x, w[2 * E:], b[2 * E:])
-        q = qk[..., :E].reshape(L, N, H, d).permute(1, 2, 0, 3)                      # [N, H, L, d]
-        k = qk[..., E:].reshape(L, N, H, d).permute(1, 2, 0, 3)
-        v = v.reshape(L, N, H, d).permute(1, 2, 0, 3)
-        o = F.scaled_dot_product_attention(q, k, v)                                  # [N, H, L, d]
-        o = o.permute(2, 0, 1, 3).reshape(L * N, E)
-        idt = identity.reshape(L * N, E) if identity.is_contiguous() else \
-            identity.contiguous().view(L * N, E)
-        t = torch.addmm(idt, o, a.out_proj.weight.t())                               # + identity
+        # token-major rows of the batch-first storage the seq-first tensors are views of: the
+        # projections, the residual GEMM and the LayerNorm then run without layout copies
+        xb = batch_first(x).reshape(N * L, E)
+        qk_in = xb + batch_first(pos).reshape(N * L, E) if pos is not None else xb
+        qk = F.linear(qk_in, w[:2 * E], b[:2 * E]).view(N, L, 2, H, d)
+        v = F.linear(xb, w[2 * E:], b[2 * E:]).view(N, L, H, d)
+        o = F.scaled_dot_product_attention(qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2),
+                                           v.transpose(1, 2))                        # [N, H, L, d]
+        o = o.transpose(1, 2).reshape(N * L, E)
+        t = torch.addmm(batch_first(identity).reshape(N * L, E), o, a.out_proj.weight.t())
         if post_norm is not None:
             t = ops.bias_add_layernorm(t, a.out_proj.bias, None, post_norm.weight, post_norm.bias,
                                        post_norm.eps)
         else:
             t = t + a.out_proj.bias
-        return t.view(L, N, E)
+        return seq_first_view(t.view(N, L, E))
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
                 attn_mask=None, key_padding_mask=None, post_norm=None, **kwargs):
