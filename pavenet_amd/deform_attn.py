@@ -24,7 +24,6 @@ import warnings
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .bricks import (BaseModule, SourceKey, batch_first, constant_init, linear_residual_norm,

@@ -11,8 +11,6 @@ and each window only runs the decoders on T cached slabs: ~T x fewer backbone / 
 """
 import torch
 
-from .bricks import seq_first_view
-
 
 class VideoPoseStream:
     """``VideoPoseStream(model, img_meta).infer_video(frames)`` -> one result per frame, equal

@@ -13,14 +13,13 @@ contiguous under sequence-first views; constant-per-shape tensors (reference gri
 start indices, XCD unit order) are cached; the clip memory is never replicated per pose; the
 value projections of all decoder layers are hoisted out of the layer loop when asked.
 """
-import math
 import os
 
 import torch
 import torch.nn as nn
 
 from .bricks import (BaseModule, SourceKey, TransformerLayerSequence, batch_first, inverse_sigmoid,
-                     layer_norm_any_layout, seq_first_view, xavier_init)
+                     seq_first_view, xavier_init)
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
                           MultiScaleDeformableAttention, frame_prefixes,
