@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_within_half_pixel',
              'test_frame_sharded_two_ranks', 'test_t15_frame_sharded_vs_oracle',
              'test_bench_multi_rank_code_path_on_one_gpu', 'test_split_caches_follow_reloaded_weights',
+             'test_derived_operand_caches_follow_reloaded_weights',
              'test_oks_nms_kernel_vs_oracle', 'test_oks_nms_kernel_survives_nan_and_inf',
              'test_deterministic_mode_is_bit_reproducible_and_matches_default',
              'test_hipgraph_replay_equals_eager')
@@ -709,6 +710,47 @@ def test_split_caches_follow_reloaded_weights():
                 bricks._GEMM['min_rows'] = old_rows
             for a, b in zip(got, ref):
                 np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    finally:
+        bricks.set_gemm_mode('native')
+        bricks._GEMM['min_rows'] = old_rows
+
+
+def test_derived_operand_caches_follow_reloaded_weights():
+    """Everything derived from parameters and cached across steps -- merged / paired / stacked
+    projection weights, the merged projection's per-token epilogue table, `pos + level_embed`, the
+    tile kernel's window shift -- must follow a weight reload: the whole forward of an UN-padded
+    clip (the path that uses them) in the split mode equals the vendor-kernel forward, reload after
+    reload, with the proposal / score selections pinned to the latter's."""
+    from pavenet_amd import bricks
+    m = _build(3, 12)
+    head, tr = m.bbox_head, m.bbox_head.transformer
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(128, 160, 3),
+                  scale_factor=(1., 1., 1., 1.))] * 2
+    img = _t(seeded_array('cache2.img', (2, 3, 3, 128, 160))).cuda()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    old_rows = bricks._GEMM['min_rows']
+
+    def run(force_topk=None, force_score=None):
+        kw = {} if force_topk is None else dict(force_topk_proposals=force_topk)
+        outs = head(m.extract_feat(img), metas, **kw)
+        taps = {}
+        res = head.get_bboxes(outs, metas, force_score_topk=force_score, taps=taps)
+        return res, tr.last_topk_proposals.clone(), taps['score_topk'].clone()
+
+    try:
+        for salt in (0, 1, 2):
+            m.load_state_dict(seeded_state_dict(shapes, salt, like=m.state_dict()), strict=True)
+            with torch.no_grad():
+                bricks.set_gemm_mode('native')
+                ref, topk, sel = run()
+                bricks.set_gemm_mode('bf16x3')
+                bricks._GEMM['min_rows'] = 1
+                got, _, _ = run(topk, sel)
+                bricks._GEMM['min_rows'] = old_rows
+            enc0 = tr.encoder.layers[0].attentions[0]
+            assert hasattr(enc0, '_merged_w') and hasattr(enc0, '_table')      # the cached path ran
+            np.testing.assert_allclose(got['kpts'].cpu().numpy(), ref['kpts'].cpu().numpy(),
+                                       rtol=0, atol=2e-2)
     finally:
         bricks.set_gemm_mode('native')
         bricks._GEMM['min_rows'] = old_rows
