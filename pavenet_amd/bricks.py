@@ -104,8 +104,8 @@ def _fusable(*tensors):
     return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
-# Dense projections (nn.Linear on [M, K] rows).  'native' (the library default): hipBLASLt fp32
-# (v_mfma_f32_*_f32, 157 TFLOP/s peak).  'bf16x3' (bench.py's default, the headline mode): the
+# Dense projections (nn.Linear on [M, K] rows).  'native': hipBLASLt fp32 (v_mfma_f32_*_f32,
+# 157 TFLOP/s peak).  'bf16x3' (the default of the library and of bench.py, the headline mode): the
 # hand-written split GEMM (pave_gemm_bf16x3_f32): both operands split EXACTLY into three bf16 terms,
 # six bf16 MFMAs per product tile, fp32 accumulate -- fp32-level accuracy
 # (tests/test_ops_gpu.py::test_gemm_bf16x3_accuracy_vs_fp64) at 1.25-1.7x hipBLASLt's fp32 rate on
@@ -116,7 +116,7 @@ def _fusable(*tensors):
 # it saves) and superseded by folding the positional term into the merged projection GEMM
 # (deform_attn._forward_merged), so it is off unless PAVE_POS_FUSION=1.
 FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
-_GEMM = {'mode': 'native', 'min_rows': 8192, 'ln_fused': True}
+_GEMM = {'mode': 'bf16x3', 'min_rows': 8192, 'ln_fused': True}
 
 
 _PLANES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'fp16': 16}   # 16 = ops.PLANES_FP16

@@ -33,7 +33,9 @@ def gemm_mode(request):
     if request.node.originalname in _OWN_MODE:
         if mode != 'native':
             pytest.skip('sets its own GEMM mode')
+        bricks.set_gemm_mode('native')     # these tests start from the vendor-kernel mode
         yield mode
+        bricks.set_gemm_mode('native')
         return
     old_rows = bricks._GEMM['min_rows']
     bricks.set_gemm_mode(mode)
