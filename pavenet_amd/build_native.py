@@ -1,7 +1,13 @@
-"""Builds pavenet_amd/lib/libpave_hip.so in-tree with hipcc for gfx950 (cross-compiles
-without a GPU).  The .so is git-ignored but travels to the GPU box with the snapshot."""
+"""Builds the native pieces in-tree (cross-compiles without a GPU); the .so files are git-ignored
+but travel to the GPU box with the snapshot:
+
+* ``pavenet_amd/lib/libpave_hip.so`` -- the C-ABI library (hipcc, gfx950);
+* ``pavenet_amd/_ext.*.so`` -- the pybind module with mmcv._ext's ``ms_deform_attn_forward /
+  _backward`` signatures on top of that C ABI (g++ against the installed torch headers).
+"""
 import os
 import subprocess
+import sysconfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
@@ -10,21 +16,58 @@ SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
            os.path.join(_HERE, 'csrc', 'pave_enc_tile.hip')]
 HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
+EXT_SOURCE = os.path.join(_HERE, 'csrc', 'pave_mmcv_ext.cpp')
+EXT_OUT = os.path.join(_HERE, '_ext' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+
+
+def _fresh(out, deps):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in deps)
 
 
 def build_native(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(
-            os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SOURCES + HEADERS):
+    if not force and _fresh(OUT, SOURCES + HEADERS):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
-           '-I' + os.path.join(ROOT, 'include'), '-o', OUT] + SOURCES
-    if verbose:
-        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-    subprocess.check_call(cmd)
+    # one hipcc process per translation unit, in parallel (the three files are independent)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(_HERE, 'lib', os.path.basename(src).replace('.hip', '.o'))
+        objs.append(obj)
+        if not force and _fresh(obj, [src] + HEADERS):
+            continue
+        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-c',
+               '-I' + os.path.join(ROOT, 'include'), '-o', obj, src]
+        if verbose:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
     return OUT
+
+
+def build_ext(force=False):
+    """The pybind module ``pavenet_amd._ext`` (mmcv._ext's two ms_deform_attn entry points,
+    pybind.cpp:737-748) linked against libpave_hip.so."""
+    if not force and _fresh(EXT_OUT, [EXT_SOURCE, OUT] + HEADERS):
+        return EXT_OUT
+    import torch
+    from torch.utils.cpp_extension import include_paths, library_paths
+    cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+           '-DTORCH_EXTENSION_NAME=_ext', '-DTORCH_API_INCLUDE_EXTENSION_H',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
+           '-I/opt/rocm/include', '-I' + os.path.join(ROOT, 'include'),
+           '-I' + sysconfig.get_paths()['include']] + ['-I' + p for p in include_paths()] + \
+          [EXT_SOURCE, '-o', EXT_OUT, '-L' + os.path.dirname(OUT), '-lpave_hip',
+           '-Wl,-rpath,$ORIGIN/lib'] + \
+          [a for p in library_paths() for a in ('-L' + p, '-Wl,-rpath,' + p)] + \
+          ['-lc10', '-lc10_hip', '-ltorch_cpu', '-ltorch_hip', '-ltorch', '-ltorch_python']
+    subprocess.check_call(cmd)
+    return EXT_OUT
 
 
 if __name__ == '__main__':
     print(build_native(force=True, verbose=True))
+    print(build_ext(force=True))

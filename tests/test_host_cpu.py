@@ -26,6 +26,30 @@ def test_capi_exports_every_declared_symbol():
     assert lib.pave_abi_version() == int(m.group(1)) == native.ABI_VERSION
 
 
+def test_pybind_ext_module_surface():
+    """pavenet_amd._ext (csrc/pave_mmcv_ext.cpp) builds against the installed torch headers, loads
+    on a CPU-only host and exposes the two entry points of mmcv._ext with the keyword names of
+    pybind.cpp:737-748; a host tensor raises before any launch (ms_deform_attn_cuda.cu:221-230)."""
+    from pavenet_amd.build_native import build_native, build_ext
+    build_native()
+    build_ext()
+    from pavenet_amd import _ext
+    fwd, bwd = _ext.ms_deform_attn_forward.__doc__, _ext.ms_deform_attn_backward.__doc__
+    assert re.findall(r'(\w+): torch.Tensor', fwd) == [
+        'value', 'value_spatial_shapes', 'value_level_start_index', 'sampling_locations',
+        'attention_weights'] and 'im2col_step' in fwd
+    assert re.findall(r'(\w+): torch.Tensor', bwd) == [
+        'value', 'value_spatial_shapes', 'value_level_start_index', 'sampling_locations',
+        'attention_weights', 'grad_output', 'grad_value', 'grad_sampling_loc', 'grad_attn_weight']
+    assert _ext.pave_abi_version() == 9
+    v = torch.zeros(1, 30, 8, 32)
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        _ext.ms_deform_attn_forward(value=v, value_spatial_shapes=torch.tensor([[5, 6]]),
+                                    value_level_start_index=torch.tensor([0]),
+                                    sampling_locations=torch.zeros(1, 2, 8, 1, 4, 2),
+                                    attention_weights=torch.zeros(1, 2, 8, 1, 4), im2col_step=64)
+
+
 def test_ops_fail_loudly_without_device():
     from pavenet_amd import ops
     v = torch.zeros(1, 30, 8, 32)

@@ -43,6 +43,74 @@ def test_mmcv_seed3_known_answer(golden_dir):
     assert (np.abs(out32 - ref32) / np.abs(ref32)).max() < 1e-6
 
 
+class _ExtFunction(torch.autograd.Function):
+    """The autograd Function of MO:20-89 written against an `ext_module` exactly as the reference
+    calls it (positional tensors, `im2col_step=` keyword): what mmcv runs on top of `mmcv._ext`."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        from pavenet_amd import _ext as ext_module
+        ctx.im2col_step = im2col_step
+        output = ext_module.ms_deform_attn_forward(
+            value, value_spatial_shapes, value_level_start_index, sampling_locations,
+            attention_weights, im2col_step=ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        from pavenet_amd import _ext as ext_module
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        grad_value, grad_loc, grad_aw = (torch.zeros_like(t) for t in (value, loc, aw))
+        ext_module.ms_deform_attn_backward(
+            value, shapes, lsi, loc, aw, grad_output.contiguous(), grad_value, grad_loc, grad_aw,
+            im2col_step=ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_aw, None
+
+
+def test_pybind_ext_seed3_known_answer_and_gradcheck(golden_dir):
+    """The boundary as a built, loaded, executed pybind module (pavenet_amd/_ext*.so, the
+    mmcv._ext surface of pybind.cpp:737-748): mmcv's seed-3 known answer at mmcv's tolerances
+    (test_ms_deformable_attn.py:73-135), its error behaviour, and torch.autograd.gradcheck through
+    an MO-style Function on top of it (test_ms_deformable_attn.py:138-182, fp64)."""
+    from pavenet_amd import _ext
+    g = np.load(os.path.join(golden_dir, 'op_msda.npz'))
+    shapes = _t(g['s3_shapes']).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    v, loc, aw = _t(g['s3_value']).cuda(), _t(g['s3_loc']).cuda(), _t(g['s3_aw']).cuda()
+    out64 = _ext.ms_deform_attn_forward(v.double(), shapes, lsi, loc.double(), aw.double(),
+                                        im2col_step=2).cpu().numpy()
+    ref64 = g['s3_out_f64']
+    assert np.abs(out64 - ref64).max() < 1e-18
+    assert (np.abs(out64 - ref64) / np.abs(ref64)).max() < 1e-15
+    out32 = _ext.ms_deform_attn_forward(value=v, value_spatial_shapes=shapes,
+                                        value_level_start_index=lsi, sampling_locations=loc,
+                                        attention_weights=aw, im2col_step=2).cpu().numpy()
+    ref32 = g['s3_out_f32']
+    assert np.abs(out32 - ref32).max() < 1e-9
+    assert (np.abs(out32 - ref32) / np.abs(ref32)).max() < 1e-6
+    with pytest.raises(RuntimeError, match='contiguous'):
+        _ext.ms_deform_attn_forward(v.expand(2, -1, -1, -1)[:, ::1].transpose(2, 3), shapes, lsi,
+                                    loc, aw, im2col_step=2)
+    with pytest.raises(RuntimeError):   # batch 3 % im2col_step 2 (ms_deform_attn_cuda.cu:242-245)
+        _ext.ms_deform_attn_forward(v.repeat(3, 1, 1, 1), shapes, lsi, loc.repeat(3, 1, 1, 1, 1, 1),
+                                    aw.repeat(3, 1, 1, 1, 1), im2col_step=2)
+    # gradcheck, mmcv's own recipe (N, M = 1, 2; Lq, L, P = 2, 2, 2; shapes (3, 2), (2, 1))
+    for D in (4, 30, 32):
+        gs = torch.as_tensor([(3, 2), (2, 1)], dtype=torch.long).cuda()
+        gl = torch.cat((gs.new_zeros((1,)), gs.prod(1).cumsum(0)[:-1]))
+        S = int(gs.prod(1).sum())
+        gen = torch.Generator().manual_seed(D)
+        value = (torch.rand(1, S, 2, D, generator=gen) * 0.01).double().cuda().requires_grad_(True)
+        sl = torch.rand(1, 2, 2, 2, 2, 2, generator=gen).double().cuda().requires_grad_(True)
+        w = torch.rand(1, 2, 2, 2, 2, generator=gen).double() + 1e-5
+        w = (w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)).cuda().requires_grad_(True)
+        assert torch.autograd.gradcheck(_ExtFunction.apply, (value, gs, gl, sl, w, 2))
+
+
 @pytest.mark.parametrize('case', ['enc', 'pose', 'joint', 'odd', 'd71'])
 def test_sampler_golden(golden_dir, case):
     from pavenet_amd.ops import ms_deform_attn_forward
