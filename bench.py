@@ -1,7 +1,11 @@
 """bench.py -- PAVE-Net forward throughput on MI355X (clips/s), the BASELINE.json metric.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a launcher (WORLD_SIZE unset): this process starts `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD
+    process before anything touches the GPU (as the reference's tools/dist_test.sh:8-10 does with
+    torch.distributed.launch), relays its JSON line and exits with its return code.  Launched under
+    torch.distributed.run already (WORLD_SIZE set) it is one rank of that job.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): PAVE-Net
 R-50, T = 7 frames, batch = 4 clips of synthetic 800x1344 video per GPU, 300 pose queries,
@@ -14,21 +18,24 @@ long-clip mode of BASELINE configs[4]: ONE clip of ``--frames`` frames per step,
 t % N, the T-frame attentions merged with one small all-gather each (strong scaling; not the
 headline).
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant hand-written kernel, the
-encoder deformable-attention launch, timed with HIP events on its own stream inside the timed
-region; ``cpu_baseline`` is the CPU oracle (a port of the reference's CPU path) timed on rank 0
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel class of the step, the
+split-operand MFMA GEMM / convolution launches (2*M*N*K counted per launch by the wrappers in
+pavenet_amd/ops.py, every launch bracketed by HIP events on its own stream inside the timed
+region: achieved = sum of FLOP / sum of launch times against the dense bf16 MFMA peak / 6 products);
+``roofline_hbm`` is the encoder deformable-attention launch (the dominant HBM-bound kernel) measured
+the same way; ``cpu_baseline`` is the CPU oracle (a port of the reference's CPU path) timed on rank 0
 at N = 1 on a bounded sample; ``parity`` compares clip 0 of the timed batch with that oracle run.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import pavenet_amd  # noqa: E402,F401  (sets the runtime flag hipGraph replay needs, before HIP starts)
-import torch  # noqa: E402
 
 LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
 S_TOKENS = sum(h * w for h, w in LEVELS)
@@ -78,6 +85,63 @@ def parse():
     if args.clips is None:
         args.clips = 1 if args.shard == 'frames' else 4
     return args
+
+
+def spawn_ranks(args):
+    """`--gpus N` (N > 1) run without a launcher: start the N ranks as ONE child process tree
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) -- never an exec,
+    and before this process has imported torch or touched the GPU.  The child's stdout (rank 0's
+    JSON line) is relayed; a failed, killed or hung child gives a non-zero return code."""
+    import signal
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    limit = float(os.environ.get('PAVE_BENCH_CHILD_TIMEOUT', 3000))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)   # the exact process group started above
+        out, _ = proc.communicate()
+        sys.stdout.write(out or '')
+        print(f'bench.py: the {args.gpus}-rank child did not finish within {limit:.0f} s; killed',
+              file=sys.stderr)
+        return 124
+    sys.stdout.write(out or '')
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        print(f'bench.py: the {args.gpus}-rank child exited with code {proc.returncode}', file=sys.stderr)
+        return proc.returncode if proc.returncode > 0 else 1
+    if not any(ln.startswith('{') for ln in (out or '').splitlines()):
+        print('bench.py: the child printed no JSON line', file=sys.stderr)
+        return 1
+    return 0
+
+
+ARGS = None
+if __name__ == '__main__':
+    ARGS = parse()
+    if ARGS.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(ARGS))
+
+import pavenet_amd  # noqa: E402,F401  (sets the runtime flag hipGraph replay needs, before HIP starts)
+import torch  # noqa: E402
+
+
+def file_git_blob_sha1(path):
+    """`git hash-object` of a file (sha1 over "blob <len>\\0" + bytes), without git."""
+    data = open(path, 'rb').read()
+    return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
+
+
+# launches of the split-operand MFMA GEMM family (pavenet_amd/csrc/pave_gemm_split.hip)
+SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided', 'conv7x7_stem')
 
 
 def algorithmic_bytes_encoder_launch(n_frames):
@@ -145,11 +209,12 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
 
 
 def main():
-    args = parse()
+    args = ARGS if ARGS is not None else parse()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     # PAVE_BENCH_ONE_DEVICE=1 (+ gloo): every rank on GPU 0, to exercise the N > 1 path on a 1-GPU box
     one_device = os.environ.get('PAVE_BENCH_ONE_DEVICE', '0') == '1'
     if one_device:
@@ -163,6 +228,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     dist = None
     host_collectives = False
+    backend = None
+    ranks_seen, devices = [0], [f'cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}']
     if world > 1:
         import torch.distributed as dist
         backend = 'gloo' if one_device else 'nccl'   # RCCL refuses two ranks on one device
@@ -171,6 +238,14 @@ def main():
         else:
             dist.init_process_group('gloo')
         host_collectives = backend == 'gloo'
+        # who is in the job: one all-gather of the rank ids on the data-path backend, one of the
+        # device each rank drives
+        ids = torch.full((1,), rank, dtype=torch.int64, device='cpu' if host_collectives else dev)
+        seen = torch.empty((world,), dtype=torch.int64, device=ids.device)
+        dist.all_gather_into_tensor(seen, ids)
+        ranks_seen = [int(v) for v in seen.cpu().tolist()]
+        devices = [None] * world
+        dist.all_gather_object(devices, f'cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}')
 
     from pavenet_amd import ops
     from pavenet_amd.models import build_model, videopose_r50_cfg
@@ -250,7 +325,9 @@ def main():
             step()
         sync()
         if record_events and graphed is None:  # (a replayed graph launches nothing through the wrappers)
-            ops.KERNEL_EVENTS = []  # the encoder launch records (start, end) HIP events on its stream
+            # tagged launches record (start, end) HIP events on the stream they launch on
+            ops.KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1') + SPLIT_GEMM_TAGS
+            ops.KERNEL_EVENTS = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
@@ -271,8 +348,36 @@ def main():
         native_dt, _, _ = timed(False)
         set_gemm_mode(args.gemm)
     dt, events, last = timed(True)
-    enc = [(tag, s.elapsed_time(e) * 1e-3) for tag, s, e in events if tag in ('enc_tile', 'enc_grid_T1')]
+    timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl in events]
+    enc = [(tag, t) for tag, t, _ in timed_ev if tag in ('enc_tile', 'enc_grid_T1')]
     n_frames = img.shape[0] * img.shape[1]   # frames this rank encodes per step
+    roofline_mfma = None
+    gm = [(tag, t, fl) for tag, t, fl in timed_ev if tag in SPLIT_GEMM_TAGS]
+    if gm and args.gemm != 'native':
+        tot_t, tot_f = sum(t for _, t, _ in gm), sum(fl for _, _, fl in gm)
+        peak = MFMA_PEAK[args.gemm]
+        by = {}
+        for tag, t, fl in gm:
+            d = by.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += t
+            d[2] += fl
+        roofline_mfma = dict(
+            bound='mfma',
+            kernel='gemm_bf16x3_kernel_occ2 / _w8 family (pave_gemm_split.hip): every Linear / FFN / '
+                   '1x1, 3x3, 7x7 convolution launch of the step',
+            achieved=round(tot_f / tot_t / 1e12, 1), peak=round(peak, 1), unit='TFLOP/s',
+            frac=round(tot_f / tot_t / 1e12 / peak, 4), traffic=None,
+            achieved_is='sum of 2*M*N*K over the launches (real K of the stem: 147) / sum of their '
+                        'HIP-event durations, inside the timed steps; fp32-equivalent FLOP',
+            peak_is='2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product' if args.gemm == 'bf16x3'
+                    else 'dense MFMA peak of the --gemm mode',
+            launches_per_step=round(len(gm) / args.steps, 1),
+            ms_per_step=round(tot_t / args.steps * 1e3, 3),
+            tflop_per_step=round(tot_f / args.steps / 1e12, 3),
+            by_entry_point={k: dict(launches_per_step=round(v[0] / args.steps, 1),
+                                    ms_per_step=round(v[1] / args.steps * 1e3, 3),
+                                    tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in sorted(by.items())})
     if graphed is not None:
         roofline = dict(skipped='graph replay: kernels are not launched through the timed wrappers')
     elif enc:
@@ -291,11 +396,15 @@ def main():
         tj = os.path.join(ROOT, 'profiles', 'enc_kernel_traffic.json')
         if os.path.exists(tj):   # HBM bytes per launch from rocprofv3 PMC passes of THIS workload
             t = json.load(open(tj))
+            src = os.path.join(ROOT, 'pavenet_amd', 'csrc', 'pave_enc_tile.hip')
+            # the figure is kept only while the kernel source it was measured on is unchanged
             if t.get('kernel', '').startswith(roofline['kernel'].split(' ')[0]) and \
-                    t.get('frames_per_launch') == n_frames:
+                    t.get('frames_per_launch') == n_frames and \
+                    t.get('kernel_source_git_blob') == file_git_blob_sha1(src):
                 roofline['traffic'] = t.get('hbm_bytes_per_launch')
                 roofline['traffic_source'] = 'profiles/enc_kernel_traffic.json (offline rocprofv3 ' \
-                                             '--pmc passes over bench.py, tools/pmc_bench_enc.sh)'
+                                             '--pmc passes over bench.py, tools/pmc_bench_enc.sh; ' \
+                                             'pave_enc_tile.hip blob ' + t['kernel_source_git_blob'][:10] + ')'
     else:
         roofline = None
     if rank == 0:
@@ -316,7 +425,9 @@ def main():
                                 parallelism=unit_note, gemm=args.gemm,
                                 gemm_select=args.gemm_select,
                                 detections_last_step=int(last[..., -N:].sum().item())),
-                    roofline=roofline)
+                    backend=backend, ranks_seen=ranks_seen, devices=devices,
+                    roofline=roofline_mfma if roofline_mfma is not None else roofline,
+                    roofline_hbm=roofline)
         if native_dt is not None:
             line['native_fp32_mfma'] = dict(value=round(clips / native_dt, 4), unit='clips/s',
                                             ms_per_step=round(native_dt / args.steps * 1e3, 3),

@@ -5,10 +5,16 @@ NumPy restatement of the reference's test-time input pipeline for one clip
 cv2.resize INTER_LINEAR on float32 images), mmcv.imnormalize (BGR->RGB, (x-mean)*(1/std)),
 mmcv.impad_to_multiple (zeros, bottom/right), frames stacked CHW.
 
-PARITY UNPINNED for the resize: cv2 is not installed in the build image, so the bilinear
-kernel below follows OpenCV's documented float INTER_LINEAR rule (half-pixel centres,
-fx = (dx + 0.5) * (src/dst) - 0.5, clamp at the borders) and could not be checked against
-cv2 itself.  rescale_size / normalise / pad are plain arithmetic.
+PARITY UNPINNED for the resize: cv2 is not installed in the build image and the reference holds
+no fixture for it (mmcv/image/geometric.py:63-107 just calls cv2.resize), so the bilinear kernel
+below restates OpenCV's float INTER_LINEAR in its published arithmetic order and could not be
+checked against cv2 itself:
+    inv_scale = dst / src (double);  scale = 1 / inv_scale (double)
+    f = float((dx + 0.5) * scale - 0.5)  computed in double, then cast;  s = floor(f);  f -= s
+    s < 0 -> s = 0, f = 0;   s >= src - 1 -> s = src - 1, f = 0
+    horizontal pass: row[dx] = S[s] * (1 - f) + S[s + 1] * f          (float, one rounding per op)
+    vertical pass:   D = row0 * (1 - fy) + row1 * fy                  (float, one rounding per op)
+rescale_size / normalise / pad are plain arithmetic (pinned: tests/golden/pipeline_shapes.json).
 """
 import numpy as np
 
@@ -25,10 +31,10 @@ def resize_linear(img, new_wh):
     img = img.astype(np.float32)
 
     def coords(n_dst, n_src):
-        f = (np.arange(n_dst, dtype=np.float32) + np.float32(0.5)) * np.float32(n_src / n_dst) \
-            - np.float32(0.5)
+        scale = 1.0 / (float(n_dst) / float(n_src))                       # double, as OpenCV
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
         i0 = np.floor(f).astype(np.int64)
-        frac = (f - i0).astype(np.float32)
+        frac = (f - i0.astype(np.float32)).astype(np.float32)
         frac[i0 < 0] = 0
         i0[i0 < 0] = 0
         frac[i0 >= n_src - 1] = 0
@@ -39,9 +45,12 @@ def resize_linear(img, new_wh):
     y0, y1, fy = coords(Hn, H0)
     fx = fx[None, :, None]
     fy = fy[:, None, None]
-    top = img[y0][:, x0] * (1 - fx) + img[y0][:, x1] * fx
-    bot = img[y1][:, x0] * (1 - fx) + img[y1][:, x1] * fx
-    return (top * (1 - fy) + bot * fy).astype(np.float32)
+    one = np.float32(1)
+    # horizontal pass on the two source rows of every output row, then the vertical pass; every
+    # product / sum is its own float32 operation (numpy never fuses them)
+    top = img[y0][:, x0] * (one - fx) + img[y0][:, x1] * fx
+    bot = img[y1][:, x0] * (one - fx) + img[y1][:, x1] * fx
+    return (top * (one - fy) + bot * fy).astype(np.float32)
 
 
 def preprocess_clip(frames, img_scale=(1333, 800), size_divisor=1,

@@ -365,8 +365,10 @@ class _Folded:
     def weights(cls, conv, bn):
         # the folded pair lives ON the conv module (dies with it; Python reuses id()s, so a
         # class-level dict keyed on id(conv) could serve another model's weights)
+        from .bricks import _CACHE_EPOCH
         key = tuple((id(t), t.data_ptr(), t._version) for t in
-                    (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+                    (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            (_CACHE_EPOCH[0],)
         hit = conv.__dict__.get('_pave_folded')
         if hit is None or hit[0] != key:
             with torch.no_grad():

@@ -13,7 +13,6 @@ token-major ``[bs*n, C]`` matrices feed the GEMMs and HIP kernels without copies
 """
 import copy
 import math
-import os
 import warnings
 
 import torch
@@ -114,8 +113,8 @@ def _fusable(*tensors):
 # Layer i's closing LayerNorm can also emit `out + query_pos` for layer i+1 (one pass less);
 # measured SLOWER on the bench workload (the extra 640 MB store costs more than the broadcast add
 # it saves) and superseded by folding the positional term into the merged projection GEMM
-# (deform_attn._forward_merged), so it is off unless PAVE_POS_FUSION=1.
-FUSE_QUERY_POS = os.environ.get('PAVE_POS_FUSION', '0') == '1'
+# (deform_attn._forward_merged), so it is off (set the attribute for an A/B run).
+FUSE_QUERY_POS = False   # A/B switch (tools/ab_switch.py sets the attribute; never read from the environment)
 _GEMM = {'mode': 'bf16x3', 'min_rows': 8192, 'ln_fused': True}
 
 
@@ -135,19 +134,33 @@ def get_gemm_mode():
     return _GEMM['mode']
 
 
+_CACHE_EPOCH = [0]
+
+
+def invalidate_caches():
+    """Drop every derived-operand cache of the package (split weight planes, merged / stacked /
+    paired projection weights, folded BatchNorm, epilogue tables): they are keyed on the identity
+    and `Tensor._version` of their sources, which in-place updates made through `.data`
+    (`p.data.copy_()`, `p.data = ...`, EMA helpers) do NOT bump.  Call this after such an update;
+    `load_state_dict` / `formats.load_checkpoint` and ordinary in-place ops need no call."""
+    _CACHE_EPOCH[0] += 1
+
+
 class SourceKey:
     """Identity + version of the tensors a derived cache was built from.  Holds the tensors
     themselves (an address is no identity: the caching allocator hands a freed parameter's address
     to its replacement with _version 0 again), so `key == SourceKey(srcs)` is true only for the
-    very same, unmodified tensor objects."""
+    very same, unmodified tensor objects (and the same `invalidate_caches` epoch)."""
 
     def __init__(self, tensors, extra=None):
         self.tensors = tuple(tensors)
         self.versions = tuple(t._version for t in self.tensors)
         self.extra = extra
+        self.epoch = _CACHE_EPOCH[0]
 
     def __eq__(self, other):
         return (isinstance(other, SourceKey) and self.extra == other.extra
+                and self.epoch == other.epoch
                 and len(self.tensors) == len(other.tensors)
                 and all(a is b for a, b in zip(self.tensors, other.tensors))
                 and self.versions == other.versions)
@@ -175,9 +188,10 @@ def _split_cached(weight, kind, make):
     slots = _split_slots(weight)
     slot = (tuple(weight.shape), tuple(weight.stride()), weight.storage_offset(), planes, kind)
     hit = slots.get(slot)
-    if hit is None or hit[0] != weight._version:
+    stamp = (weight._version, _CACHE_EPOCH[0])
+    if hit is None or hit[0] != stamp:
         with torch.no_grad():
-            hit = (weight._version, make(planes))
+            hit = (stamp, make(planes))
         slots[slot] = hit
         _SPLIT_STATS['made'] += 1
     return hit[1]
@@ -472,7 +486,10 @@ class MultiheadAttention(BaseModule):
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
                 attn_mask=None, key_padding_mask=None, post_norm=None, **kwargs):
         a = self.attn
+        # (train() under no_grad -- a validation pass without eval(), MC dropout -- keeps the
+        # reference's attention dropout: the fast path has none)
         if (query.is_cuda and query.dtype == torch.float32 and not torch.is_grad_enabled()
+                and (not self.training or a.dropout == 0)
                 and not self.batch_first and query.dim() == 3 and attn_mask is None
                 and key_padding_mask is None and (key is None or key is query)
                 and (value is None or value is query)

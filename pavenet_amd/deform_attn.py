@@ -208,7 +208,10 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         nv = self.value_proj.out_features
         # the per-token epilogue table depends on the positional table and this layer's weights only
         src = pos_row._base if pos_row._base is not None else pos_row
-        tkey = SourceKey([src, self.value_proj.bias, w_cat, b_cat], (tuple(pos_row.shape), S))
+        # (two same-shaped slices of one base tensor are different tables: the view's offset and
+        # strides are part of the key)
+        tkey = SourceKey([src, self.value_proj.bias, w_cat, b_cat],
+                         (tuple(pos_row.shape), pos_row.storage_offset(), tuple(pos_row.stride()), S))
         if getattr(self, '_table_key', None) == tkey:
             table = self._table
         else:

@@ -66,6 +66,7 @@ class VideoPoseV1(BaseModule):
         Frame-sharded multi-GPU: pass ``frame_shard=FrameShard(T, rank, world)`` and only the
         rank's frames, img [B, T_loc, 3, H, W] (frames t with t % world == rank, in order)."""
         feat = self.extract_feat(img)
+        head_kwargs.setdefault('last_level_only', True)   # get_bboxes reads [-1] only
         outs = self.bbox_head(feat, img_metas, **head_kwargs)
         return self.bbox_head.get_bboxes(outs, img_metas, rescale=rescale,
                                          force_score_topk=force_score_topk)

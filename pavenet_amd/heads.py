@@ -140,9 +140,11 @@ class VideoPoseHeadMulFrames(BaseModule):
         self.num_keypoints = num_keypoints
         self.num_frames = num_frames
         self.frame_prefixes = frame_prefixes(num_frames)
-        # eval: run the class / key-point / sigma branches on the last decoder level only (the
-        # earlier levels feed training losses); False = the reference's full [levels, ...] stacks
-        self.eval_last_level_only = True
+        # False (default) = the reference's contract: `forward` returns full [levels, ...] stacks of
+        # class / key-point / sigma predictions (HEAD:486-545).  The inference entry points
+        # (`simple_test_bboxes`, the detector's `forward_device`) only read [-1] (HEAD:1304-1330) and
+        # ask `forward(..., last_level_only=True)` for one-level stacks instead.
+        self.eval_last_level_only = False
         if not self.as_two_stage:
             raise RuntimeError('only "as_two_stage=True" is supported.')
         transformer = copy.deepcopy(dict(transformer))
@@ -241,7 +243,10 @@ class VideoPoseHeadMulFrames(BaseModule):
         return masks, pos, has_padding
 
     # HEAD:403-567 ----------------------------------------------------------
-    def forward(self, mlvl_feats, img_metas, **tr_kwargs):
+    def forward(self, mlvl_feats, img_metas, last_level_only=None, **tr_kwargs):
+        """HEAD:403-567.  `last_level_only` (eval mode only; default `self.eval_last_level_only`):
+        run the class / key-point / sigma branches on the last decoder level only -- the returned
+        `all_*` stacks then have leading dim 1 instead of num_dec_layers (`[-1]` is unchanged)."""
         T, Q = self.num_frames, self.num_query
         c = T // 2
         shard = tr_kwargs.get('frame_shard')
@@ -263,7 +268,8 @@ class VideoPoseHeadMulFrames(BaseModule):
         n_lvl = hs.shape[0]
         # The class / key-point / sigma branches of the earlier decoder levels only feed training
         # losses (HEAD:1304-1330 reads [-1]); in eval mode they are skipped unless asked for.
-        levels = range(n_lvl) if (self.training or not self.eval_last_level_only) else [n_lvl - 1]
+        only_last = self.eval_last_level_only if last_level_only is None else bool(last_level_only)
+        levels = [n_lvl - 1] if (only_last and not self.training) else range(n_lvl)
         for lvl in levels:
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             if lvl == n_lvl - 1:
@@ -414,7 +420,7 @@ class VideoPoseHeadMulFrames(BaseModule):
 
     def simple_test_bboxes(self, feats, img_metas, rescale=False):
         """HEAD:1507-1529 -> list (per clip) of (det_bboxes [n,5], det_labels [n], det_kpts [n,K,3])."""
-        outs = self.forward(feats, img_metas)
+        outs = self.forward(feats, img_metas, last_level_only=True)
         res = self.get_bboxes(outs, img_metas, rescale=rescale)
         return self.results_to_list(res)
 

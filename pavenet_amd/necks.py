@@ -1,6 +1,5 @@
 """``mmdet.ChannelMapper`` (a14), restated from
 third_party/mmdetection/mmdet/models/necks/channel_mapper.py:50-100."""
-import os
 
 import torch
 import torch.nn as nn
@@ -17,8 +16,8 @@ class ChannelMapper(BaseModule):
                  init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')):
         super().__init__(init_cfg)
         assert isinstance(in_channels, (list, tuple))
-        # device eval: levels are written into one flattened buffer (PAVE_NO_FLAT_NECK=1: A/B switch)
-        self.flat_output = os.environ.get('PAVE_NO_FLAT_NECK', '0') != '1'
+        # device eval: levels are written into one flattened buffer (attribute = A/B switch)
+        self.flat_output = True
         self.extra_convs = None
         if num_outs is None:
             num_outs = len(in_channels)
@@ -45,7 +44,10 @@ class ChannelMapper(BaseModule):
 
     def _flat_ok(self, inputs):
         mods = list(self.convs) + list(self.extra_convs or [])
-        return (not self.training and all(x.is_cuda and x.dtype == torch.float32 for x in inputs)
+        # the flat path writes through raw pointers / `out=` (no grad_fn): inference only.  With
+        # grad mode on (frozen-neck fine-tuning, saliency) the differentiable ConvModule path runs.
+        return (not self.training and not torch.is_grad_enabled()
+                and all(x.is_cuda and x.dtype == torch.float32 for x in inputs)
                 and (self.extra_convs is None or len(self.extra_convs) == 1)
                 and all(m.with_norm and not m.with_activation and m.conv.bias is None
                         and isinstance(getattr(m, m.norm_name), nn.GroupNorm) for m in mods))
@@ -105,7 +107,9 @@ class ChannelMapper(BaseModule):
             h, w = y.shape[2:]
             rows = y.permute(0, 2, 3, 1).reshape(n, h * w, C)          # view of the NHWC storage
             dst = buf[:, st:st + h * w]
-            if C % 4 == 0 and (C // G) % 4 == 0 and 256 % (C // 4) == 0 and gn.affine:
+            # (the kernel's own shape conditions, pave_groupnorm_nhwc_f32: anything else -> torch below)
+            if C % 4 == 0 and C <= 1024 and C % G == 0 and (C // G) % 4 == 0 and G <= 256 \
+                    and 256 % (C // 4) == 0 and gn.affine:
                 from . import ops
                 ops.groupnorm_nhwc_into(rows, gn.weight, gn.bias, G, gn.eps, dst)   # HIP, 3 launches
                 outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))

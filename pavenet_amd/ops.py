@@ -21,7 +21,7 @@ from . import native
 
 
 # When set to a list, launches whose tag is in KERNEL_EVENT_TAGS append (tag, start_event,
-# end_event) recorded on the stream they launch on (bench.py times the dominant kernel this way
+# end_event, flops) recorded on the stream they launch on (bench.py times the dominant kernel this way
 # inside its timed region; every other launch records nothing).
 KERNEL_EVENTS = None
 KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1')
@@ -32,8 +32,9 @@ def _stream_ptr():
 
 
 class _Timed:
-    def __init__(self, tag):
+    def __init__(self, tag, flops=0):
         self.tag = tag if (KERNEL_EVENTS is not None and tag in KERNEL_EVENT_TAGS) else None
+        self.flops = flops
 
     def __enter__(self):
         if self.tag is not None:
@@ -44,7 +45,7 @@ class _Timed:
     def __exit__(self, *a):
         if self.tag is not None:
             self.e.record()
-            KERNEL_EVENTS.append((self.tag, self.s, self.e))
+            KERNEL_EVENTS.append((self.tag, self.s, self.e, self.flops))
 
 
 def _require(cond, msg):
@@ -541,7 +542,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
                                       PLANES_FP16 if fp16 else int(w_planes.shape[1]),
@@ -568,7 +569,7 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
         _require(bias.numel() == Cout, 'conv1x1_strided_split: bias [Cout]')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv1x1_strided'):
+    with torch.cuda.device(x.device), _Timed('conv1x1_strided', 2 * N * Ho * Wo * Cin * Cout):
         st = lib.pave_conv1x1_strided_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), _stream_ptr())
@@ -602,7 +603,7 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
         _require(bias.numel() == Cout, 'conv7x7s2_nchw_split: bias [Cout]')
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv7x7_stem'):
+    with torch.cuda.device(x.device), _Timed('conv7x7_stem', 2 * N * Ho * Wo * Cout * 147):
         st = lib.pave_conv7x7s2_nchw_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cout, int(bool(relu)), _stream_ptr())
@@ -679,7 +680,7 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_ln: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln'):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln', 2 * M * K * N):
         st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
                                          gamma.data_ptr(), beta.data_ptr(), float(eps),
                                          out.data_ptr(), M, K, N, _stream_ptr())
@@ -719,7 +720,7 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
     out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3'):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N):
         st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                          ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
                                          M, K, N, int(bool(relu)),
@@ -755,7 +756,7 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False):
         _require(bias.numel() == Cout, 'conv3x3_split: bias [Cout]')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv3x3_split'):
+    with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin):
         st = lib.pave_conv3x3_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)),

@@ -13,7 +13,6 @@ contiguous under sequence-first views; constant-per-shape tensors (reference gri
 start indices, XCD unit order) are cached; the clip memory is never replicated per pose; the
 value projections of all decoder layers are hoisted out of the layer loop when asked.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -298,8 +297,8 @@ class Transformer(BaseModule):
         self._is_init = True
 
 
-# processing order of encoder tokens (pavenet_amd/locality.py); PAVE_UNIT_ORDER overrides for A/B runs
-UNIT_ORDER_MODE = os.environ.get('PAVE_UNIT_ORDER', 'band')
+# processing order of encoder tokens (pavenet_amd/locality.py)
+UNIT_ORDER_MODE = 'band'   # module attribute (tests / tools set it); not read from the environment
 
 
 class _LevelGeometry:

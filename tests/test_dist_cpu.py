@@ -107,3 +107,22 @@ def test_frame_shard_rejects_more_ranks_than_frames():
     with pytest.raises(AssertionError):
         FrameShard(3, 0, 4)
     assert FrameShard(3, 2, 3).local == [2] and FrameShard(15, 3, 4).local == [3, 7, 11]
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_and_reports_failure():
+    """`python bench.py --gpus 2` with no launcher (how the driver runs it) starts the two ranks
+    itself as a child `torch.distributed.run` (never an exec).  This host has no GPU, so the ranks
+    die in `torch.cuda.set_device`: the parent must relay that as a non-zero return code and say
+    so -- not fall back to one rank, not retry."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip('covered on the GPU box by test_bench_multi_rank_code_path_on_one_gpu')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1',
+                        '--warmup', '0', '--height', '128', '--width', '160', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert 'the 2-rank child exited with code' in r.stderr
+    assert 'nproc-per-node' not in r.stdout and not any(l.startswith('{') for l in r.stdout.splitlines())

@@ -19,7 +19,8 @@ _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_w
              'test_derived_operand_caches_follow_reloaded_weights',
              'test_oks_nms_kernel_vs_oracle', 'test_oks_nms_kernel_survives_nan_and_inf',
              'test_deterministic_mode_is_bit_reproducible_and_matches_default',
-             'test_hipgraph_replay_equals_eager')
+             'test_hipgraph_replay_equals_eager', 'test_bench_batch_full_size_t7_b4_vs_oracle',
+             'test_neck_eval_with_grad_keeps_the_differentiable_path')
 
 
 @pytest.fixture(autouse=True, params=['native', 'bf16x3'])
@@ -42,9 +43,11 @@ def gemm_mode(request):
     if mode != 'native':
         bricks._GEMM['min_rows'] = 1   # take the hand-written kernels at test sizes too
     made = bricks._SPLIT_STATS['made']
+    _STRICT[0] = mode == 'bf16x3'
     try:
         yield mode
     finally:
+        _STRICT[0] = False
         bricks.set_gemm_mode('native')
         bricks._GEMM['min_rows'] = old_rows
     if mode != 'native' and request.node.originalname not in ('test_oks_nms_kernel_vs_oracle',):
@@ -53,6 +56,34 @@ def gemm_mode(request):
 
 def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+_STRICT = [False]   # set by the gemm_mode fixture: True in the bit-reproducible 'bf16x3' mode
+
+
+def _close(actual, desired, rtol=1e-7, atol=0.0):
+    """np.testing.assert_allclose with the tolerances of the mode under test.  'native' (vendor
+    fp32 kernels, not run-to-run deterministic): the values written at the call.  'bf16x3' (the
+    headline mode; bit-reproducible forward, tools/soak.py): pixel quantities (written atol = 1e-2
+    px: det_kpts / det_bboxes) are asserted at BASELINE.md section 4's goal of 1e-3 px, and the
+    encoder-memory / decoder-state comparisons (written rtol = 2e-3) at half their tolerances.
+    PAVE_TOL_REPORT=<file>: append the worst |err| / tolerance ratio of every comparison."""
+    if _STRICT[0]:
+        if atol == 1e-2:
+            atol = 1e-3
+        elif rtol == 2e-3:
+            rtol, atol = 1e-3, atol / 2
+    a, d = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+    rep = os.environ.get('PAVE_TOL_REPORT')
+    if rep and a.shape == d.shape and a.size:
+        import inspect
+        err = np.abs(a - d)
+        ratio = float(np.nanmax(err / (atol + rtol * np.abs(d))))
+        fr = inspect.stack()[1]
+        with open(rep, 'a') as f:
+            f.write(f'{fr.function}:{fr.lineno} strict={_STRICT[0]} rtol={rtol:g} atol={atol:g} '
+                    f'max_abs_err={float(np.nanmax(err)):.3e} worst_ratio={ratio:.3f}\n')
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=atol)
 
 
 def _g(golden_dir, name):
@@ -79,7 +110,7 @@ def test_encoder_msda_module(golden_dir):
         out = m(_t(g['query']).cuda(), None, None, query_pos=_t(g['pos']).cuda(),
                 key_padding_mask=_t(g['mask']).cuda(), reference_points=_t(g['ref']).cuda(),
                 spatial_shapes=shapes, level_start_index=_lsi(shapes))
-    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
+    _close(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
 
 
 def test_encoder_msda_shared_pos_merged_projection_vs_oracle(gemm_mode):
@@ -110,7 +141,7 @@ def test_encoder_msda_shared_pos_merged_projection_vs_oracle(gemm_mode):
                  level_start_index=_lsi(shapes).cuda(), tile_levels=hw)
     if gemm_mode != 'native':
         assert hasattr(md, '_merged_w') and bricks._SPLIT_STATS['made'] > made   # merged path ran
-    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=5e-5)
+    _close(out.cpu().numpy(), exp.numpy(), rtol=1e-4, atol=5e-5)
 
 
 def test_pose_single_module(golden_dir):
@@ -122,7 +153,7 @@ def test_pose_single_module(golden_dir):
         out = m(_t(g['query']).cuda(), None, _t(g['value']).cuda(), query_pos=_t(g['pos']).cuda(),
                 key_padding_mask=_t(g['mask']).cuda(), reference_points=_t(g['ref']).cuda(),
                 spatial_shapes=shapes, level_start_index=_lsi(shapes))
-    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
+    _close(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
 
 
 @pytest.mark.parametrize('T', [3, 5])
@@ -139,7 +170,7 @@ def test_pose_mulframes_module(golden_dir, T):
         out = m(_t(g['query']).cuda(), None, _t(g['value']).cuda(), query_pos=_t(g['pos']).cuda(),
                 key_padding_mask=_t(g['mask']).cuda(), reference_points=_t(g['ref']).cuda(),
                 spatial_shapes=shapes, level_start_index=_lsi(shapes))
-    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
+    _close(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
 
 
 @pytest.mark.parametrize('T', [3, 5])
@@ -170,7 +201,7 @@ def test_joint_mulframes_module(golden_dir, T, convention):
         out = m(_t(g['query']).cuda(), None, value, query_pos=_t(g['pos']).cuda(),
                 key_padding_mask=mask, reference_points=_t(g['ref']).cuda(),
                 spatial_shapes=shapes, level_start_index=_lsi(shapes), **extra)
-    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
+    _close(out.cpu().numpy(), g['out'], rtol=1e-4, atol=5e-5)
 
 
 def _assert_same_selection(values, ref_idx, tol, what):
@@ -209,18 +240,18 @@ def test_end_to_end_vs_reference_golden(golden_dir, T):
         outs = m.bbox_head(feat, metas)
         memory = outs['memory'].permute(1, 0, 2)  # [B*T, S, C]
         if 'memory' in g.files:
-            np.testing.assert_allclose(memory.cpu().numpy(), g['memory'], rtol=2e-3, atol=5e-4)
+            _close(memory.cpu().numpy(), g['memory'], rtol=2e-3, atol=5e-4)
         else:
-            np.testing.assert_allclose(memory[T // 2::T].cpu().numpy(), g['memory_center'],
+            _close(memory[T // 2::T].cpu().numpy(), g['memory_center'],
                                        rtol=2e-3, atol=5e-4)
         _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 1e-4, 'proposals')
         # follow the reference's exact proposal order for the value-level comparison
         outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
-        np.testing.assert_allclose(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
+        _close(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
                                    rtol=2e-3, atol=1e-3)
-        np.testing.assert_allclose(outs['inter_references'].cpu().numpy(),
+        _close(outs['inter_references'].cpu().numpy(),
                                    g['inter_references'], rtol=1e-3, atol=2e-4)
-        np.testing.assert_allclose(outs['all_cls_scores'][-1].cpu().numpy(), g['cls_last'],
+        _close(outs['all_cls_scores'][-1].cpu().numpy(), g['cls_last'],
                                    rtol=1e-3, atol=1e-3)
         _assert_same_selection(outs['all_cls_scores'][-1][0].sigmoid(), g['score_topk'], 1e-5,
                                'score top-k')
@@ -229,8 +260,8 @@ def test_end_to_end_vs_reference_golden(golden_dir, T):
         assert res['order'][0].tolist() == list(range(N))
         (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
     assert kpts.shape == g['det_kpts'].shape, 'OKS-NMS keep set differs from the reference'
-    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+    _close(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    _close(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
     assert labels.cpu().tolist() == g['det_labels'].tolist()
 
 
@@ -266,8 +297,8 @@ def test_end_to_end_vs_oracle(T, B):
         eb, el, ek = exp[b]
         gb, gl, gk = got[b]
         assert gk.shape == ek.shape
-        np.testing.assert_allclose(gk.cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)
-        np.testing.assert_allclose(gb.cpu().numpy(), eb.numpy(), rtol=1e-4, atol=1e-2)
+        _close(gk.cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)
+        _close(gb.cpu().numpy(), eb.numpy(), rtol=1e-4, atol=1e-2)
 
 
 def test_oks_nms_kernel_survives_nan_and_inf():
@@ -358,21 +389,21 @@ def test_petr_end_to_end_vs_reference_golden(golden_dir, name, K, head):
     with torch.no_grad():
         feat = m.extract_feat(_t(g['img']).cuda())
         outs = m.bbox_head(feat, metas)
-        np.testing.assert_allclose(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
+        _close(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
                                    rtol=2e-3, atol=5e-4)
         _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 1e-4, 'proposals')
         outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
-        np.testing.assert_allclose(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
+        _close(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
                                    rtol=2e-3, atol=1e-3)
-        np.testing.assert_allclose(outs['inter_references'].cpu().numpy(), g['inter_references'],
+        _close(outs['inter_references'].cpu().numpy(), g['inter_references'],
                                    rtol=1e-3, atol=2e-4)
         _assert_same_selection(outs['all_cls_scores'][-1][0].sigmoid(), g['score_topk'], 1e-5,
                                'score top-k')
         res = m.bbox_head.get_bboxes(outs, metas,
                                      force_score_topk=_t(g['score_topk'])[None].cuda())
         (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
-    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+    _close(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    _close(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
 
 
 def test_petr_batched_vs_oracle():
@@ -396,7 +427,7 @@ def test_petr_batched_vs_oracle():
     got = m.bbox_head.results_to_list(m.forward_device(
         img.cuda(), metas, force_topk_proposals=prop.cuda(), force_score_topk=score.cuda()))
     for b in range(2):
-        np.testing.assert_allclose(got[b][2].cpu().numpy(), exp[b][2].numpy(), rtol=1e-4, atol=1e-2)
+        _close(got[b][2].cpu().numpy(), exp[b][2].numpy(), rtol=1e-4, atol=1e-2)
 
 
 def test_petr_hrnet_w48_vs_reference_golden(golden_dir):
@@ -411,7 +442,7 @@ def test_petr_hrnet_w48_vs_reference_golden(golden_dir):
     with torch.no_grad():
         feat = m.extract_feat(_t(g['img']).cuda())
         outs = m.bbox_head(feat, metas)
-        np.testing.assert_allclose(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
+        _close(outs['memory'].permute(1, 0, 2).cpu().numpy(), g['memory'],
                                    rtol=2e-3, atol=5e-4)
         _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 1e-4, 'proposals')
         outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
@@ -420,7 +451,7 @@ def test_petr_hrnet_w48_vs_reference_golden(golden_dir):
         res = m.bbox_head.get_bboxes(outs, metas,
                                      force_score_topk=_t(g['score_topk'])[None].cuda())
         (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
-    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    _close(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize('B', [1, 2])
@@ -447,7 +478,7 @@ def test_videopose_hrnet_w48_t7_vs_oracle(B):
     with torch.no_grad():
         outs = m.bbox_head(m.extract_feat(img.cuda()), metas)
         for b in range(B):
-            np.testing.assert_allclose(outs['memory'].permute(1, 0, 2)[b * T:(b + 1) * T].cpu().numpy(),
+            _close(outs['memory'].permute(1, 0, 2)[b * T:(b + 1) * T].cpu().numpy(),
                                        taps[b]['memory'].numpy(), rtol=2e-3, atol=5e-4)
             _assert_same_selection(m.bbox_head.transformer.last_enc_cls[b, :, 0], prop[b], 1e-4,
                                    'proposals')
@@ -456,8 +487,8 @@ def test_videopose_hrnet_w48_t7_vs_oracle(B):
         got = m.bbox_head.results_to_list(res)
     for b in range(B):
         assert got[b][2].shape == exp[b][2].shape
-        np.testing.assert_allclose(got[b][2].cpu().numpy(), exp[b][2].numpy(), rtol=1e-4, atol=1e-2)
-        np.testing.assert_allclose(got[b][0].cpu().numpy(), exp[b][0].numpy(), rtol=1e-4, atol=1e-2)
+        _close(got[b][2].cpu().numpy(), exp[b][2].numpy(), rtol=1e-4, atol=1e-2)
+        _close(got[b][0].cpu().numpy(), exp[b][0].numpy(), rtol=1e-4, atol=1e-2)
 
 
 def test_deterministic_mode_is_bit_reproducible_and_matches_default():
@@ -479,7 +510,7 @@ def test_deterministic_mode_is_bit_reproducible_and_matches_default():
     for r in res[1:]:
         assert torch.equal(r['kpts'], res[0]['kpts']) and torch.equal(r['keep'], res[0]['keep'])
     for a, b in zip(feat_default, feats[0]):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-4)
+        _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-4)
 
 
 def test_hipgraph_replay_equals_eager():
@@ -495,7 +526,7 @@ def test_hipgraph_replay_equals_eager():
         got = {k: v.clone() for k, v in g(img).items()}
         exp = m.forward_device(img, metas)
         for k in ('bboxes', 'kpts', 'keep'):
-            np.testing.assert_allclose(got[k].float().cpu().numpy(),
+            _close(got[k].float().cpu().numpy(),
                                        exp[k].float().cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
@@ -513,16 +544,16 @@ def test_swin_l_t3_vs_reference_golden(golden_dir):
         feat = m.extract_feat(_t(g['img']).cuda())
         outs = m.bbox_head(feat, metas)
         memory = outs['memory'].permute(1, 0, 2)
-        np.testing.assert_allclose(memory[1::3].cpu().numpy(), g['memory_center'],
+        _close(memory[1::3].cpu().numpy(), g['memory_center'],
                                    rtol=2e-3, atol=1e-3)
         _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 2e-4, 'proposals')
         outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
-        np.testing.assert_allclose(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
+        _close(outs['hs'].permute(0, 2, 1, 3).cpu().numpy(), g['hs'],
                                    rtol=2e-3, atol=2e-3)
         res = m.bbox_head.get_bboxes(outs, metas, force_score_topk=_t(g['score_topk'])[None].cuda())
         (bboxes, labels, kpts), = m.bbox_head.results_to_list(res)
     assert kpts.shape == g['det_kpts'].shape
-    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=2e-2)
+    _close(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=2e-2)
 
 
 def test_streaming_video_equals_per_window_simple_test():
@@ -549,7 +580,7 @@ def test_streaming_video_equals_per_window_simple_test():
                               force_score_topk=res['score_index'])
         got_c = m.bbox_head.results_to_list(res_s)[0]
         assert got_c[2].shape == exp[2].shape
-        np.testing.assert_allclose(got_c[2].cpu().numpy(), exp[2].cpu().numpy(),
+        _close(got_c[2].cpu().numpy(), exp[2].cpu().numpy(),
                                    rtol=1e-4, atol=1e-2)
 
 
@@ -578,10 +609,10 @@ def test_split_gemm_mode_matches_native():
         bricks._GEMM['min_rows'] = old_rows
     assert bricks._SPLIT_STATS['made'] > 10, 'the split GEMM was not exercised'
     for a, b in zip(feat, feat2):
-        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(outs2['memory'].cpu().numpy(), outs['memory'].cpu().numpy(),
+        _close(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    _close(outs2['memory'].cpu().numpy(), outs['memory'].cpu().numpy(),
                                rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(res2['kpts'].cpu().numpy(), res['kpts'].cpu().numpy(),
+    _close(res2['kpts'].cpu().numpy(), res['kpts'].cpu().numpy(),
                                rtol=1e-4, atol=1e-2)
 
 
@@ -631,24 +662,24 @@ def test_full_size_800x1344_vs_reference_golden(golden_dir):
                 mean, amax, _ = stats[f'neck{i}']
                 assert abs(float(f.mean()) - mean) < 1e-4
                 assert abs(float(f.abs().max()) - amax) < 1e-3 * amax
-            np.testing.assert_allclose(feat[3].cpu().numpy(), g['neck3'], rtol=1e-3, atol=3e-4)
+            _close(feat[3].cpu().numpy(), g['neck3'], rtol=1e-3, atol=3e-4)
             outs = m.bbox_head(feat, metas)
             memory = outs['memory'].permute(1, 0, 2)  # [B*T, S, C]
             mean, amax, _ = stats['memory']
             assert abs(float(memory.mean()) - mean) < 1e-4
             assert abs(float(memory.abs().max()) - amax) < 2e-3 * amax
             rows = _t(g['rows']).cuda()
-            np.testing.assert_allclose(memory[:, rows].cpu().numpy(), g['memory_rows'],
+            _close(memory[:, rows].cpu().numpy(), g['memory_rows'],
                                        rtol=2e-3, atol=5e-4)
-            np.testing.assert_allclose(outs['enc_cls_scores'][0, :, 0].cpu().numpy(), g['enc_cls'],
+            _close(outs['enc_cls_scores'][0, :, 0].cpu().numpy(), g['enc_cls'],
                                        rtol=1e-3, atol=1e-3)
             _assert_same_selection(outs['enc_cls_scores'][0, :, 0], g['enc_topk'], 1e-4, 'proposals')
             outs = m.bbox_head(feat, metas, force_topk_proposals=_t(g['enc_topk']).cuda())
-            np.testing.assert_allclose(outs['hs'][-1].permute(1, 0, 2).cpu().numpy(), g['hs_last'],
+            _close(outs['hs'][-1].permute(1, 0, 2).cpu().numpy(), g['hs_last'],
                                        rtol=2e-3, atol=1e-3)
-            np.testing.assert_allclose(outs['inter_references'].cpu().numpy(),
+            _close(outs['inter_references'].cpu().numpy(),
                                        g['inter_references'], rtol=1e-3, atol=2e-4)
-            np.testing.assert_allclose(outs['all_cls_scores'][-1].cpu().numpy(), g['cls_last'],
+            _close(outs['all_cls_scores'][-1].cpu().numpy(), g['cls_last'],
                                        rtol=1e-3, atol=1e-3)
             _assert_same_selection(outs['all_cls_scores'][-1][0].sigmoid(), g['score_topk'], 1e-5,
                                    'score top-k')
@@ -658,35 +689,120 @@ def test_full_size_800x1344_vs_reference_golden(golden_dir):
     finally:
         tuning.disable()
     assert kpts.shape == g['det_kpts'].shape, 'OKS-NMS keep set differs from the reference'
-    np.testing.assert_allclose(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+    _close(kpts.cpu().numpy(), g['det_kpts'], rtol=1e-4, atol=1e-2)
+    _close(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
+
+
+def test_bench_batch_full_size_t7_b4_vs_oracle():
+    """BASELINE configs[2] at FULL size inside the GPU suite: bench.py's own batch (R-50, T = 7,
+    4 clips of 800 x 1344, bench weights, headline GEMM mode 'bf16x3', shipped GEMM selections),
+    clip 0 against ONE run of the CPU oracle (about a minute on the box's host cores):
+    key points within 1e-3 px with the oracle's two top-k selections pinned, equal OKS-NMS keep
+    sets, and the FREE run (nothing pinned) reproducing every pose the oracle kept."""
+    import bench
+    from pavenet_amd import bricks, tuning
+    from pavenet_amd.models import build_model, videopose_r50_cfg
+    from pavenet_amd.weights import init_random_weights
+    T, B, N, K, H, W = 7, 4, 20, 15, 800, 1344
+    m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=N))
+    init_random_weights(m, seed=0)
+    m = m.cuda().eval()
+
+    class A:
+        height, width = H, W
+    clip0 = bench.clip0_image(A, T)
+    g = torch.Generator(device='cuda').manual_seed(1234)
+    img = torch.randn(B, T, 3, H, W, device='cuda', generator=g)
+    img[0].copy_(clip0[0])
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))
+             for _ in range(B)]
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    cfg = dict(num_frames=T, num_keypoints=K, num_query=300, max_per_img=N)
+    taps = {}
+    old = R.SAMPLER
+    R.SAMPLER = 'torch'
+    try:
+        with torch.no_grad():
+            eb, el, ek = R.videopose_simple_test(sd, cfg, clip0, taps=taps)
+    finally:
+        R.SAMPLER = old
+    bricks.set_gemm_mode('bf16x3')
+    tuning.use_tuned_gemms()
+    try:
+        with torch.no_grad():
+            free = m.bbox_head.results_to_list(m.forward_device(img, metas))[0][2].cpu()
+            res = m.forward_device(img[:1], metas[:1],
+                                   force_topk_proposals=taps['topk_idx'].cuda(),
+                                   force_score_topk=taps['score_topk_idx'].view(1, -1).cuda())
+            (gb, gl, gk), = m.bbox_head.results_to_list(res)
+    finally:
+        tuning.disable()
+        bricks.set_gemm_mode('native')
+    assert tuple(gk.shape) == tuple(ek.shape), 'OKS-NMS keep set differs from the oracle'
+    assert ek.shape[0] >= 5, 'degenerate clip: too few poses survive NMS to mean anything'
+    max_px = float((gk.cpu()[..., :2] - ek[..., :2]).abs().max())
+    assert max_px <= 1e-3, max_px
+    _close(gb.cpu().numpy()[:, :4], eb.numpy()[:, :4], rtol=0, atol=1e-3)
+    _close(gk.cpu().numpy()[..., 2], ek.numpy()[..., 2], rtol=1e-4, atol=1e-5)   # key-point scores
+    # the un-pinned batch run found every oracle pose (its own top-k, its own NMS)
+    assert free.shape[0] == ek.shape[0], (free.shape, ek.shape)
+    for pose in ek[..., :2]:
+        assert float((free[..., :2] - pose).abs().amax(dim=(1, 2)).min()) <= 1e-3
+
+
+def test_neck_eval_with_grad_keeps_the_differentiable_path():
+    """Advisor finding (round 2): the neck's flat path writes through raw pointers (no grad_fn), so
+    with grad mode ON (frozen-neck fine-tuning, saliency maps) an eval() neck must fall back to
+    the differentiable ConvModule path -- same values, gradients reach GroupNorm, the conv and the
+    input."""
+    from pavenet_amd import bricks
+    from pavenet_amd.models import build_model, videopose_r50_cfg
+    m = _build(3, 12)
+    neck = m.neck
+    feats = [_t(seeded_array(f'neckgrad.{i}', (2, c, h, w))).cuda()
+             for i, (c, h, w) in enumerate(((512, 16, 20), (1024, 8, 10), (2048, 4, 5)))]
+    for mode in ('native', 'bf16x3'):
+        bricks.set_gemm_mode(mode)
+        try:
+            with torch.no_grad():
+                flat = neck(feats)
+            xs = [f.clone().requires_grad_(True) for f in feats]
+            outs = neck(xs)
+            assert all(o.grad_fn is not None for o in outs)
+            for a, b in zip(flat, outs):
+                _close(b.detach().cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=1e-4)
+            sum(o.square().mean() for o in outs).backward()
+            gn = getattr(neck.convs[0], neck.convs[0].norm_name)
+            assert gn.weight.grad is not None and float(gn.weight.grad.abs().sum()) > 0
+            assert neck.convs[0].conv.weight.grad is not None and xs[0].grad is not None
+            neck.zero_grad()
+        finally:
+            bricks.set_gemm_mode('native')
 
 
 @pytest.mark.parametrize('shard', ['clips', 'frames'])
 def test_bench_multi_rank_code_path_on_one_gpu(shard):
     """bench.py's N > 1 code (rank set-up, clip-parallel result all-gather / frame-sharded forward,
-    max-over-ranks timing, the JSON line) executed every round: two ranks share this box's GPU over
-    gloo (PAVE_BENCH_ONE_DEVICE=1; on the 8-GPU node the same code runs on nccl = RCCL)."""
-    import socket
+    max-over-ranks timing, the JSON line) executed every round, started EXACTLY as the driver
+    starts it -- `python bench.py --gpus 2 ...`, no launcher in the command: bench.py spawns its own
+    ranks (tools/dist_test.sh:8-10).  Two ranks share this box's GPU over gloo
+    (PAVE_BENCH_ONE_DEVICE=1; on the 8-GPU node the same code runs on nccl = RCCL)."""
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+    cmd = [sys.executable, os.path.join(root, 'bench.py'),
            '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '128', '--width', '160',
            '--shard', shard, '--frames', '5' if shard == 'frames' else '3', '--no-cpu-baseline',
            '--gemm-select', 'default']
     env = dict(os.environ, PAVE_BENCH_ONE_DEVICE='1')
+    env.pop('WORLD_SIZE', None)
     torch.cuda.empty_cache()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:] + '\n---\n' + r.stderr[-4000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['steps'] == 2
     assert line['scaling'] == ('strong' if shard == 'frames' else 'weak')
+    assert line['backend'] == 'gloo' and line['ranks_seen'] == [0, 1] and len(line['devices']) == 2
 
 
 def test_split_caches_follow_reloaded_weights():
@@ -711,7 +827,7 @@ def test_split_caches_follow_reloaded_weights():
                 got = m.extract_feat(img)
                 bricks._GEMM['min_rows'] = old_rows
             for a, b in zip(got, ref):
-                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
+                _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
     finally:
         bricks.set_gemm_mode('native')
         bricks._GEMM['min_rows'] = old_rows
@@ -751,7 +867,7 @@ def test_derived_operand_caches_follow_reloaded_weights():
                 bricks._GEMM['min_rows'] = old_rows
             enc0 = tr.encoder.layers[0].attentions[0]
             assert hasattr(enc0, '_merged_w') and hasattr(enc0, '_table')      # the cached path ran
-            np.testing.assert_allclose(got['kpts'].cpu().numpy(), ref['kpts'].cpu().numpy(),
+            _close(got['kpts'].cpu().numpy(), ref['kpts'].cpu().numpy(),
                                        rtol=0, atol=2e-2)
     finally:
         bricks.set_gemm_mode('native')
@@ -780,8 +896,8 @@ def test_simple_test_rescale_result_lists_vs_reference_golden(golden_dir):
     bbox_results, kpt_results = bbox_kpt2result(b, l, k, m.bbox_head.num_classes)
     assert len(bbox_results) == 1 and len(kpt_results) == 1
     assert isinstance(bbox_results[0], np.ndarray) and kpt_results[0].shape == g['kpt_results'].shape
-    np.testing.assert_allclose(kpt_results[0], g['kpt_results'], rtol=1e-4, atol=3e-2)
-    np.testing.assert_allclose(bbox_results[0], g['bbox_results'], rtol=1e-4, atol=3e-2)
+    _close(kpt_results[0], g['kpt_results'], rtol=1e-4, atol=3e-2)
+    _close(bbox_results[0], g['bbox_results'], rtol=1e-4, atol=3e-2)
     # the un-forced public call: same list structure; same numbers whenever its own top-k
     # selections coincide with the reference's (near-ties under random weights may differ)
     (pb, pk), = m.simple_test(img, metas, rescale=True)
@@ -789,7 +905,7 @@ def test_simple_test_rescale_result_lists_vs_reference_golden(golden_dir):
     if pk[0].shape == g['kpt_results'].shape and \
             set(m.bbox_head.transformer.last_topk_proposals.flatten().tolist()) == \
             set(g0['enc_topk'].flatten().tolist()):
-        np.testing.assert_allclose(pk[0], g['kpt_results'], rtol=1e-4, atol=3e-2)
+        _close(pk[0], g['kpt_results'], rtol=1e-4, atol=3e-2)
     # empty result lists keep the reference's shapes (transforms.py:145-148)
     eb, ek = bbox_kpt2result(torch.zeros(0, 5), torch.zeros(0, dtype=torch.long),
                              torch.zeros(0, 15, 3), 1)
@@ -817,11 +933,11 @@ def test_streaming_windows_vs_oracle():
         with torch.no_grad():
             eb, el, ek = R.videopose_simple_test(sd, cfg, video[wins[c]][None],
                                                  img_shape=(120, 150, 3), taps=taps)
-        np.testing.assert_allclose(torch.stack([slabs[i] for i in wins[c]]).cpu().numpy(),
+        _close(torch.stack([slabs[i] for i in wins[c]]).cpu().numpy(),
                                    taps['memory'].numpy(), rtol=2e-3, atol=5e-4)
         res = stream.decode(slabs, [wins[c]], force_topk_proposals=taps['topk_idx'].cuda(),
                             force_score_topk=taps['score_topk_idx'].view(1, -1).cuda())
         (gb, gl, gk), = m.bbox_head.results_to_list(res)
         assert gk.shape == ek.shape
-        np.testing.assert_allclose(gk.cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)
-        np.testing.assert_allclose(gb.cpu().numpy(), eb.numpy(), rtol=1e-4, atol=1e-2)
+        _close(gk.cpu().numpy(), ek.numpy(), rtol=1e-4, atol=1e-2)
+        _close(gb.cpu().numpy(), eb.numpy(), rtol=1e-4, atol=1e-2)

@@ -536,7 +536,9 @@ def test_preprocess_clip_vs_oracle_resize_kernel_unpinned_no_cv2(dtype, hw, div)
     assert tuple(out.shape) == exp.shape and meta['img_shape'] == emeta['img_shape']
     assert meta['batch_input_shape'] == emeta['batch_input_shape']
     np.testing.assert_allclose(meta['scale_factor'], emeta['scale_factor'])
-    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=1e-4)  # fma contraction
+    # both sides follow OpenCV's published order operation by operation (double coordinates, float
+    # fractions, horizontal then vertical pass, no fused multiply-add): bit-exact
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 64, 64, 1), (1, 20, 9, 128, 128, 1),
@@ -705,7 +707,7 @@ def test_split_bf16x3_is_exact():
 @pytest.mark.parametrize('M,K,N', [(1000, 256, 1024), (257, 1024, 256), (5, 64, 128), (3000, 128, 256),
                                    (1300, 256, 64)])
 def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
-    """The split-bf16 GEMM is as accurate as an fp32 GEMM: its error against fp64 is within 4x of
+    """The split-bf16 GEMM is as accurate as an fp32 GEMM: its error against fp64 is within 2.5x of
     torch's fp32 matmul error on the same data (and far below bf16 / tf32 levels)."""
     from pavenet_amd.ops import gemm_bf16x3, split_weight_bf16x3
     g = torch.Generator().manual_seed(M + K + N)
@@ -722,7 +724,7 @@ def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
     err, err32 = (got - exact).abs().max().item(), (ref32 - exact).abs().max().item()
     scale = exact.abs().max().item()
     print(f'bf16x3 GEMM M={M} K={K} N={N}: max err {err:.3e} (torch fp32 {err32:.3e}, scale {scale:.2f})')
-    assert err <= max(4.0 * err32, 2e-7 * scale), (err, err32, scale)
+    assert err <= max(2.5 * err32, 2e-7 * scale), (err, err32, scale)
     assert err < 1e-5 * scale            # bf16 would be ~4e-3, tf32 ~5e-4
     # epilogue / prologue variants
     out = gemm_bf16x3(ad, wp, b.cuda(), r.cuda(), relu=True)

@@ -12,7 +12,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side > $R/gpurun_out/$OUT/p$i.log 2>&1
 done
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, hashlib
+_src = open('$R/pavenet_amd/csrc/pave_enc_tile.hip', 'rb').read()
+blob = hashlib.sha1(b'blob %d\0' % len(_src) + _src).hexdigest()
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$R/gpurun_out/$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -33,7 +35,7 @@ if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
     wr = out['WRITE_SIZE']['mean'] * 1024
     res = dict(kernel=kname + ' (encoder MSDA, T=1)', workload='bench.py default (28 frames/launch)', frames_per_launch=28,
                fetch_size_kb_raw=out['FETCH_SIZE']['mean'], write_size_kb=out['WRITE_SIZE']['mean'],
-               read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
+               read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr, kernel_source_git_blob=blob,
                note='FETCH_SIZE doubled per the gfx950 correction for 16-B/lane loads; separate --pmc passes')
     json.dump(res, open('$R/gpurun_out/$OUT/enc_kernel_traffic.json', 'w'), indent=1)
     print(json.dumps(res))
