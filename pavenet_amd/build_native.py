@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
            os.path.join(_HERE, 'csrc', 'pave_gemm_split.hip'),
-           os.path.join(_HERE, 'csrc', 'pave_enc_tile.hip')]
+           os.path.join(_HERE, 'csrc', 'pave_enc_tile.hip'),
+           os.path.join(_HERE, 'csrc', 'pave_gemm_dma.hip')]
 HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
 EXT_SOURCE = os.path.join(_HERE, 'csrc', 'pave_mmcv_ext.cpp')

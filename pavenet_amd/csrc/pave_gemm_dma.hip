@@ -1,0 +1,570 @@
+// libpave_hip.so -- the 3-plane split GEMM (see pave_gemm_split.hip for the arithmetic), second
+// generation: EVERY global -> LDS byte moves by LDS-DMA (global_load_lds_dwordx4: no VGPR round
+// trip, no ds_write), the activation tile lands in LDS as raw fp32 and is split into its three
+// bf16 planes by the wave that consumes it, at operand-fetch time.
+//
+// Why (timing ablations of the first-generation kernel, one binary, FFN2 shape): removing the
+// global -> VGPR loads of the loop bought 20 %, removing the ds_write staging 14 %, the VALU split
+// itself only 3 %.  The loads and the LDS stores were the cost, not the split.
+//
+// Block = 4 WN waves: wave (wm, wn) owns rows [32 wm, 32 wm + 32) x columns [128 wn, 128 wn + 32 TN)
+// (TN accumulator tiles); WN = 1 (256 threads, two blocks per CU) or WN = 2 (512 threads, the block
+// spans N = 256 whole rows: LayerNorm in the epilogue).  K slab = 16 = one
+// v_mfma_f32_32x32x16_bf16 k-step.  LDS is a ring of 3 stages; a stage holds
+//     A raw  [128 rows][4 chunks of 16 B]       chunk c of row r at slot c ^ ((r >> 2) & 3)
+//     W      [3 planes][BN rows][2 halves]      half h of row r at slot h ^ ((r >> 3) & 1)
+// The slot permutations make the ds_read_b128 of the MFMA operands (lane -> row l & 31, k half
+// l >> 5) bank-conflict free without padding (a DMA instruction writes 1 KiB of CONSECUTIVE LDS
+// bytes; the permutation is applied on the per-lane SOURCE address).
+// Pipeline per slab s: wait until the DMA of slab s + 1 has landed (vmcnt counts in issue order:
+// only the DMAs of slab s + 2 may still be in flight) and all LDS reads of this wave have returned,
+// barrier, issue the DMA of slab s + 3 into the stage slab s occupied, read the operand fragments
+// of slab s + 1, run the 6 TN MFMAs of slab s from registers while the split of slab s + 1 runs
+// on the VALU.  One barrier per slab, two slabs of load latency covered.  The residual rows of the
+// epilogue are fetched before the last slab's MFMAs.
+// (A persistent form -- 2 blocks per CU walking an XCD-local tile list, the next tile's first three
+// slabs issued before the epilogue -- was built and measured 7-10 % SLOWER on every shape: the tile
+// loop costs 40 more VGPRs (spills around the epilogue) and, vmcnt being one in-order counter, the
+// next tile's first wait also drains the epilogue's stores.  One tile per block stays.)
+// The DMA instructions are inline assembly (the compiler's wait-count pass would otherwise fence
+// every LDS read behind the youngest DMA); every wait on them is an explicit vmcnt here.  LDS
+// reads stay ordinary loads, so their lgkmcnt waits are the compiler's.  Results are bit-identical
+// to the first-generation kernel (same products, same order per accumulator).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pave_hip.h"
+#include "pave_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int QBM = 128;   // rows per block
+constexpr int QNS = 3;     // ring stages
+constexpr int QCST = 36;   // epilogue chunk (32 rows x 32 columns per wave) row stride in floats
+
+struct QConv {   // convolution forms: NHWC geometry
+  int H, W, Cin, Ho, Wo, stride;
+};
+struct QOut {    // epilogue options: second output from column nsplit on, row-periodic residual
+  float* out2;
+  int nsplit;
+  int res_rows;
+};
+struct QLn {     // LayerNorm over the output row (LNORM forms, N == block width)
+  const float* gamma;
+  const float* beta;
+  float eps;
+};
+
+__device__ __forceinline__ unsigned hi16(float x) { return __float_as_uint(x) & 0xffff0000u; }
+__device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_rne(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 consecutive fp32 (two 16-byte chunks) -> the three bf16 planes of an MFMA A operand
+// (4 dwords each): truncation, truncation, exact remainder.
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 (&pl)[3]) {
+  float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    unsigned h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      h[i] = hi16(x[i]);
+      x[i] -= __uint_as_float(h[i]);
+    }
+    pl[t] = u32x4{pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7])};
+  }
+  pl[2] = u32x4{pack_rne(x[0], x[1]), pack_rne(x[2], x[3]), pack_rne(x[4], x[5]), pack_rne(x[6], x[7])};
+}
+
+// one LDS-DMA instruction: 64 lanes x 16 B from sbase + voff (per lane) to LDS bytes
+// [lds_addr, lds_addr + 1024) in lane order
+__device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+// the same with a full 64-bit per-lane address (3x3 form: a lane may point at the zero chunk)
+__device__ __forceinline__ void dma16_flat(const void* vaddr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(vaddr), "s"(lds_addr)
+               : "memory");
+}
+// every DMA older than the NV youngest vector-memory operations of this wave has landed, every LDS
+// read of this wave has returned; then the workgroup barrier
+#define PAVE_QWAIT(NV) \
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV) : "memory")
+// LDS-only barrier of the epilogue (no vector-memory wait)
+#define PAVE_QBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (zero padding)
+
+// KIND: 0 = plain rows A [M, K];  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map;
+//       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride)
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM>
+__device__ __forceinline__ void gemm_q_body(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias, const QConv g, const QOut os, const QLn ln) {
+  constexpr int NWAVE = 4 * WN;
+  constexpr int BN = WN * TN * 32;           // block width
+  constexpr int A_STAGE = QBM * 64;          // raw fp32: 128 rows x 64 B
+  constexpr int W_STAGE = 3 * BN * 32;       // 3 planes x BN rows x 32 B
+  constexpr int STAGE = A_STAGE + W_STAGE;
+  constexpr int NA = A_STAGE / 1024;         // DMA instructions per slab: A (8)
+  constexpr int NWI = W_STAGE / 1024;        //                            W (6 | 12 | 24)
+  constexpr int NDI = NA + NWI;
+  constexpr int QMAX = (NDI + NWAVE - 1) / NWAVE;   // per wave and slab: at most / at least
+  constexpr int QMIN = NDI / NWAVE;
+  constexpr int QA = (NA + NWAVE - 1) / NWAVE;      // A instructions per wave: 2 (WN 1) | 1 (WN 2)
+  constexpr int EPI_OFF = 0;                        // per-wave epilogue chunks reuse the ring
+  constexpr int STAT_OFF = QNS * STAGE;             // LayerNorm row statistics
+  constexpr int ABOFF = STAT_OFF + (LNORM ? 2 * QBM * WN * 4 : 0);   // a_bias vector
+  static_assert(NA % NWAVE == 0, "A DMA instructions divide evenly over the waves");
+  static_assert(!LNORM || KIND == 0, "LayerNorm epilogue: plain row GEMM only");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, kh = lane >> 5;
+  const int ntiles = N / BN;
+  const int ttot = ((M + QBM - 1) / QBM) * ntiles;
+  // XCD-aware bijective tile order (the hardware deals blocks round-robin over the 8 XCDs; each
+  // XCD gets a contiguous run of logical tiles, column tile fastest, so the column tiles of one
+  // row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once)
+  const int per = ttot >> 3, rem = ttot & 7;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int nslabs = K / 16;
+  const long long w_slab = (long long)3 * N * 32;   // bytes per K slab of the weight planes
+  const unsigned char* const w_base = reinterpret_cast<const unsigned char*>(Wp);
+
+  // ---- DMA roles of this wave: instructions d = wave + NWAVE q;  q < QA: A rows, else W rows
+  int m0 = 0, n0 = 0;
+  unsigned a_voff[QA];       // KIND 0 / 3: byte offset of the lane's chunk from the slab base
+  int a_iy0[QA], a_ix0[QA];  // KIND 1: top-left input pixel of the lane's output pixel
+  const float* a_img[QA];    // KIND 1: image base + chunk offset
+  unsigned w_voff[QMAX - QA];
+  const unsigned char* a_base = reinterpret_cast<const unsigned char*>(A);
+
+  auto setup_tile = [&](const int t) {
+    const int xcd = t & 7, idx = t >> 3;
+    const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    m0 = (lb / ntiles) * QBM;
+    n0 = (lb % ntiles) * BN;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int d = wave + NWAVE * q;
+      const int r = d * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      long long gm = (long long)m0 + r;
+      if (gm >= M) gm = M - 1;   // rows past M: stand-in data, never stored
+      if (KIND == 0) {
+        a_voff[q] = (unsigned)(((gm - m0) * K + c * 4) * 4);
+      } else {
+        const unsigned ur = (unsigned)gm, gy = ur / (unsigned)g.Wo;
+        const int ox = (int)(ur - gy * (unsigned)g.Wo);
+        const int n = (int)(gy / (unsigned)g.Ho);
+        const int oy = (int)(gy - (unsigned)n * (unsigned)g.Ho);
+        if (KIND == 3) {
+          a_voff[q] = (unsigned)(((((long long)n * g.H + oy * g.stride) * g.W + ox * g.stride) * K + c * 4) * 4);
+        } else {
+          a_iy0[q] = oy * g.stride - 1;
+          a_ix0[q] = ox * g.stride - 1;
+          a_img[q] = A + (long long)n * g.H * g.W * g.Cin + c * 4;
+        }
+      }
+    }
+    if (KIND == 0) a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * K);
+#pragma unroll
+    for (int q = QA; q < QMAX; ++q) {
+      const int j = wave + NWAVE * (q - QA);         // W instruction: plane j / (NWI/3), 32 rows
+      const int p = j / (NWI / 3), row = (j % (NWI / 3)) * 32 + (lane >> 1);
+      const int h = (lane & 1) ^ ((row >> 3) & 1);
+      w_voff[q - QA] = (unsigned)((((long long)p * N + n0 + row) * 32 + h * 16));
+    }
+  };
+  auto issue = [&](const int slab, const int stage) {
+    const unsigned sl = lds0 + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const unsigned dst = sl + (wave + NWAVE * q) * 1024;
+      if (KIND == 1) {
+        const int k0 = slab * 16;
+        const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // (scalar) a slab lies inside one tap
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
+        const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        const float* src = ok ? a_img[q] + ((long long)iy * g.W + ix) * g.Cin + c0
+                              : reinterpret_cast<const float*>(g_zero_chunk);
+        dma16_flat(src, dst);
+      } else {
+        dma16(a_voff[q], a_base + (long long)slab * 64, dst);
+      }
+    }
+#pragma unroll
+    for (int q = QA; q < QMAX; ++q) {
+      const int j = wave + NWAVE * (q - QA);
+      if (NWI % NWAVE == 0 || j < NWI)   // (wave-uniform; always true unless BN = 64)
+        dma16(w_voff[q - QA], w_base + slab * w_slab, sl + A_STAGE + j * 1024);
+    }
+  };
+
+  // ---- operand fragment addresses (bytes inside a stage)
+  const int sw = (lr >> 2) & 3;
+  const int a_rd0 = (wm * 32 + lr) * 64 + (((2 * kh) ^ sw) * 16);
+  const int a_rd1 = a_rd0 ^ 16;
+  const int w_rd = A_STAGE + (wn * TN * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);
+
+  f32x16 acc[TN];
+  f32x4 raw[2];            // the lane's 8 fp32 of the next slab
+  u32x4 apl[2][3];         // A planes: [set][plane]
+  u32x4 wf[2][3][TN];      // W fragments: [set][plane][column tile]
+  const float* const ab_lds = reinterpret_cast<const float*>(smem + ABOFF);
+
+  auto read_frags = [&](const int stage, const int set) {
+    const unsigned char* st = smem + stage * STAGE;
+    raw[0] = *reinterpret_cast<const f32x4*>(st + a_rd0);
+    raw[1] = *reinterpret_cast<const f32x4*>(st + a_rd1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        wf[set][p][j] = *reinterpret_cast<const u32x4*>(st + w_rd + (p * BN + j * 32) * 32);
+  };
+  auto split_raw = [&](const int slab, const int set) {
+    f32x4 lo = raw[0], hi = raw[1];
+    if (ABIAS) {   // A' = relu(A + a_bias[k]) (the previous BatchNorm + ReLU), a_bias staged in LDS
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(ab_lds + slab * 16 + kh * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(ab_lds + slab * 16 + kh * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] = fmaxf(lo[i] + b0[i], 0.f);
+        hi[i] = fmaxf(hi[i] + b1[i], 0.f);
+      }
+    }
+    split8(lo, hi, apl[set]);
+  };
+  // the products of order o = pa + pb (o = 2, 1, 0: smallest terms first), column tiles innermost
+  auto mma = [&](const int set, const int o) {
+#pragma unroll
+    for (int pa = 0; pa <= o; ++pa)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, apl[set][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
+            acc[j], 0, 0, 0);
+  };
+
+  // ---- epilogue state
+  constexpr int NPS = 4;                 // passes per accumulator tile: 8 rows x 8 float4 each
+  const int erow = lane >> 3, ec4 = lane & 7;
+  float4 resv[TN][NPS];
+  auto prefetch_residual = [&](const int em0, const int en0) {
+    if (!residual) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
+        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+        const long long rr = os.res_rows ? (long long)((unsigned)gm % (unsigned)os.res_rows) : gm;
+        resv[j][ps] = gm < M ? *reinterpret_cast<const float4*>(residual + rr * N + ncol)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  };
+
+  if (ABIAS) {
+    float* ab = reinterpret_cast<float*>(smem + ABOFF);
+    for (int i = tid; i < K; i += 64 * NWAVE) ab[i] = a_bias[i];
+  }
+  // ---- three slabs in flight
+  setup_tile(blockIdx.x);
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  {
+    const int em0 = m0, en0 = n0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    PAVE_QWAIT(2 * QMIN);                  // slab 0 has landed everywhere
+    read_frags(0, 0);
+    split_raw(0, 0);
+
+    // ---- main loop, 6 slabs per trip (ring stage = slab % 3, register set = slab & 1).  FULL
+    // steps (no slab-count tests: one basic block, so the split of slab s + 1 is scheduled between
+    // the MFMAs of slab s) run while three more slabs follow; the guarded form runs up to the
+    // last slab but one.  nslabs is even, so the last slab's operands sit in register set 1.
+#define PAVE_QSTEP(I, FULL)                                                    \
+  if (FULL || s + I < nslabs - 1) {                                            \
+    constexpr int cur = (I) & 1, nxt = cur ^ 1;                                \
+    const int sl = s + I;                                                      \
+    if (FULL || sl + 2 < nslabs) PAVE_QWAIT(QMIN); else PAVE_QWAIT(0);         \
+    if (FULL || sl + 3 < nslabs) issue(sl + 3, (I) % 3);                       \
+    read_frags(((I) + 1) % 3, nxt);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    mma(cur, 2);                                                               \
+    split_raw(sl + 1, nxt);                                                    \
+    mma(cur, 1);                                                               \
+    mma(cur, 0);                                                               \
+  }
+    int s = 0;
+    for (; s + 9 <= nslabs; s += 6) {
+      PAVE_QSTEP(0, true)
+      PAVE_QSTEP(1, true)
+      PAVE_QSTEP(2, true)
+      PAVE_QSTEP(3, true)
+      PAVE_QSTEP(4, true)
+      PAVE_QSTEP(5, true)
+    }
+    for (; s < nslabs - 1; s += 6) {
+      PAVE_QSTEP(0, false)
+      PAVE_QSTEP(1, false)
+      PAVE_QSTEP(2, false)
+      PAVE_QSTEP(3, false)
+      PAVE_QSTEP(4, false)
+      PAVE_QSTEP(5, false)
+    }
+    // ---- last slab: every wave has read the last stage (the epilogue reuses the ring); the
+    // residual rows are fetched under the last MFMAs
+    PAVE_QWAIT(0);
+    prefetch_residual(em0, en0);
+    mma(1, 2);
+    mma(1, 1);
+    mma(1, 0);
+#undef PAVE_QSTEP
+
+    // ---- epilogue: one 32 x 32 accumulator tile at a time through the wave's own LDS chunk,
+    // float4 row segments (one full 128-byte line per row and pass)
+    float* Cs = reinterpret_cast<float*>(smem + EPI_OFF) + wave * 32 * QCST;
+    const bool seg2 = os.out2 != nullptr && en0 >= os.nsplit;
+    float* const obase = seg2 ? os.out2 : out;
+    const int ldo = os.out2 == nullptr ? N : (seg2 ? N - os.nsplit : os.nsplit);
+    const int csh = seg2 ? os.nsplit : 0;
+    if constexpr (!LNORM) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int lrow = ps * 8 + erow;
+          const long long gm = (long long)em0 + wm * 32 + lrow;
+          float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
+          v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+          if (residual) {
+            v.x += resv[j][ps].x, v.y += resv[j][ps].y, v.z += resv[j][ps].z, v.w += resv[j][ps].w;
+          }
+          if (relu) {
+            v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+          }
+          if (gm < M) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      // LayerNorm over the N = BN columns of a row: v = acc + bias + residual kept in registers,
+      // row sums completed across the 8 lanes of a row segment, the TN tiles and the WN waves of
+      // the row (through LDS); two passes: mean, then the centred sum of squares
+      float* st1 = reinterpret_cast<float*>(smem + STAT_OFF);   // [QBM][WN]
+      float* st2 = st1 + QBM * WN;
+      float4 v[TN][NPS];
+      float rsum[NPS];
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) rsum[ps] = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int lrow = ps * 8 + erow;
+          const long long gm = (long long)em0 + wm * 32 + lrow;
+          float4 x = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
+          x.x += b4.x, x.y += b4.y, x.z += b4.z, x.w += b4.w;
+          if (residual) {
+            x.x += resv[j][ps].x, x.y += resv[j][ps].y, x.z += resv[j][ps].z, x.w += resv[j][ps].w;
+          }
+          if (gm >= M) x = make_float4(0.f, 0.f, 0.f, 0.f);
+          v[j][ps] = x;
+          rsum[ps] += (x.x + x.y) + (x.z + x.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        float sm = rsum[ps];
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        if (ec4 == 0) st1[(wm * 32 + ps * 8 + erow) * WN + wn] = sm;
+      }
+      PAVE_QBAR();
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int brow = wm * 32 + ps * 8 + erow;
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sm += st1[brow * WN + w];
+        const float mean = sm * (1.f / (float)BN);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float4& x = v[j][ps];
+          x.x -= mean, x.y -= mean, x.z -= mean, x.w -= mean;
+          q += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (ec4 == 0) st2[brow * WN + wn] = q;
+      }
+      PAVE_QBAR();
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int brow = wm * 32 + ps * 8 + erow;
+        const long long gm = (long long)em0 + brow;
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) q += st2[brow * WN + w];
+        const float rstd = rsqrtf(q * (1.f / (float)BN) + ln.eps);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+          const float4 g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
+          const float4 be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
+          float4 x = v[j][ps];
+          x.x = fmaf(x.x * rstd, g4.x, be4.x);
+          x.y = fmaf(x.y * rstd, g4.y, be4.y);
+          x.z = fmaf(x.z * rstd, g4.z, be4.z);
+          x.w = fmaf(x.w * rstd, g4.w, be4.w);
+          if (gm < M) *reinterpret_cast<float4*>(out + gm * N + ncol) = x;
+        }
+      }
+    }
+  }
+}
+
+template <int TN, int KIND, bool ABIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const float* __restrict__ a_bias, const QConv g, const QOut os) {
+  gemm_q_body<TN, 1, KIND, ABIAS, false>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
+                                         QLn{nullptr, nullptr, 0.f});
+}
+// 128 x 256 block on 8 waves (two per SIMD, one block per CU): the block owns whole rows of an
+// N = 256 output, LayerNorm runs in the epilogue
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_ln_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
+  gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
+                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0}, ln);
+}
+
+template <int TN, int KIND, bool ABIAS>
+int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
+             long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
+             const QOut os) {
+  constexpr int BN = TN * 32;
+  constexpr int STAGE = QBM * 64 + 3 * BN * 32;
+  const int smem = QNS * STAGE + (ABIAS ? K * 4 : 0);
+  const long long gx = ((M + QBM - 1) / QBM) * (N / BN);
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_q: grid too large");
+  auto kern = gemm_q_kernel<TN, KIND, ABIAS>;
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_q: cannot raise dynamic LDS limit");
+    attr_smem = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, st, a, w, bias, residual, out, (int)M, K,
+                     N, relu, a_bias, g, os);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+}  // namespace
+
+// Internal entries (pave_gemm_split.hip dispatches here).  kind as the kernel's KIND; the geometry
+// is ignored for kind 0.
+int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
+                         const float* residual, long long residual_rows, float* out, float* out2,
+                         int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
+                         int Cin, int Ho, int Wo, int stride, void* stream) {
+  const QConv g{H, W, Cin, Ho, Wo, stride};
+  const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint16_t* w = static_cast<const uint16_t*>(w_planes);
+  if (K % 32 != 0 || K < 64) return pave_internal_fail(PAVE_E_ARG, "gemm_q: K %% 32 == 0, K >= 64");
+  if (a_bias && (kind != 0 || K > 8192))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: a_bias with the plain row form, K <= 8192");
+  if (kind == 1 && Cin % 32 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 32 == 0");
+#define PAVE_QGO(TN_)                                                                               \
+  if (kind == 0) {                                                                                  \
+    if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
+    return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);    \
+  }                                                                                                 \
+  if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
+  return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os)
+  if (N % 128 == 0) { PAVE_QGO(4); }
+  if (N % 64 == 0) { PAVE_QGO(2); }
+#undef PAVE_QGO
+  return pave_internal_fail(PAVE_E_ARG, "gemm_q: N %% 64 == 0 required");
+}
+
+int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
+                            const float* gamma, const float* beta, float eps, float* out, long long M,
+                            int K, int N, void* stream) {
+  if (K % 32 != 0 || K < 64 || N != 256)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_q_ln: K %% 32 == 0, K >= 64 and N == 256 required");
+  constexpr int STAGE = QBM * 64 + 3 * 256 * 32;
+  constexpr int smem = QNS * STAGE + 2 * QBM * 2 * 4;
+  auto kern = gemm_q_ln_kernel;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_q_ln: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  const long long gx = (M + QBM - 1) / QBM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), smem,
+                     reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes),
+                     bias, residual, out, (int)M, K, N, QLn{gamma, beta, eps});
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}

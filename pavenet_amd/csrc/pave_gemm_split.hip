@@ -544,7 +544,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
-                         // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never
+                         // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never,
+                         // 9 = first-generation kernels for every 3-plane form (A/B against
+                         // the LDS-DMA generation of pave_gemm_dma.hip, the default)
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {
@@ -644,6 +646,11 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
                                           "with 3 planes) required");
   if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
+  // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip); the kernels of this
+  // file keep the 1- / 2-plane and fp16 modes and the NCHW stem
+  if (nplanes == 3 && g_diag_variant != 9 && K % 32 == 0 && N % 64 == 0)
+    return pave_internal_gemm_q(a, a_bias, w_planes, bias, residual, os.res_rows, out, os.out2, os.nsplit,
+                                M, K, N, relu, 0, 0, 0, 0, 0, 0, 0, stream);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (N == 64) {  // 128 x 64 tiles (the ResNet layer1 1x1 reductions): HBM-bound, A read once
@@ -690,6 +697,8 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: bad sizes (0 < M < 2^31)");
   if (K % 64 != 0 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_ln: K %% 64 == 0 and N == 256 required");
+  if (g_diag_variant != 9)
+    return pave_internal_gemm_q_ln(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
   return launch_gemm<2, 2, false, 3, false, false, true, 4, true>(
       a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, nullptr,
       reinterpret_cast<hipStream_t>(stream), ConvGeom{0, 0, 0, 0, 0, 0}, OutSplit{nullptr, 0, 0},
@@ -712,6 +721,9 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: tensor too large");
+  if (nplanes == 3 && g_diag_variant != 9)
+    return pave_internal_gemm_q(x, nullptr, w_planes, bias, nullptr, 0, y, nullptr, 0, M, 9 * Cin, Cout,
+                                relu, 1, H, W, Cin, Ho, Wo, stride, stream);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};
@@ -745,6 +757,9 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: tensor too large");
+  if (g_diag_variant != 9)
+    return pave_internal_gemm_q(x, nullptr, w_planes, bias, nullptr, 0, y, nullptr, 0, M, Cin, Cout, relu,
+                                3, H, W, Cin, Ho, Wo, stride, stream);
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};
   return launch_gemm<2, 2, false, 3, false, 0, true>(x, static_cast<const uint16_t*>(w_planes), bias,
                                                      nullptr, y, M, Cin, Cout, relu, nullptr,

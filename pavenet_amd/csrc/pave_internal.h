@@ -3,3 +3,11 @@
 #define PAVE_INTERNAL_H_
 int pave_internal_fail(int code, const char* msg); /* records pave_last_error(), returns code */
 #endif
+// pave_gemm_dma.hip: the LDS-DMA generation of the 3-plane split GEMM (rows / 3x3 / strided rows)
+int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
+                         const float* residual, long long residual_rows, float* out, float* out2,
+                         int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
+                         int Cin, int Ho, int Wo, int stride, void* stream);
+int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
+                            const float* gamma, const float* beta, float eps, float* out, long long M,
+                            int K, int N, void* stream);

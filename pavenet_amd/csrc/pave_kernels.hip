@@ -1021,13 +1021,14 @@ __global__ __launch_bounds__(256) void preprocess_frames_kernel(
     const int W0, const int Hn, const int Wn, const int Hp, const int Wp, const float m0,
     const float m1, const float m2, const float s0, const float s1, const float s2,
     const int to_rgb) {
+#pragma clang fp contract(off)   // every product and sum below is rounded on its own (no FMA)
   const long long n = (long long)T * Hp * Wp;
   // OpenCV's float INTER_LINEAR (mmcv.imresize -> cv2.resize on the to_float32 image,
   // mmcv/image/geometric.py:63-107) in its published arithmetic order: inv_scale = dst / src and
   // scale = 1 / inv_scale in DOUBLE, source coordinate (dx + 0.5) * scale - 0.5 in double, cast to
   // float, floor, fraction in float, border clamp with the fraction zeroed; the horizontal pass
   // (a * (1 - fx) + b * fx) then the vertical one, each product and sum rounded to float on its
-  // own (no fused multiply-add: the __f*_rn intrinsics are never contracted).
+  // own (no fused multiply-add: contraction is switched off for this function).
   const double scx = 1.0 / ((double)Wn / (double)W0), scy = 1.0 / ((double)Hn / (double)H0);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -1038,14 +1039,14 @@ __global__ __launch_bounds__(256) void preprocess_frames_kernel(
     if (x < Wn && y < Hn) {
       float fx = (float)(((double)x + 0.5) * scx - 0.5), fy = (float)(((double)y + 0.5) * scy - 0.5);
       int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
-      fx = __fsub_rn(fx, (float)x0);
-      fy = __fsub_rn(fy, (float)y0);
+      fx = fx - (float)x0;
+      fy = fy - (float)y0;
       if (x0 < 0) { x0 = 0; fx = 0.f; }
       if (x0 >= W0 - 1) { x0 = W0 - 1; fx = 0.f; }
       if (y0 < 0) { y0 = 0; fy = 0.f; }
       if (y0 >= H0 - 1) { y0 = H0 - 1; fy = 0.f; }
       const int x1 = min(x0 + 1, W0 - 1), y1 = min(y0 + 1, H0 - 1);
-      const float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
+      const float gx = 1.f - fx, gy = 1.f - fy;
       const src_t* f = src + (long long)t * H0 * W0 * 3;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -1053,18 +1054,19 @@ __global__ __launch_bounds__(256) void preprocess_frames_kernel(
         const float b = (float)f[((long long)y0 * W0 + x1) * 3 + k];
         const float cc = (float)f[((long long)y1 * W0 + x0) * 3 + k];
         const float d = (float)f[((long long)y1 * W0 + x1) * 3 + k];
-        const float top = __fadd_rn(__fmul_rn(a, gx), __fmul_rn(b, fx));
-        const float bot = __fadd_rn(__fmul_rn(cc, gx), __fmul_rn(d, fx));
-        c[k] = __fadd_rn(__fmul_rn(top, gy), __fmul_rn(bot, fy));
+        const float t0 = a * gx, t1 = b * fx, b0 = cc * gx, b1 = d * fx;
+        const float top = t0 + t1, bot = b0 + b1;
+        const float u0 = top * gy, u1 = bot * fy;
+        c[k] = u0 + u1;
       }
       if (to_rgb) {
         const float tmp = c[0];
         c[0] = c[2];
         c[2] = tmp;
       }
-      c[0] = __fmul_rn(__fsub_rn(c[0], m0), s0);   // mmcv.imnormalize: subtract, then multiply
-      c[1] = __fmul_rn(__fsub_rn(c[1], m1), s1);
-      c[2] = __fmul_rn(__fsub_rn(c[2], m2), s2);
+      c[0] = (c[0] - m0) * s0;   // mmcv.imnormalize: subtract, then multiply
+      c[1] = (c[1] - m1) * s1;
+      c[2] = (c[2] - m2) * s2;
     }
     const long long plane = (long long)Hp * Wp;
     float* o = dst + (long long)t * 3 * plane + (long long)y * Wp + x;

@@ -25,6 +25,7 @@ from . import native
 # inside its timed region; every other launch records nothing).
 KERNEL_EVENTS = None
 KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1')
+KERNEL_EVENT_SHAPES = None   # tools/gemm_census.py: a list that receives the shape note of every recorded launch
 
 
 def _stream_ptr():
@@ -32,9 +33,11 @@ def _stream_ptr():
 
 
 class _Timed:
-    def __init__(self, tag, flops=0):
+    def __init__(self, tag, flops=0, shape=None):
         self.tag = tag if (KERNEL_EVENTS is not None and tag in KERNEL_EVENT_TAGS) else None
         self.flops = flops
+        if self.tag is not None and KERNEL_EVENT_SHAPES is not None:
+            KERNEL_EVENT_SHAPES.append(shape)
 
     def __enter__(self):
         if self.tag is not None:
@@ -542,7 +545,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
                                       PLANES_FP16 if fp16 else int(w_planes.shape[1]),
@@ -569,7 +572,7 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
         _require(bias.numel() == Cout, 'conv1x1_strided_split: bias [Cout]')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv1x1_strided', 2 * N * Ho * Wo * Cin * Cout):
+    with torch.cuda.device(x.device), _Timed('conv1x1_strided', 2 * N * Ho * Wo * Cin * Cout, (N * Ho * Wo, Cin, Cout, f's{stride}')):
         st = lib.pave_conv1x1_strided_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), _stream_ptr())
@@ -603,7 +606,7 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
         _require(bias.numel() == Cout, 'conv7x7s2_nchw_split: bias [Cout]')
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv7x7_stem', 2 * N * Ho * Wo * Cout * 147):
+    with torch.cuda.device(x.device), _Timed('conv7x7_stem', 2 * N * Ho * Wo * Cout * 147, (N * Ho * Wo, 147, Cout)):
         st = lib.pave_conv7x7s2_nchw_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cout, int(bool(relu)), _stream_ptr())
@@ -680,7 +683,7 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_ln: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln', 2 * M * K * N):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln', 2 * M * K * N, (M, K, N, 'ln', 'res' if residual is not None else '')):
         st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
                                          gamma.data_ptr(), beta.data_ptr(), float(eps),
                                          out.data_ptr(), M, K, N, _stream_ptr())
@@ -720,7 +723,7 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
     out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N):
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'ex', f'rows{rr}', f'split{n_split}')):
         st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                          ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
                                          M, K, N, int(bool(relu)),
@@ -756,7 +759,7 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False):
         _require(bias.numel() == Cout, 'conv3x3_split: bias [Cout]')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin):
+    with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin, (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}')):
         st = lib.pave_conv3x3_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)),
