@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 9
+#define PAVE_ABI_VERSION 10
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -284,6 +284,18 @@ int pave_ref_update_f32(const float* tmp, const float* ref, float* out, long lon
 int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y,
                             long long y_batch_stride, int N, int HW, int C, int G, float eps,
                             double* partial, int nchunks, float* ab, void* stream);
+
+/*
+ * out[M, N] = act([a | a2] @ W^T + bias + residual): two row matrices a [M, K1] and a2 [M, K - K1]
+ * share one K axis and one accumulator (3 bf16 planes) -- the ResNet Bottleneck tail with a
+ * stride-1 downsample, relu(conv3(y) + downsample(x)) = relu([y | x] @ [W3 | Wd]^T + b3 + bd)
+ * (third_party/mmdetection/mmdet/models/backbones/resnet.py:264-283), in ONE launch with no
+ * concatenation copy.  w_planes = the planes of the [N, K] row-concatenated weight.
+ * K %% 32 == 0, N %% 64 == 0, 0 < K1 < K, K1 %% 16 == 0.  residual may be NULL or alias out.
+ */
+int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, const void* w_planes,
+                             const float* bias, const float* residual, float* out, long long M, int K,
+                             int N, int relu, void* stream);
 
 /*
  * out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta  (3 bf16 planes, N == 256): the

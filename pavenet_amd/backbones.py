@@ -270,7 +270,17 @@ class ResNet(BaseModule):
                 return self._as_map(out, onhw)
             xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
             xrows, _ = self._as_rows(xs)
-            if tail is not None:
+            from .bricks import _split_cached
+            if tail is not None and b2 is None and get_gemm_mode() == 'bf16x3' \
+                    and not torch.is_grad_enabled() and yrows.shape[0] >= _GEMM['min_rows'] \
+                    and tail[0].shape[0] % 32 == 0 and tail[0].shape[1] % 64 == 0 \
+                    and yrows.shape[1] % 16 == 0:
+                # relu([y | x] @ [W3 | Wd]^T + b3 + bd) on the split kernel: two A sources, one
+                # accumulator, one launch (bn2 + relu were applied by the 3x3 kernel's epilogue)
+                wcat = _split_cached(tail[0], 'tail_cat', lambda planes: ops.split_weight_bf16x3(
+                    tail[0].t().contiguous(), planes))
+                out = ops.gemm_bf16x3_cat(yrows, xrows, wcat, tail[1], None, relu=True)
+            elif tail is not None:
                 # relu([relu(y + b2) | x] @ [W3; Wd] + b3 + bd): the whole tail in one kernel
                 out = ops.rows_gemm_bias_res_act(yrows, tail[0], tail[1], None, relu=True,
                                                  a_bias=b2, a2=xrows)

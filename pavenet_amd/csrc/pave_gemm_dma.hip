@@ -114,12 +114,15 @@ __device__ __forceinline__ void dma16_flat(const void* vaddr, unsigned lds_addr)
 __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (zero padding)
 
 // KIND: 0 = plain rows A [M, K];  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map;
-//       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride)
+//       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride);
+//       4 = rows [A | A2]: the first g.Cin columns of the K axis come from A [M, g.Cin], the rest
+//           from A2 [M, K - g.Cin] (two GEMMs sharing one accumulator: conv3 + downsample)
 template <int TN, int WN, int KIND, bool ABIAS, bool LNORM>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const QConv g, const QOut os, const QLn ln) {
+    const float* __restrict__ a_bias, const QConv g, const QOut os, const QLn ln,
+    const float* __restrict__ A2 = nullptr) {
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
   constexpr int A_STAGE = QBM * 64;          // raw fp32: 128 rows x 64 B
@@ -155,7 +158,9 @@ __device__ __forceinline__ void gemm_q_body(
 
   // ---- DMA roles of this wave: instructions d = wave + NWAVE q;  q < QA: A rows, else W rows
   int m0 = 0, n0 = 0;
-  unsigned a_voff[QA];       // KIND 0 / 3: byte offset of the lane's chunk from the slab base
+  unsigned a_voff[QA];       // KIND 0 / 3 / 4: byte offset of the lane's chunk from the slab base
+  unsigned a2_voff[QA];      // KIND 4: the same inside A2
+  const unsigned char* a2_base = reinterpret_cast<const unsigned char*>(A2);
   int a_iy0[QA], a_ix0[QA];  // KIND 1: top-left input pixel of the lane's output pixel
   const float* a_img[QA];    // KIND 1: image base + chunk offset
   unsigned w_voff[QMAX - QA];
@@ -175,6 +180,9 @@ __device__ __forceinline__ void gemm_q_body(
       if (gm >= M) gm = M - 1;   // rows past M: stand-in data, never stored
       if (KIND == 0) {
         a_voff[q] = (unsigned)(((gm - m0) * K + c * 4) * 4);
+      } else if (KIND == 4) {
+        a_voff[q] = (unsigned)(((gm - m0) * g.Cin + c * 4) * 4);
+        a2_voff[q] = (unsigned)(((gm - m0) * (K - g.Cin) + c * 4) * 4);
       } else {
         const unsigned ur = (unsigned)gm, gy = ur / (unsigned)g.Wo;
         const int ox = (int)(ur - gy * (unsigned)g.Wo);
@@ -190,6 +198,10 @@ __device__ __forceinline__ void gemm_q_body(
       }
     }
     if (KIND == 0) a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * K);
+    if (KIND == 4) {
+      a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * g.Cin);
+      a2_base = reinterpret_cast<const unsigned char*>(A2 + (long long)m0 * (K - g.Cin));
+    }
 #pragma unroll
     for (int q = QA; q < QMAX; ++q) {
       const int j = wave + NWAVE * (q - QA);         // W instruction: plane j / (NWI/3), 32 rows
@@ -212,6 +224,10 @@ __device__ __forceinline__ void gemm_q_body(
         const float* src = ok ? a_img[q] + ((long long)iy * g.W + ix) * g.Cin + c0
                               : reinterpret_cast<const float*>(g_zero_chunk);
         dma16_flat(src, dst);
+      } else if (KIND == 4) {
+        const int s1 = g.Cin >> 4;   // (scalar) slabs of the first source
+        if (slab < s1) dma16(a_voff[q], a_base + (long long)slab * 64, dst);
+        else dma16(a2_voff[q], a2_base + (long long)(slab - s1) * 64, dst);
       } else {
         dma16(a_voff[q], a_base + (long long)slab * 64, dst);
       }
@@ -264,10 +280,11 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int pa = 0; pa <= o; ++pa)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             __builtin_bit_cast(bf16x8, apl[set][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
             acc[j], 0, 0, 0);
+      }
   };
 
   // ---- epilogue state
@@ -276,16 +293,31 @@ __device__ __forceinline__ void gemm_q_body(
   float4 resv[TN][NPS];
   auto prefetch_residual = [&](const int em0, const int en0) {
     if (!residual) return;
+    // row-periodic table (row m adds residual[m % res_rows]): one modulo per lane and tile, the
+    // passes step the row by 8 with a wrap (res_rows >= 32: at most one wrap per step)
+    const long long gm0 = (long long)em0 + wm * 32 + erow;
+    const bool table = os.res_rows != 0;
+    const bool stepwise = os.res_rows >= 32;
+    long long rbase = table ? (long long)((unsigned)gm0 % (unsigned)os.res_rows) : gm0;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int ps = 0; ps < NPS; ++ps) {
+      const long long gm = gm0 + ps * 8;
+      long long rr = gm;
+      if (table) {
+        if (stepwise) {
+          rr = rbase + ps * 8;
+          if (rr >= os.res_rows) rr -= os.res_rows;
+        } else {
+          rr = (long long)((unsigned)gm % (unsigned)os.res_rows);
+        }
+      }
 #pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) {
-        const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
+      for (int j = 0; j < TN; ++j) {
         const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-        const long long rr = os.res_rows ? (long long)((unsigned)gm % (unsigned)os.res_rows) : gm;
         resv[j][ps] = gm < M ? *reinterpret_cast<const float4*>(residual + rr * N + ncol)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
   };
 
   if (ABIAS) {
@@ -479,9 +511,9 @@ template <int TN, int KIND, bool ABIAS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
-    const float* __restrict__ a_bias, const QConv g, const QOut os) {
+    const float* __restrict__ a_bias, const QConv g, const QOut os, const float* __restrict__ A2) {
   gemm_q_body<TN, 1, KIND, ABIAS, false>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
-                                         QLn{nullptr, nullptr, 0.f});
+                                         QLn{nullptr, nullptr, 0.f}, A2);
 }
 // 128 x 256 block on 8 waves (two per SIMD, one block per CU): the block owns whole rows of an
 // N = 256 output, LayerNorm runs in the epilogue
@@ -495,7 +527,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int TN, int KIND, bool ABIAS>
 int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
-             const QOut os) {
+             const QOut os, const float* a2 = nullptr) {
   constexpr int BN = TN * 32;
   constexpr int STAGE = QBM * 64 + 3 * BN * 32;
   const int smem = QNS * STAGE + (ABIAS ? K * 4 : 0);
@@ -510,7 +542,7 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
     attr_smem = smem;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, st, a, w, bias, residual, out, (int)M, K,
-                     N, relu, a_bias, g, os);
+                     N, relu, a_bias, g, os, a2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -523,7 +555,7 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
 int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
                          const float* residual, long long residual_rows, float* out, float* out2,
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
-                         int Cin, int Ho, int Wo, int stride, void* stream) {
+                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2) {
   const QConv g{H, W, Cin, Ho, Wo, stride};
   const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -532,12 +564,15 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (a_bias && (kind != 0 || K > 8192))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: a_bias with the plain row form, K <= 8192");
   if (kind == 1 && Cin % 32 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 32 == 0");
+  if (kind == 4 && (!a2 || Cin <= 0 || Cin >= K || Cin % 16 != 0))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: two-source rows need a2 and 0 < K1 < K, K1 %% 16 == 0");
 #define PAVE_QGO(TN_)                                                                               \
   if (kind == 0) {                                                                                  \
     if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
     return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);    \
   }                                                                                                 \
   if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
+  if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2); \
   return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os)
   if (N % 128 == 0) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }

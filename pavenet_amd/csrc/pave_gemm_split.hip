@@ -688,6 +688,18 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
 #undef PAVE_GO
 }
 
+int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, const void* w_planes,
+                             const float* bias, const float* residual, float* out, long long M, int K,
+                             int N, int relu, void* stream) {
+  if (!a || !a2 || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: null pointer");
+  if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: bad sizes (0 < M < 2^31)");
+  if (K % 32 != 0 || K < 64 || N % 64 != 0 || K1 <= 0 || K1 >= K || K1 % 16 != 0)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: K %% 32 == 0, N %% 64 == 0, 0 < K1 < K, K1 %% 16 == 0");
+  return pave_internal_gemm_q(a, nullptr, w_planes, bias, residual, 0, out, nullptr, 0, M, K, N, relu, 4,
+                              0, 0, (int)K1, 0, 0, 0, stream, a2);
+}
+
 int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
                             const float* residual, const float* gamma, const float* beta, float eps,
                             float* out, long long M, int K, int N, void* stream) {

@@ -33,6 +33,8 @@ SIGNATURES = {
     'pave_gemm_bf16x3_f32': [_vp] * 6 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_ex_f32': [_vp] * 5 + [ctypes.c_longlong, _vp, _vp, _c_int, ctypes.c_longlong]
                                + [_c_int] * 4 + [_vp],
+    'pave_gemm_bf16x3_cat_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,
+                                 _c_int, _vp],
     'pave_gemm_bf16x3_ln_f32': [_vp] * 6 + [ctypes.c_float, _vp, ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_groupnorm_nhwc_f32': [_vp] * 4 + [ctypes.c_longlong] + [_c_int] * 4 + [ctypes.c_float, _vp,
                                 _c_int, _vp, _vp],
@@ -47,7 +49,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
 
 _lib = None
-ABI_VERSION = 9  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 10  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

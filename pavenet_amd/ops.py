@@ -554,6 +554,43 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     return out
 
 
+def gemm_bf16x3_cat(a, a2, w_planes, bias=None, residual=None, relu=False, out=None):
+    """out[M, N] = act([a | a2] @ W^T + bias + residual): two row matrices share the K axis and one
+    accumulator (the Bottleneck tail with a stride-1 downsample: conv3 and the downsample
+    convolution in one launch, no concatenation copy).  w_planes = split_weight_bf16x3 of the
+    [N, K1 + K2] row-concatenated weight."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(a2, 'a2', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(a.dim() == 2 and a2.dim() == 2 and a.shape[0] == a2.shape[0],
+             'gemm_bf16x3_cat: a [M, K1], a2 [M, K2]')
+    M, K1 = a.shape
+    K = K1 + a2.shape[1]
+    _require(w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[3] == 16
+             and w_planes.shape[0] * 16 == K, 'gemm_bf16x3_cat: w_planes [(K1+K2)/16, 3, N, 16]')
+    N = w_planes.shape[2]
+    _require(K % 32 == 0 and N % 64 == 0 and K1 % 16 == 0, 'gemm_bf16x3_cat: K % 32, N % 64, K1 % 16')
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == N, 'gemm_bf16x3_cat: bias [N]')
+    if residual is not None:
+        _dev(residual, 'residual', torch.float32)
+        _require(tuple(residual.shape) == (M, N), 'gemm_bf16x3_cat: residual [M, N]')
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _dev(out, 'out', torch.float32)
+        _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_cat: out [M, N]')
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'cat', f'k1={K1}')):
+        st = lib.pave_gemm_bf16x3_cat_f32(a.data_ptr(), K1, a2.data_ptr(), w_planes.data_ptr(),
+                                          ptr(bias), ptr(residual), out.data_ptr(), M, K, N,
+                                          int(bool(relu)), _stream_ptr())
+    native.check(st, 'gemm_bf16x3_cat')
+    return out
+
+
 def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
     """1x1 convolution with a stride on a channels_last map through the 3-plane split GEMM (the A
     rows are the strided input pixels: no slice copy).  x [N, Cin, H, W] channels_last;

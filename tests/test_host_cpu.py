@@ -33,7 +33,7 @@ def test_pybind_ext_module_surface():
     from pavenet_amd.build_native import build_native, build_ext
     build_native()
     build_ext()
-    from pavenet_amd import _ext
+    from pavenet_amd import _ext, native
     fwd, bwd = _ext.ms_deform_attn_forward.__doc__, _ext.ms_deform_attn_backward.__doc__
     assert re.findall(r'(\w+): torch.Tensor', fwd) == [
         'value', 'value_spatial_shapes', 'value_level_start_index', 'sampling_locations',
@@ -41,7 +41,7 @@ def test_pybind_ext_module_surface():
     assert re.findall(r'(\w+): torch.Tensor', bwd) == [
         'value', 'value_spatial_shapes', 'value_level_start_index', 'sampling_locations',
         'attention_weights', 'grad_output', 'grad_value', 'grad_sampling_loc', 'grad_attn_weight']
-    assert _ext.pave_abi_version() == 9
+    assert _ext.pave_abi_version() == native.ABI_VERSION
     v = torch.zeros(1, 30, 8, 32)
     with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
         _ext.ms_deform_attn_forward(value=v, value_spatial_shapes=torch.tensor([[5, 6]]),

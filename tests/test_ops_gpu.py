@@ -737,6 +737,88 @@ def test_gemm_bf16x3_accuracy_vs_fp64(M, K, N):
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('M,K1,K2,N', [(1000, 64, 64, 256), (333, 128, 64, 128), (129, 48, 80, 64)])
+def test_gemm_bf16x3_cat_two_sources_vs_fp64(M, K1, K2, N):
+    """pave_gemm_bf16x3_cat_f32: [a | a2] @ W^T + bias (+ residual, ReLU) with the two row matrices
+    read in place (the Bottleneck tail conv3 + stride-1 downsample, resnet.py:264-283) -- vs fp64."""
+    from pavenet_amd.ops import gemm_bf16x3_cat, split_weight_bf16x3
+    g = torch.Generator().manual_seed(M + K1 + N)
+    a, a2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    w = torch.randn(N, K1 + K2, generator=g) / (K1 + K2)**0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    wp = split_weight_bf16x3(w.cuda()) if (K1 + K2) % 64 == 0 and N % 64 == 0 else None
+    if wp is None:
+        pytest.skip('weight layout helper needs K % 64 == 0')
+    exact = torch.cat([a, a2], 1).double() @ w.double().t() + b.double()
+    out = gemm_bf16x3_cat(a.cuda(), a2.cuda(), wp, b.cuda(), None, relu=False)
+    np.testing.assert_allclose(out.cpu().numpy(), exact.numpy(), rtol=1e-5, atol=1e-5)
+    out = gemm_bf16x3_cat(a.cuda(), a2.cuda(), wp, b.cuda(), r.cuda(), relu=True)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.relu(exact + r.double()).numpy(),
+                               rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('form', ['rows', 'rows_n64', 'rows_abias_res', 'ex', 'ln', 'strided', 'conv3x3',
+                                  'conv3x3_s2'])
+def test_gemm_generations_are_bit_identical(form):
+    """The LDS-DMA generation of the 3-plane split GEMM (pave_gemm_dma.hip, the default) issues the
+    same six products in the same order per accumulator as the first-generation kernels
+    (pave_gemm_split.hip): every form must give bit-identical results (LayerNorm epilogue: same
+    GEMM, different summation order of the row statistics -> 2e-6), including ragged M."""
+    from pavenet_amd import native, ops
+    lib = native.load()
+    g = torch.Generator().manual_seed(len(form))
+    dev = 'cuda'
+
+    def run():
+        if form in ('rows', 'rows_n64', 'rows_abias_res'):
+            M, K, N = (1237, 192, 384) if form == 'rows' else ((515, 256, 64) if form == 'rows_n64'
+                                                                else (777, 128, 256))
+            a = torch.randn(M, K, generator=g).to(dev)
+            wp = ops.split_weight_bf16x3((torch.randn(N, K, generator=g) * 0.05).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            if form == 'rows_abias_res':
+                r, ab = torch.randn(M, N, generator=g).to(dev), torch.randn(K, generator=g).to(dev)
+                return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True, a_bias=ab)
+            return lambda: ops.gemm_bf16x3(a, wp, b, None, relu=(form == 'rows'))
+        if form == 'ex':
+            M, K, N, rows, ns = 901, 256, 640, 53, 256
+            a = torch.randn(M, K, generator=g).to(dev)
+            wp = ops.split_weight_bf16x3((torch.randn(N, K, generator=g) * 0.05).to(dev))
+            tab = torch.randn(rows, N, generator=g).to(dev)
+            return lambda: torch.cat(ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=rows, n_split=ns), 1)
+        if form == 'ln':
+            M, K = 645, 320
+            a = torch.randn(M, K, generator=g).to(dev)
+            wp = ops.split_weight_bf16x3((torch.randn(256, K, generator=g) * 0.05).to(dev))
+            b, r = torch.randn(256, generator=g).to(dev), torch.randn(M, 256, generator=g).to(dev)
+            gam, bet = (torch.rand(256, generator=g) + 0.5).to(dev), torch.randn(256, generator=g).to(dev)
+            return lambda: ops.gemm_bf16x3_ln(a, wp, b, r, gam, bet, 1e-5)
+        if form == 'strided':
+            x = torch.randn(2, 128, 17, 23, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+            wp = ops.split_weight_bf16x3((torch.randn(256, 128, generator=g) * 0.05).to(dev))
+            b = torch.randn(256, generator=g).to(dev)
+            return lambda: ops.conv1x1_strided_split(x, wp, b, stride=2, relu=True).contiguous()
+        st = 2 if form == 'conv3x3_s2' else 1
+        x = torch.randn(3, 64, 19, 27, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wp = ops.split_conv3x3_weight((torch.randn(128, 64, 3, 3, generator=g) * 0.04).to(dev))
+        b = torch.randn(128, generator=g).to(dev)
+        return lambda: ops.conv3x3_split(x, wp, b, stride=st, relu=True).contiguous()
+
+    fn = run()
+    try:
+        lib.pave_diag_gemm_variant(9)
+        old = fn().clone()
+        lib.pave_diag_gemm_variant(0)
+        new = fn().clone()
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    torch.cuda.synchronize()
+    if form == 'ln':
+        np.testing.assert_allclose(new.cpu().numpy(), old.cpu().numpy(), rtol=0, atol=4e-6)
+    else:
+        assert torch.equal(new, old), float((new - old).abs().max())
+
+
 @pytest.mark.parametrize('M,K,N,rows,nsplit', [(1000, 256, 640, 125, 256), (777, 64, 384, 0, 128),
                                                (300, 128, 256, 7, 0), (513, 256, 512, 0, 256)])
 def test_gemm_bf16x3_ex_row_table_and_two_outputs(M, K, N, rows, nsplit):
