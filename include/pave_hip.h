@@ -333,9 +333,13 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
 /*
  * The ResNet / HRNet stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; folded BatchNorm as
  * `bias`; third_party/mmdetection/mmdet/models/backbones/resnet.py:632-640) read straight from the
- * NCHW fp32 image batch x [N, 3, H, W], as an implicit GEMM through the 3-plane split kernel:
- * K axis = (c, ky, kx) with kx padded 7 -> 8 and (c, ky) padded 21 -> 24 rows = 192; w_planes =
- * the weight laid out [64, 192] that way and split like pave_gemm_bf16x3_f32's operand.
+ * NCHW fp32 image batch x [N, 3, H, W], as an implicit GEMM on the 3-plane split scheme.
+ * w_planes = 23 K-slabs [23][3][64][16] bf16 holding the SAME weights in two K layouts:
+ *   slabs 0..11:  K = (c, ky, kx) with kx padded 7 -> 8 and (c, ky) padded 21 -> 24 rows (192) --
+ *                 the per-lane window-load kernel (any W);
+ *   slabs 12..22: K = (c, ky, kx') with kx' = kx + 1 (tap 0 unused) and (c, ky) padded 21 -> 22 rows
+ *                 (176) -- the kernel that stages the block's input window in LDS by LDS-DMA,
+ *                 taken when W %% 4 == 0 and x is 16-byte aligned.
  * y [N, Ho, Wo, 64] NHWC, Ho = (H - 1) / 2 + 1.
  */
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,

@@ -788,6 +788,12 @@ int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const fl
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * 3 * H * W >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: tensor too large");
+  // w_planes holds two layouts of the same weights (ops.split_stem7x7_weight): 12 slabs
+  // (c, ky, kx | pad) for the kernel of this file, then 11 slabs (c, ky, kx + 1) for the LDS-window
+  // kernel of pave_gemm_dma.hip, which needs 16-byte aligned image rows
+  if (g_diag_variant != 9 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    return pave_internal_stem7x7_q(x, static_cast<const uint16_t*>(w_planes) + 12 * 3 * 64 * 16, bias, y,
+                                   N, H, W, relu, stream);
   const ConvGeom g{H, W, 3, Ho, Wo, 2};
   return launch_gemm<2, 1, false, 3, false, 2, true>(x, static_cast<const uint16_t*>(w_planes), bias,
                                                      nullptr, y, M, 192, Cout, relu, nullptr,

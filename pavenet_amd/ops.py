@@ -618,13 +618,19 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
 
 
 def split_stem7x7_weight(weight):
-    """Stem weight [64, 3, 7, 7] -> operand of conv7x7s2_nchw_split: K axis (c, ky, kx) with kx
-    padded to 8 and the 21 (c, ky) rows padded to 24 (K = 192), split into 3 bf16 planes."""
+    """Stem weight [64, 3, 7, 7] -> operand of conv7x7s2_nchw_split, int16 [23, 3, 64, 16]: the 3
+    bf16 planes in two K layouts (include/pave_hip.h): 12 slabs of (c, ky, kx | pad) (K = 192)
+    followed by 11 slabs of (c, ky, kx + 1) with a zero 22nd row (K = 176)."""
     _require(tuple(weight.shape[1:]) == (3, 7, 7), 'split_stem7x7_weight: weight [Cout, 3, 7, 7]')
     co = weight.shape[0]
     w = torch.zeros((co, 24, 8), dtype=torch.float32, device=weight.device)
     w[:, :21, :7] = weight.reshape(co, 21, 7)
-    return split_weight_bf16x3(w.reshape(co, 192).contiguous(), 3)
+    a = split_weight_bf16x3(w.reshape(co, 192).contiguous(), 3)
+    w2 = torch.zeros((co, 22, 8), dtype=torch.float32, device=weight.device)
+    w2[:, :21, 1:] = weight.reshape(co, 21, 7)
+    pl = split_bf16x3(w2.reshape(co, 176).contiguous(), 3)              # [3, co, 176]
+    b = pl.view(3, co, 11, 16).permute(2, 0, 1, 3).contiguous()
+    return torch.cat([a, b], 0)
 
 
 def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
@@ -634,7 +640,7 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
     _dev(x, 'x', torch.float32)
     _dev(w_planes, 'w_planes', torch.int16)
     _require(x.dim() == 4 and x.shape[1] == 3, 'conv7x7s2_nchw_split: x [N, 3, H, W] (NCHW, dense)')
-    _require(w_planes.dim() == 4 and tuple(w_planes.shape[:2]) == (12, 3) and w_planes.shape[3] == 16,
+    _require(w_planes.dim() == 4 and tuple(w_planes.shape[:2]) == (23, 3) and w_planes.shape[3] == 16,
              'conv7x7s2_nchw_split: w_planes from split_stem7x7_weight')
     N, _, H, W = x.shape
     Cout = w_planes.shape[2]

@@ -585,10 +585,13 @@ def test_rows_gemm_bias_res_act_vs_torch(M, K, N):
                                rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('N,H,W', [(2, 37, 53, ), (1, 64, 96), (3, 16, 8), (1, 21, 130)])
+@pytest.mark.parametrize('N,H,W', [(2, 37, 53, ), (1, 64, 96), (3, 16, 8), (1, 21, 130), (2, 33, 388),
+                                   (1, 18, 200)])
 def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
     """pave_conv7x7s2_nchw_split_f32 (7x7 / stride 2 / pad 3 stem read from the NCHW batch) against
-    torch's convolution in fp64, incl. odd sizes and the edge columns."""
+    torch's convolution in fp64, incl. odd sizes and the edge columns.  W % 4 == 0 takes the
+    LDS-window kernel (several 96-pixel segments per row at W = 388, a ragged last one), the other
+    widths the per-lane window-load kernel; both must also agree bit for bit."""
     from pavenet_amd.ops import conv7x7s2_nchw_split, split_stem7x7_weight
     g = torch.Generator().manual_seed(H * W)
     x = torch.randn(N, 3, H, W, generator=g)
@@ -608,6 +611,16 @@ def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
     bad = torch.isnan(y[0]).any(0).cpu()
     expn = torch.isnan(torch.nn.functional.conv2d(xn, w, None, 2, 3)[0]).any(0)
     assert torch.equal(bad, expn)
+    if W % 4 == 0:
+        from pavenet_amd import native
+        lib = native.load()
+        new = conv7x7s2_nchw_split(x.cuda(), wp, b.cuda(), relu=True).clone()
+        try:
+            lib.pave_diag_gemm_variant(9)
+            old = conv7x7s2_nchw_split(x.cuda(), wp, b.cuda(), relu=True).clone()
+        finally:
+            lib.pave_diag_gemm_variant(0)
+        assert torch.equal(new, old)
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 256, 512, 2), (1, 20, 9, 64, 128, 2),
