@@ -240,7 +240,10 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
  * activation of its caller in the epilogue.  `w_planes` = the weight [N, K] split once by
  * pave_split_bf16x3_f32 into `nplanes` bf16 planes and re-laid slab-major [K/16][nplanes][N][16]
  * (one 16-wide K slab of a column tile contiguous; pavenet_amd.ops.split_weight_bf16x3).
- * residual may alias out.  K %% 64 == 0, N %% 128 == 0, M < 2^31.
+ * residual may alias out.  M < 2^31.
+ *   3 planes: K %% 32 == 0 (K >= 64), N %% 4 == 0; for N %% 64 != 0 the weight planes carry
+ *   roundup(N, 64) rows (zero rows beyond N) while out / bias / residual have N columns.
+ *   1 / 2 planes, fp16: K %% 64 == 0, N %% 128 == 0.
  */
 #define PAVE_PLANES_FP16 16 /* nplanes value: ONE plane of fp16 (not bf16) operands */
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
@@ -313,12 +316,17 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
  * split-operand kernel (K axis = (ky, kx, cin)), bias (+ReLU) in the epilogue:
  *   x [N, H, W, Cin];  w_planes = the weight [Cout, 3, 3, Cin] (i.e. [Cout, 9*Cin] rows) split and
  *   re-laid like pave_gemm_bf16x3_f32's operand;  y [N, Ho, Wo, Cout], Ho = (H - 1)/stride + 1.
- * Replaces a ResNet / HRNet 3x3 nn.Conv2d + folded BatchNorm (+ReLU) in the split / 16-bit GEMM
- * modes.  Cin %% 64 == 0, Cout %% 64 == 0.
+ * Replaces a ResNet / HRNet 3x3 nn.Conv2d + folded BatchNorm (+ identity) (+ReLU)
+ * (third_party/mmdetection/mmdet/models/backbones/resnet.py:53-98 BasicBlock, hrnet.py:183-260)
+ * in the split / 16-bit GEMM modes.
+ *   3 planes: Cin %% 16 == 0, Cout %% 4 == 0; the weight planes are ZERO-PADDED to
+ *   roundup(9 Cin, 32) columns and roundup(Cout, 64) rows (HRNet's 48- / 96-channel branches);
+ *   residual [N, Ho, Wo, Cout] (may be NULL or alias y) is added before the ReLU.
+ *   1 / 2 planes, fp16: Cin %% 64 == 0, Cout %% 64 == 0, residual == NULL.
  */
-int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                           int N, int H, int W, int Cin, int Cout, int stride, int relu,
-                           int nplanes, void* stream);
+int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,
+                           const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                           int stride, int relu, int nplanes, void* stream);
 
 /*
  * 1x1 convolution with a stride on an NHWC map (the ResNet downsample branch,

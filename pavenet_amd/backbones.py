@@ -395,12 +395,31 @@ class _Folded:
         w, b = cls.weights(conv, bn)
         if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) \
                 and conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
-            wsplit = split_conv_weight(w)   # split / 16-bit GEMM modes, Cin, Cout % 64 == 0
+            wsplit = split_conv_weight(w)   # split / 16-bit GEMM modes
+            if wsplit is not None and wsplit.shape[1] == 3:
+                # exact 3-plane kernel: any Cin % 16, Cout % 4 (zero-padded planes); bias, identity
+                # and ReLU in its epilogue (no separate pass)
+                return ops.conv3x3_split(x, wsplit, b, stride=conv.stride[0], relu=relu,
+                                         residual=residual, cout=w.shape[0])
             if wsplit is not None:
                 y = ops.conv3x3_split(x, wsplit, b, stride=conv.stride[0],
                                       relu=relu and residual is None,
                                       fp16=get_gemm_mode() == 'fp16')
                 return y if residual is None else ops.bias_act_rows_(y, None, residual, relu=relu)
+        if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) \
+                and conv.groups == 1 and get_gemm_mode() == 'bf16x3' and w.shape[1] % 32 == 0 \
+                and w.shape[1] >= 64 and w.shape[0] % 4 == 0 \
+                and x.is_contiguous(memory_format=torch.channels_last):
+            # 1x1 convolution = row GEMM on the NHWC map through the exact 3-plane kernel (planes
+            # zero-padded to Cout % 64 == 0), bias / identity / ReLU in its epilogue
+            from .bricks import _split_cached
+            n, cin, h, wd = x.shape
+            wp = _split_cached(w, 'gemm_pad', lambda planes: ops.split_weight_bf16x3(
+                w.detach().flatten(1).contiguous(), planes, pad=True))
+            rows = x.permute(0, 2, 3, 1).reshape(-1, cin)
+            res = residual.permute(0, 2, 3, 1).reshape(-1, w.shape[0]) if residual is not None else None
+            out = ops.gemm_bf16x3(rows, wp, b, res, relu=relu, n_out=w.shape[0])
+            return out.view(n, h, wd, -1).permute(0, 3, 1, 2)
         y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)

@@ -211,8 +211,12 @@ def split_conv_weight(weight):
     """Folded 3x3 conv weight [Cout, Cin, 3, 3] -> cached operand of ops.conv3x3_split for the
     current GEMM mode, or None when the mode / shape does not take the split kernel."""
     if _GEMM['mode'] not in _PLANES or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) \
-            or weight.shape[0] % 64 or weight.shape[1] % 64 or not weight.is_cuda \
-            or weight.dtype != torch.float32:
+            or not weight.is_cuda or weight.dtype != torch.float32:
+        return None
+    if _GEMM['mode'] == 'bf16x3':      # 3 planes: zero-padded planes (HRNet's 48 / 96 channels)
+        if weight.shape[0] % 4 or weight.shape[1] % 16:
+            return None
+    elif weight.shape[0] % 64 or weight.shape[1] % 64:
         return None
     from . import ops
     return _split_cached(weight, 'conv',

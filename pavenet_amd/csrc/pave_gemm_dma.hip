@@ -50,10 +50,11 @@ constexpr int QCST = 36;   // epilogue chunk (32 rows x 32 columns per wave) row
 struct QConv {   // convolution forms: NHWC geometry
   int H, W, Cin, Ho, Wo, stride;
 };
-struct QOut {    // epilogue options: second output from column nsplit on, row-periodic residual
-  float* out2;
-  int nsplit;
+struct QOut {    // epilogue options: second output from column nsplit on, row-periodic residual,
+  float* out2;   // real output width n_real <= N (N = the width of the zero-padded weight planes:
+  int nsplit;    // out / bias / residual have n_real columns, the columns beyond are not stored)
   int res_rows;
+  int n_real;
 };
 struct QLn {     // LayerNorm over the output row (LNORM forms, N == block width)
   const float* gamma;
@@ -220,7 +221,8 @@ __device__ __forceinline__ void gemm_q_body(
         const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // (scalar) a slab lies inside one tap
         const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
-        const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        // (tap >= 9: the zero slab that pads K = 9 Cin to a multiple of 32)
+        const bool ok = tap < 9 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
         const float* src = ok ? a_img[q] + ((long long)iy * g.W + ix) * g.Cin + c0
                               : reinterpret_cast<const float*>(g_zero_chunk);
         dma16_flat(src, dst);
@@ -314,8 +316,9 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-        resv[j][ps] = gm < M ? *reinterpret_cast<const float4*>(residual + rr * N + ncol)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        resv[j][ps] = (gm < M && ncol < os.n_real)
+                          ? *reinterpret_cast<const float4*>(residual + rr * os.n_real + ncol)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -387,14 +390,15 @@ __device__ __forceinline__ void gemm_q_body(
     float* Cs = reinterpret_cast<float*>(smem + EPI_OFF) + wave * 32 * QCST;
     const bool seg2 = os.out2 != nullptr && en0 >= os.nsplit;
     float* const obase = seg2 ? os.out2 : out;
-    const int ldo = os.out2 == nullptr ? N : (seg2 ? N - os.nsplit : os.nsplit);
+    const int ldo = os.out2 == nullptr ? os.n_real : (seg2 ? N - os.nsplit : os.nsplit);
     const int csh = seg2 ? os.nsplit : 0;
     if constexpr (!LNORM) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + ncol)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool colok = ncol < os.n_real;
+        const float4 b4 = (bias && colok) ? *reinterpret_cast<const float4*>(bias + ncol)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
@@ -413,7 +417,7 @@ __device__ __forceinline__ void gemm_q_body(
           if (relu) {
             v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
           }
-          if (gm < M) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
+          if (gm < M && colok) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
   gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
-                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0}, ln);
+                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N}, ln);
 }
 
 // ---------------------------------------------------------------------------
@@ -684,15 +688,18 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
 int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
                          const float* residual, long long residual_rows, float* out, float* out2,
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
-                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2) {
+                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real) {
   const QConv g{H, W, Cin, Ho, Wo, stride};
-  const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows};
+  if (n_real <= 0) n_real = N;
+  if (n_real > N || n_real % 4 != 0 || (out2 && n_real != N))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: n_real %% 4 == 0, n_real <= N (== N with two outputs)");
+  const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows, n_real};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (K % 32 != 0 || K < 64) return pave_internal_fail(PAVE_E_ARG, "gemm_q: K %% 32 == 0, K >= 64");
   if (a_bias && (kind != 0 || K > 8192))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: a_bias with the plain row form, K <= 8192");
-  if (kind == 1 && Cin % 32 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 32 == 0");
+  if (kind == 1 && Cin % 16 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 16 == 0");
   if (kind == 4 && (!a2 || Cin <= 0 || Cin >= K || Cin % 16 != 0))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: two-source rows need a2 and 0 < K1 < K, K1 %% 16 == 0");
 #define PAVE_QGO(TN_)                                                                               \

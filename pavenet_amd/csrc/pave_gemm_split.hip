@@ -641,16 +641,18 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
+  // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip) takes K %% 32 == 0 and any
+  // N %% 4 == 0 -- the weight planes then carry roundup(N, 64) rows (zero rows beyond N), out / bias /
+  // residual have N columns.  The kernels of this file keep the 1- / 2-plane and fp16 modes.
+  if (nplanes == 3 && g_diag_variant != 9 && K % 32 == 0 && K >= 64 && N % 4 == 0 &&
+      (N % 64 == 0 || !os.out2))
+    return pave_internal_gemm_q(a, a_bias, w_planes, bias, residual, os.res_rows, out, os.out2, os.nsplit,
+                                M, K, (N + 63) / 64 * 64, relu, 0, 0, 0, 0, 0, 0, 0, stream, nullptr, N);
   if (K % 64 != 0 || (N % 128 != 0 && !(N == 64 && nplanes == 3 && !os.out2)))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 (or N == 64 "
                                           "with 3 planes) required");
   if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
-  // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip); the kernels of this
-  // file keep the 1- / 2-plane and fp16 modes and the NCHW stem
-  if (nplanes == 3 && g_diag_variant != 9 && K % 32 == 0 && N % 64 == 0)
-    return pave_internal_gemm_q(a, a_bias, w_planes, bias, residual, os.res_rows, out, os.out2, os.nsplit,
-                                M, K, N, relu, 0, 0, 0, 0, 0, 0, 0, stream);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (N == 64) {  // 128 x 64 tiles (the ResNet layer1 1x1 reductions): HBM-bound, A read once
@@ -719,23 +721,27 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
 
 void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tools/)
 
-int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                           int N, int H, int W, int Cin, int Cout, int stride, int relu,
-                           int nplanes, void* stream) {
+int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,
+                           const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                           int stride, int relu, int nplanes, void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: null pointer");
   if (N <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2))
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: bad sizes (stride 1 or 2)");
-  if (Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: Cin %% 64 == 0 and Cout %% 64 == 0 required");
+  const bool padded = Cin % 64 != 0 || Cout % 64 != 0;   // zero-padded weight planes: 3-plane DMA kernel only
+  if (Cin <= 0 || Cout <= 0 || Cin % 16 != 0 || Cout % 4 != 0 ||
+      ((padded || residual) && (nplanes != 3 || g_diag_variant == 9)))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: Cin %% 16 == 0 and Cout %% 4 == 0 (3 planes; the other "
+                                          "modes: Cin, Cout %% 64 == 0, no residual) required");
   if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: nplanes must be 1, 2, 3 or PAVE_PLANES_FP16");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: tensor too large");
-  if (nplanes == 3 && g_diag_variant != 9)
-    return pave_internal_gemm_q(x, nullptr, w_planes, bias, nullptr, 0, y, nullptr, 0, M, 9 * Cin, Cout,
-                                relu, 1, H, W, Cin, Ho, Wo, stride, stream);
+  if (nplanes == 3 && g_diag_variant != 9)   // K = 9 Cin padded to a multiple of 32, Cout to one of 64
+    return pave_internal_gemm_q(x, nullptr, w_planes, bias, residual, 0, y, nullptr, 0, M,
+                                (9 * Cin + 31) / 32 * 32, (Cout + 63) / 64 * 64, relu, 1, H, W, Cin, Ho,
+                                Wo, stride, stream, nullptr, Cout);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};

@@ -7,7 +7,8 @@ int pave_internal_fail(int code, const char* msg); /* records pave_last_error(),
 int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
                          const float* residual, long long residual_rows, float* out, float* out2,
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
-                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2 = nullptr);
+                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2 = nullptr,
+                         int n_real = 0);
 int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, float* out, long long M,
                             int K, int N, void* stream);

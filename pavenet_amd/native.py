@@ -42,7 +42,7 @@ SIGNATURES = {
     'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 5 + [_vp],
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
-    'pave_conv3x3_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
+    'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
 # every symbol include/pave_hip.h declares

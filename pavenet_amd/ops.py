@@ -502,25 +502,34 @@ def split_bf16x3(x, planes=3):
     return out
 
 
-def split_weight_bf16x3(weight, planes=3):
+def split_weight_bf16x3(weight, planes=3, pad=False):
     """nn.Linear weight [N, K] -> the W operand of `gemm_bf16x3`: int16 [K/16, planes, N, 16],
     i.e. the bf16 planes cut into 16-wide K slabs, slab-major, so that one slab of a column tile
-    is contiguous in memory (every 128-byte line is fetched once)."""
-    _require(weight.dim() == 2 and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0,
-             'split_weight_bf16x3: weight [N % 64 == 0, K % 64 == 0]')
+    is contiguous in memory (every 128-byte line is fetched once).  pad=True (3-plane kernels):
+    zero rows / columns up to N % 64 == 0, K % 32 == 0 (the kernels store the real N columns)."""
+    _require(weight.dim() == 2, 'split_weight_bf16x3: weight [N, K]')
     N, K = weight.shape
+    if pad and (N % 64 or K % 32):
+        Np, Kp = (N + 63) // 64 * 64, (K + 31) // 32 * 32
+        wpad = torch.zeros((Np, Kp), dtype=weight.dtype, device=weight.device)
+        wpad[:N, :K] = weight
+        weight, N, K = wpad, Np, Kp
+    _require((K % 64 == 0 and N % 64 == 0) or (pad and K % 32 == 0 and N % 64 == 0),
+             'split_weight_bf16x3: weight [N % 64 == 0, K % 64 == 0] (pad=True: any N, K)')
     pl = split_bf16x3(weight.contiguous(), planes)
     return pl.view(pl.shape[0], N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
 
 
 def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None,
-                fp16=False):
+                fp16=False, n_out=None):
     """out[M, N] = act(A' @ W^T + bias + residual), A' = relu(a + a_bias) if a_bias is given, on
     the bf16 matrix cores with both operands split into P = w_planes.shape[1] bf16 terms
     (P = 3: exact split, 6 MFMA products, fp32-level accuracy;  2: 3 products, ~2^-16;
     1: plain bf16 operands, or fp16 operands with fp16=True and a PLANES_FP16 weight), fp32
     accumulate, fp32 in / out.
-    w_planes = split_weight_bf16x3(weight [N, K]).  `residual` may be the tensor given as `out`."""
+    w_planes = split_weight_bf16x3(weight [N, K]).  `residual` may be the tensor given as `out`.
+    n_out (3 planes): the real output width when the planes were zero-padded to N % 64 == 0
+    (split_weight_bf16x3(..., pad=True)); out / bias / residual then have n_out columns."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
     _dev(w_planes, 'w_planes', torch.int16)
@@ -530,8 +539,13 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
              'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
     N = w_planes.shape[2]
-    _require(N % 128 == 0 or (N == 64 and w_planes.shape[1] == 3),
-             'gemm_bf16x3: N % 128 == 0 (or N == 64 with 3 planes)')
+    if n_out is not None and n_out != N:
+        _require(w_planes.shape[1] == 3 and n_out % 4 == 0 and (n_out + 63) // 64 * 64 == N,
+                 'gemm_bf16x3: n_out % 4 == 0 with 3 planes padded to roundup(n_out, 64) rows')
+        N = int(n_out)
+    else:
+        _require(N % 128 == 0 or (N % 64 == 0 and w_planes.shape[1] == 3),
+                 'gemm_bf16x3: N % 128 == 0 (or N % 64 == 0 with 3 planes)')
     for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
         if t is not None:
             _dev(t, nm, torch.float32)
@@ -781,30 +795,42 @@ def split_conv3x3_weight(weight, planes=3):
     split and re-laid by `split_weight_bf16x3`."""
     _require(weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3), 'split_conv3x3_weight: [Cout,Cin,3,3]')
     cout, cin = weight.shape[:2]
-    return split_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous(), planes)
+    # 3 planes: rows / columns zero-padded to Cout % 64 == 0, 9 Cin % 32 == 0 (HRNet's 48 / 96 channels)
+    return split_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous(), planes,
+                               pad=planes == 3)
 
 
-def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False):
+def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False, residual=None, cout=None):
     """3x3 / pad 1 convolution of a channels_last map through the split-operand GEMM kernel
-    (implicit GEMM), bias (+ReLU) fused.  x [N, Cin, H, W] channels_last; w_planes =
-    split_conv3x3_weight(weight) -> [N, Cout, Ho, Wo] channels_last."""
+    (implicit GEMM), bias (+ residual) (+ReLU) fused.  x [N, Cin, H, W] channels_last; w_planes =
+    split_conv3x3_weight(weight) -> [N, Cout, Ho, Wo] channels_last.  `cout` = the real number of
+    output channels when the planes were zero-padded (3 planes: Cin % 16 == 0, Cout % 4 == 0);
+    residual [N, Cout, Ho, Wo] channels_last is added before the ReLU (3 planes)."""
     lib = native.load()
     _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv3x3_split: fp32 4-D')
     _require(x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_split: channels_last input')
     _dev(w_planes, 'w_planes', torch.int16)
     N, Cin, H, W = x.shape
-    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == 9 * Cin and w_planes.shape[3] == 16,
+    kp = 9 * Cin if w_planes.shape[1] != 3 else (9 * Cin + 31) // 32 * 32
+    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == kp and w_planes.shape[3] == 16,
              'conv3x3_split: w_planes [9*Cin/16, P, Cout, 16] (split_conv3x3_weight)')
     _require(not fp16 or w_planes.shape[1] == 1, 'conv3x3_split: fp16 takes a single plane')
-    Cout = w_planes.shape[2]
+    Cout = int(cout) if cout is not None else w_planes.shape[2]
+    _require((Cout + 63) // 64 * 64 == w_planes.shape[2], 'conv3x3_split: cout does not match the planes')
     if bias is not None:
         _dev(bias, 'bias', torch.float32)
         _require(bias.numel() == Cout, 'conv3x3_split: bias [Cout]')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if residual is not None:
+        _require(residual.is_cuda and residual.dtype == torch.float32
+                 and tuple(residual.shape) == (N, Cout, Ho, Wo)
+                 and residual.is_contiguous(memory_format=torch.channels_last),
+                 'conv3x3_split: residual [N, Cout, Ho, Wo] channels_last')
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin, (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}')):
         st = lib.pave_conv3x3_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+            residual.data_ptr() if residual is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)),
             PLANES_FP16 if fp16 else int(w_planes.shape[1]), _stream_ptr())
     native.check(st, 'conv3x3_split')

@@ -770,6 +770,56 @@ def test_gemm_bf16x3_cat_two_sources_vs_fp64(M, K1, K2, N):
                                rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 48, 48, 1), (1, 11, 9, 96, 48, 1),
+                                                   (2, 14, 10, 48, 96, 2), (1, 9, 12, 96, 192, 2)])
+def test_conv3x3_split_padded_channels_with_residual_vs_fp64(N, H, W, Cin, Cout, stride):
+    """HRNet's 48- / 96-channel 3x3 convolutions (hrnet.py:183-260: BasicBlock conv + BN + identity
+    + ReLU; fuse-layer stride-2 convolutions) on the exact 3-plane kernel: weight planes zero-padded
+    to Cout % 64 == 0 and 9 Cin % 32 == 0, the real Cout columns stored, identity and ReLU in the
+    epilogue -- against fp64."""
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    g = torch.Generator().manual_seed(Cin * Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin**0.5)
+    b = torch.randn(Cout, generator=g)
+    exp = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    r = torch.randn(exp.shape, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wp = split_conv3x3_weight(w.cuda())
+    y = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout)
+    assert tuple(y.shape) == tuple(exp.shape)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    rd = r.cuda().contiguous(memory_format=torch.channels_last)
+    y = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=True, residual=rd, cout=Cout)
+    np.testing.assert_allclose(y.cpu().numpy(), torch.relu(exp + r.double()).numpy(), rtol=1e-5, atol=2e-5)
+    xn = x.clone()
+    xn[0, 3, 2, 2] = float('nan')     # the zero slab that pads K must not spread a NaN pixel
+    y = conv3x3_split(xn.cuda().contiguous(memory_format=torch.channels_last), wp, None, stride=stride,
+                      cout=Cout)
+    bad = torch.isnan(y[0]).any(0).cpu()
+    expn = torch.isnan(torch.nn.functional.conv2d(xn, w, None, stride, 1)[0]).any(0)
+    assert torch.equal(bad, expn)
+
+
+@pytest.mark.parametrize('M,K,N', [(700, 96, 48), (333, 192, 96), (129, 384, 192), (1000, 64, 36)])
+def test_gemm_bf16x3_padded_output_width_vs_fp64(M, K, N):
+    """Row GEMM with N % 64 != 0 (HRNet fuse-layer 1x1 convolutions 96 -> 48 etc.): planes padded
+    to roundup(N, 64) rows, N columns stored; bias / residual / ReLU have N columns."""
+    from pavenet_amd.ops import gemm_bf16x3, split_weight_bf16x3
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    wp = split_weight_bf16x3(w.cuda(), pad=True)
+    exact = a.double() @ w.double().t() + b.double()
+    out = gemm_bf16x3(a.cuda(), wp, b.cuda(), None, n_out=N)
+    assert tuple(out.shape) == (M, N)
+    np.testing.assert_allclose(out.cpu().numpy(), exact.numpy(), rtol=1e-5, atol=1e-5)
+    out = gemm_bf16x3(a.cuda(), wp, b.cuda(), r.cuda(), relu=True, n_out=N)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.relu(exact + r.double()).numpy(),
+                               rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('form', ['rows', 'rows_n64', 'rows_abias_res', 'ex', 'ln', 'strided', 'conv3x3',
                                   'conv3x3_s2'])
 def test_gemm_generations_are_bit_identical(form):
