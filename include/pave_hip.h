@@ -301,6 +301,20 @@ int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, cons
                              int N, int relu, void* stream);
 
 /*
+ * Grouped row GEMM (3 bf16 planes): the N axis is cut into N / group_n groups; group i computes
+ *   out[:, i group_n : (i + 1) group_n] = act(a[:, i K : (i + 1) K] @ W_i^T + bias_i),
+ * a [M, lda] row-major (lda >= groups * K), W_i [group_n, K]; w_planes = the planes of the [N, K]
+ * row-concatenation of the W_i.  One launch for the T per-frame Linears of one layer of the
+ * reference's per-frame key-point / regression branches (pre_pre_ / pre_ / "" / next_ / next_next_
+ * kpt_branches, opera/models/utils/transformer.py:6728-6740;
+ * third_party/mmdetection/mmdet/models/utils/transformer.py:860-875).
+ * K %% 32 == 0, group_n %% 64 == 0, lda %% 4 == 0.
+ */
+int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_planes, const float* bias,
+                                 float* out, long long M, int K, int N, int group_n, int relu,
+                                 void* stream);
+
+/*
  * out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta  (3 bf16 planes, N == 256): the
  * attention / FFN output Linear, its residual add and the post-norm of a BaseTransformerLayer
  * (third_party/mmcv/mmcv/cnn/bricks/transformer.py:1316-1353) in ONE launch -- a 128 x 256 block

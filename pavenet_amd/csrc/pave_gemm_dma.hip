@@ -114,7 +114,9 @@ __device__ __forceinline__ void dma16_flat(const void* vaddr, unsigned lds_addr)
 
 __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (zero padding)
 
-// KIND: 0 = plain rows A [M, K];  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map;
+// KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
+//           is cut into groups of g.W columns, group i multiplies columns [i K, (i + 1) K) of A by its
+//           own [g.W, K] weight -- T per-frame Linears of one layer as ONE launch);  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map;
 //       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride);
 //       4 = rows [A | A2]: the first g.Cin columns of the K axis come from A [M, g.Cin], the rest
 //           from A2 [M, K - g.Cin] (two GEMMs sharing one accumulator: conv3 + downsample)
@@ -180,7 +182,7 @@ __device__ __forceinline__ void gemm_q_body(
       long long gm = (long long)m0 + r;
       if (gm >= M) gm = M - 1;   // rows past M: stand-in data, never stored
       if (KIND == 0) {
-        a_voff[q] = (unsigned)(((gm - m0) * K + c * 4) * 4);
+        a_voff[q] = (unsigned)(((gm - m0) * (g.H > 0 ? g.H : K) + c * 4) * 4);
       } else if (KIND == 4) {
         a_voff[q] = (unsigned)(((gm - m0) * g.Cin + c * 4) * 4);
         a2_voff[q] = (unsigned)(((gm - m0) * (K - g.Cin) + c * 4) * 4);
@@ -198,7 +200,9 @@ __device__ __forceinline__ void gemm_q_body(
         }
       }
     }
-    if (KIND == 0) a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * K);
+    if (KIND == 0)
+      a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * (g.H > 0 ? g.H : K) +
+                                                      (g.W > 0 ? (long long)(n0 / g.W) * K : 0));
     if (KIND == 4) {
       a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * g.Cin);
       a2_base = reinterpret_cast<const unsigned char*>(A2 + (long long)m0 * (K - g.Cin));
@@ -690,6 +694,8 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
                          int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real) {
   const QConv g{H, W, Cin, Ho, Wo, stride};
+  const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
+  if (narrow) N = -N;
   if (n_real <= 0) n_real = N;
   if (n_real > N || n_real % 4 != 0 || (out2 && n_real != N))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: n_real %% 4 == 0, n_real <= N (== N with two outputs)");
@@ -710,7 +716,7 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
   if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2); \
   return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os)
-  if (N % 128 == 0) { PAVE_QGO(4); }
+  if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO
   return pave_internal_fail(PAVE_E_ARG, "gemm_q: N %% 64 == 0 required");

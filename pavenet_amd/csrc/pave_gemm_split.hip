@@ -702,6 +702,22 @@ int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, cons
                               0, 0, (int)K1, 0, 0, 0, stream, a2);
 }
 
+int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_planes, const float* bias,
+                                 float* out, long long M, int K, int N, int group_n, int relu,
+                                 void* stream) {
+  if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: null pointer");
+  if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0 || group_n <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: bad sizes (0 < M < 2^31)");
+  if (K % 32 != 0 || K < 64 || N % group_n != 0 || group_n % 64 != 0 ||
+      lda < (long long)(N / group_n) * K || lda % 4 != 0 || lda >= (1ll << 24))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: K %% 32 == 0, group_n %% 64 == 0, N %% group_n == 0, "
+                                          "lda >= groups * K, lda %% 4 == 0");
+  // column tiles must not straddle a group: 128-wide tiles need group_n %% 128 == 0
+  const int np = (N % 128 == 0 && group_n % 128 == 0) ? N : -N;
+  return pave_internal_gemm_q(a, nullptr, w_planes, bias, nullptr, 0, out, nullptr, 0, M, K, np, relu, 0,
+                              (int)lda, group_n, 0, 0, 0, 0, stream);
+}
+
 int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
                             const float* residual, const float* gamma, const float* beta, float eps,
                             float* out, long long M, int K, int N, void* stream) {

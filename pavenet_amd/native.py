@@ -35,6 +35,8 @@ SIGNATURES = {
                                + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_cat_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,
                                  _c_int, _vp],
+    'pave_gemm_bf16x3_grouped_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,
+                                     _c_int, _c_int, _vp],
     'pave_gemm_bf16x3_ln_f32': [_vp] * 6 + [ctypes.c_float, _vp, ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_groupnorm_nhwc_f32': [_vp] * 4 + [ctypes.c_longlong] + [_c_int] * 4 + [ctypes.c_float, _vp,
                                 _c_int, _vp, _vp],

@@ -605,6 +605,32 @@ def gemm_bf16x3_cat(a, a2, w_planes, bias=None, residual=None, relu=False, out=N
     return out
 
 
+def gemm_bf16x3_grouped(a, w_planes, bias, group_n, relu=False):
+    """Grouped row GEMM: a [M, G*K] (group i = columns [i K, (i+1) K)), w_planes = planes of the
+    [G*group_n, K] row-concatenated per-group weights -> out [M, G*group_n] with
+    out[:, i*group_n:(i+1)*group_n] = act(a_i @ W_i^T + bias_i).  One launch for G Linears."""
+    lib = native.load()
+    _dev(a, 'a', torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[3] == 16,
+             'gemm_bf16x3_grouped: a [M, G*K], w_planes [K/16, 3, N, 16]')
+    M, lda = a.shape
+    K, N = w_planes.shape[0] * 16, w_planes.shape[2]
+    G = N // int(group_n)
+    _require(G * group_n == N and G * K == lda, 'gemm_bf16x3_grouped: a has G*K columns, N = G*group_n')
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == N, 'gemm_bf16x3_grouped: bias [N]')
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'grouped', f'g{G}')):
+        st = lib.pave_gemm_bf16x3_grouped_f32(a.data_ptr(), lda, w_planes.data_ptr(),
+                                              bias.data_ptr() if bias is not None else None,
+                                              out.data_ptr(), M, K, N, int(group_n), int(bool(relu)),
+                                              _stream_ptr())
+    native.check(st, 'gemm_bf16x3_grouped')
+    return out
+
+
 def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
     """1x1 convolution with a stride on a channels_last map through the 3-plane split GEMM (the A
     rows are the strided input pixels: no slice copy).  x [N, Cin, H, W] channels_last;

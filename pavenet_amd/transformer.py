@@ -89,6 +89,45 @@ def _frame_branches(branches, lid, x, cat_dim):
     lead = x.shape[:-1]
     rows = x.reshape(-1, x.shape[-1])
     R = rows.shape[0]
+    from .bricks import _GEMM, get_gemm_mode
+    dims = [l[0].weight.shape for l in lins]                      # [(out, in)] per layer
+    if (get_gemm_mode() == 'bf16x3' and R >= _GEMM['min_rows'] and rows.is_contiguous()
+            and dims[0][1] % 32 == 0 and dims[0][1] >= 64 and (T * dims[0][0]) % 64 == 0
+            and all(d[1] % 32 == 0 and d[1] >= 64 for d in dims[1:])
+            and all(d[0] % 64 == 0 for d in dims[1:-1]) and dims[-1][0] % 2 == 0):
+        # the exact 3-plane split kernels: ONE GEMM for the T first Linears, then one GROUPED
+        # launch per following layer (group t = frame t's Linear on its own column block)
+        from . import ops
+        gp = m0.__dict__.get('_pave_grouped')
+        if gp is None or gp[0] != key:
+            with torch.no_grad():
+                planes = [ops.split_weight_bf16x3(torch.cat([l.weight for l in lins[0]], 0).contiguous())]
+                biases = [b1]
+                for li, layer in enumerate(lins[1:]):
+                    o = layer[0].weight.shape[0]
+                    op = (o + 63) // 64 * 64          # the last layer (2K outputs) is padded per group
+                    wcat = torch.zeros((T, op, layer[0].weight.shape[1]), device=x.device)
+                    bcat = torch.zeros((T, op), device=x.device)
+                    for t, l in enumerate(layer):
+                        wcat[t, :o] = l.weight
+                        bcat[t, :o] = l.bias
+                    planes.append(ops.split_weight_bf16x3(wcat.flatten(0, 1).contiguous()))
+                    biases.append(bcat.flatten().contiguous())
+            gp = (key, planes, biases)
+            m0.__dict__['_pave_grouped'] = gp
+        _, planes, biases = gp
+        y = ops.gemm_bf16x3(rows, planes[0], biases[0], None, relu=True)          # [R, T*h]
+        for li in range(1, len(lins)):
+            last = li + 1 == len(lins)
+            o = dims[li][0]
+            y = ops.gemm_bf16x3_grouped(y, planes[li], biases[li], (o + 63) // 64 * 64, relu=not last)
+        o = dims[-1][0]
+        y = y.view(R, T, -1)[:, :, :o].permute(1, 0, 2)            # [T, R, out]
+        y = y.reshape((T,) + tuple(lead) + (o,))
+        if cat_dim == 0:
+            return y.reshape((T * lead[0],) + tuple(lead[1:]) + (o,))
+        assert cat_dim == 1
+        return y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], o)
     y = torch._addmm_activation(b1, rows, w1)                    # relu(x W1^T + b1), all frames
     y = y.view(R, T, -1).transpose(0, 1)                          # [T, R, h]
     for li, (w, b) in enumerate(rest):

@@ -820,6 +820,21 @@ def test_gemm_bf16x3_padded_output_width_vs_fp64(M, K, N):
                                rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('M,K,G,gn', [(1200, 512, 7, 512), (300, 256, 3, 64), (77, 64, 5, 128)])
+def test_gemm_bf16x3_grouped_vs_fp64(M, K, G, gn):
+    """pave_gemm_bf16x3_grouped_f32: G per-frame Linears of one layer (OT:6728-6740 kpt_branches) in
+    one launch -- group g multiplies its own column block of a by its own weight -- vs fp64."""
+    from pavenet_amd.ops import gemm_bf16x3_grouped, split_weight_bf16x3
+    g = torch.Generator().manual_seed(M + K + G)
+    a = torch.randn(M, G * K, generator=g)
+    w = torch.randn(G, gn, K, generator=g) / K**0.5
+    b = torch.randn(G, gn, generator=g)
+    wp = split_weight_bf16x3(w.flatten(0, 1).contiguous().cuda())
+    out = gemm_bf16x3_grouped(a.cuda(), wp, b.flatten().cuda(), gn, relu=True)
+    exp = torch.relu(torch.einsum('mgk,gnk->mgn', a.view(M, G, K).double(), w.double()) + b.double())
+    np.testing.assert_allclose(out.cpu().numpy(), exp.reshape(M, G * gn).numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('form', ['rows', 'rows_n64', 'rows_abias_res', 'ex', 'ln', 'strided', 'conv3x3',
                                   'conv3x3_s2'])
 def test_gemm_generations_are_bit_identical(form):
