@@ -84,6 +84,10 @@ int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_
  *   unit_clip  [n_units] int32 clip index of each unit, or NULL => unit / units_per_clip
  *   order      [n_units] int32 permutation giving the processing order of units (XCD/L2
  *              locality), or NULL => identity
+ *   frame_table [n_clips*T] int32, or NULL: the value slab of frame t of clip c is
+ *              frame_table[c*T + t] instead of c*T + t -- `value` is then a per-frame cache
+ *              [n_cached_frames, S, 8, 32] shared by overlapping clips (streaming windows of a video,
+ *              opera/datasets/posetrack_video_pose.py:578-623: no per-window copy / re-projection)
  *   out        [n_units, 256]
  *   stat_max, stat_sum  [n_units, 8] or NULL: per-head max logit and sum(exp(logit-max)) over the
  *              frames this call saw (for merging frame-sharded partial results)
@@ -99,13 +103,15 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const float* ref, const int32_t* unit_clip,
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
-                                    int T, int S, int L, int P, int proj_stride, void* stream);
+                                    int T, int S, int L, int P, int proj_stride,
+                                    const int32_t* frame_table, void* stream);
 
 int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start, const float* proj,
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
-                                    int K, int proj_stride, void* stream);
+                                    int K, int proj_stride, const int32_t* frame_table,
+                                    void* stream);
 
 /*
  * Greedy OKS-NMS, one launch for n_clips clips (replaces oks_nms / oks_iou,

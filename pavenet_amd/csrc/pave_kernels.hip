@@ -228,6 +228,7 @@ struct FusedParams {
   const float* ref;
   const int32_t* unit_clip;
   const int32_t* order;
+  const int32_t* frame_table;  // slab of (clip, t) = frame_table[clip * T + t] (NULL: clip * T + t)
   float* out;
   float* stat_max;
   float* stat_sum;
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParam
     const int lp0 = (MODE == kGrid) ? 0 : lvl * P;
     const float* lg = logit_row + (t * kHeads + h) * LP + lp0;
     const float* of = off_row + ((long long)(t * kHeads + h) * LP + lp0) * 2;
+    const int slab = p.frame_table ? p.frame_table[clip * T + t] : clip * T + t;
     const char* frame = reinterpret_cast<const char*>(p.value) +
-                        (long long)(clip * T + t) * p.S * rowbytes + j * 16;
+                        (long long)slab * p.S * rowbytes + j * 16;
 
     float rx[PPL], ry[PPL];
     float whx = 0.f, why = 0.f;
@@ -1471,7 +1473,8 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const float* ref, const int32_t* unit_clip,
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
-                                    int T, int S, int L, int P, int proj_stride, void* stream) {
+                                    int T, int S, int L, int P, int proj_stride,
+                                    const int32_t* frame_table, void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_grid_fused: null pointer");
   if (n_units <= 0 || T <= 0 || S <= 0 || n_clips <= 0 || units_per_clip <= 0)
@@ -1494,6 +1497,7 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
   p.ref = ref;
   p.unit_clip = unit_clip;
   p.order = order;
+  p.frame_table = frame_table;
   p.out = out;
   p.stat_max = stat_max;
   p.stat_sum = stat_sum;
@@ -1520,7 +1524,8 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     const int64_t* level_start, const float* proj,
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
-                                    int K, int proj_stride, void* stream) {
+                                    int K, int proj_stride, const int32_t* frame_table,
+                                    void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_pose_fused: null pointer");
   if (n_clips <= 0 || Q <= 0 || T <= 0 || S <= 0 || K <= 0)
@@ -1541,6 +1546,7 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
   p.ref = ref;
   p.unit_clip = nullptr;
   p.order = nullptr;
+  p.frame_table = frame_table;
   p.out = out;
   p.stat_max = stat_max;
   p.stat_sum = stat_sum;

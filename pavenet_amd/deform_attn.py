@@ -399,7 +399,10 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
             idt = inp_residual if self.batch_first else batch_first(inp_residual)
             out = linear_residual_norm(out, self.output_proj, idt, post_norm)
             return out if self.batch_first else seq_first_view(out)
-        assert v.shape[0] == bs * T, 'value must hold num_frames slabs per clip'
+        # streaming: `v` is a per-frame cache of projected values and frame t of clip b is slab
+        # table[b * T + t] (pavenet_amd/streaming.py) -- no per-window copy or re-projection
+        table = kwargs.get('value_frame_table')
+        assert table is not None or v.shape[0] == bs * T, 'value must hold num_frames slabs per clip'
         w, b = self._cat_proj()
         proj = linear_rows(q.reshape(bs * num_query, self.embed_dims), w, b)
         if _fused_ok(self, q, v) and L <= 4 and K <= 24:
@@ -409,11 +412,13 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
             res = ops.deform_attn_pose_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
                 proj, ref, T=T, n_clips=bs, num_query=num_query, num_keypoints=K,
-                return_stats=stats)
+                return_stats=stats, frame_table=table)
             if stats:  # frame-sharded multi-GPU: caller merges partial rows, then projects
                 return res
             out = res.view(bs, num_query, self.embed_dims)
         else:
+            if table is not None:
+                v = v[table.long()]
             out = self._unfused(v, proj, reference_points, spatial_shapes, level_start_index, bs,
                                 num_query)
         idt = inp_residual if self.batch_first else batch_first(inp_residual)
@@ -596,9 +601,10 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         projected = kwargs.get('value_projected')
         shard = kwargs.get('frame_shard')
         Tv = T if shard is None else max(shard.n_local, 1)  # frames present in `value`
+        table = kwargs.get('value_frame_table')   # streaming: per-frame cache + frame table
         if projected is not None:
             v = projected
-            n_clips = v.shape[0] // Tv
+            n_clips = (v.shape[0] if table is None else table.numel()) // Tv
             if clip_index is None:
                 assert n_clips == 1 or n_clips == N
                 clip_index = torch.arange(N, device=q.device) if n_clips == N and N > 1 else \
@@ -652,9 +658,11 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
             out = ops.deform_attn_grid_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
                 proj, ref if ref.is_contiguous() else ref.contiguous(), T=T, n_clips=n_clips,
-                units_per_clip=num_query, unit_clip=unit_clip)
+                units_per_clip=num_query, unit_clip=unit_clip, frame_table=table)
             out = out.view(N, num_query, self.embed_dims)
         else:
+            if table is not None:
+                v = v[table.long()]
             out = self._unfused(v, proj, ref, clip_index, spatial_shapes, level_start_index, N,
                                 num_query)
         idt = identity if self.batch_first else batch_first(identity)

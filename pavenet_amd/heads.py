@@ -250,6 +250,7 @@ class VideoPoseHeadMulFrames(BaseModule):
         T, Q = self.num_frames, self.num_query
         c = T // 2
         shard = tr_kwargs.get('frame_shard')
+        refine_value_cache = tr_kwargs.pop('refine_value_cache', None)   # streaming (see forward_refine)
         pre = tr_kwargs.pop('precomputed', None)
         if pre is not None:  # streaming: encoder memory comes from the per-frame cache
             mlvl_masks, mlvl_pos, has_padding, tr_kwargs['encoded'] = pre
@@ -295,12 +296,12 @@ class VideoPoseHeadMulFrames(BaseModule):
                     enc_cls_scores=enc_outputs_class, enc_kpt_preds=enc_outputs_kpt.sigmoid(),
                     enc_sigma_preds=enc_outputs_sigma.sigmoid(), memory=memory,
                     mlvl_masks=mlvl_masks, has_padding=has_padding, aux_poses=aux_poses,
-                    frame_shard=shard,
+                    frame_shard=shard, refine_value_cache=refine_value_cache,
                     hs=hs, init_reference=init_reference, inter_references=inter_references)
 
     # HEAD:569-674 (inference branch) ----------------------------------------
     def forward_refine(self, memory, mlvl_masks, frame_poses, img_inds, has_padding=True,
-                       frame_shard=None):
+                       frame_shard=None, value_cache=None):
         """frame_poses: list of T tensors [Ntot, 2K] (centre = selected kpt preds).
         Returns (kpts [Ntot, K, 2] normalised, score [Ntot, K, 1], sigma [Ntot, K, 2]) of the last
         refine layer plus all intermediates."""
@@ -310,10 +311,13 @@ class VideoPoseHeadMulFrames(BaseModule):
         S = memory.size(0)
         Tl = T if frame_shard is None else frame_shard.n_local
         mem4 = memory.reshape(S, -1, Tl, memory.size(-1))  # [S, B, T(_loc), C] view
+        extra = {}
+        if value_cache is not None:   # streaming: (per-layer projected-value caches, frame table)
+            extra = dict(values_projected=value_cache[0], value_frame_table=value_cache[1])
         hs, init_reference, inter_references = self.transformer.forward_refine(
             mlvl_masks, mem4, pos_kpt_preds.detach(), img_inds,
             frame_kpt_branches=self._branches('refine_kpt_branches'), has_padding=has_padding,
-            frame_shard=frame_shard)
+            frame_shard=frame_shard, **extra)
         hs = hs.permute(0, 2, 1, 3)
         outs_kpt, outs_sigma, outs_score = [], [], []
         for lvl in range(hs.shape[0]):
@@ -392,7 +396,8 @@ class VideoPoseHeadMulFrames(BaseModule):
         img_inds = torch.arange(B, device=cls_scores.device).repeat_interleave(N)
         r_kpts, r_scores, r_sigmas, r_hs = self.forward_refine(
             outs['memory'], outs['mlvl_masks'], frame_poses, img_inds,
-            has_padding=outs['has_padding'], frame_shard=outs.get('frame_shard'))
+            has_padding=outs['has_padding'], frame_shard=outs.get('frame_shard'),
+            value_cache=outs.get('refine_value_cache'))
         det_kpts = r_kpts[-1].view(B, N, K, 2)
         det_sigmas = r_sigmas[-1].view(B, N, K, 2)
         if taps is not None:

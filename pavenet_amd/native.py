@@ -17,8 +17,8 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     'pave_ms_deform_attn_forward_f32': [_vp] * 6 + [_c_int] * 8 + [_vp],
     'pave_ms_deform_attn_forward_f64': [_vp] * 6 + [_c_int] * 8 + [_vp],
-    'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp],
-    'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp],
+    'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp, _vp],
+    'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp, _vp],
     'pave_bias_act_rows_f32': [_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_bias_add_layernorm_f32': [_vp] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _vp],
     'pave_bias_add_layernorm_pos_f32': [_vp] * 7 + [ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int,

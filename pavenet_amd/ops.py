@@ -163,7 +163,7 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
 
 def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,
                            n_clips, units_per_clip, unit_clip=None, order=None,
-                           return_stats=False):
+                           return_stats=False, frame_table=None):
     """Fused grid-offset deformable attention over T frames ([R2] with T=1, [R4]).
 
     value [n_clips*T, S, 8, 32]; proj [n_units, >= T*8*16*3]; ref [T, n_units, 4, 2]
@@ -173,6 +173,7 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     if torch.is_grad_enabled() and not return_stats and \
             (value.requires_grad or proj.requires_grad or ref.requires_grad):
         from .fused_autograd import GridFusedFunction
+        _require(frame_table is None, 'deform_attn_grid_fused: frame_table is an inference-only option')
         return GridFusedFunction.apply(value, spatial_shapes, level_start_index, proj, ref, T,
                                        n_clips, units_per_clip, unit_clip, order)
     lib = native.load()
@@ -184,7 +185,11 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _dev(ref, 'ref', f32)
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_grid_fused: value must be [frames, S, 8, 32]')
-    _require(value.shape[0] == n_clips * T, 'deform_attn_grid_fused: value frames != n_clips*T')
+    if frame_table is not None:   # value = per-frame cache, slab of (clip, t) = frame_table[clip*T + t]
+        _dev(frame_table, 'frame_table', torch.int32)
+        _require(frame_table.numel() == n_clips * T, 'deform_attn_grid_fused: frame_table [n_clips*T]')
+    else:
+        _require(value.shape[0] == n_clips * T, 'deform_attn_grid_fused: value frames != n_clips*T')
     S = value.shape[1]
     L = spatial_shapes.shape[0]
     _require(proj.dim() == 2, 'deform_attn_grid_fused: proj must be 2-D')
@@ -211,7 +216,8 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
             order.data_ptr() if order is not None else None, out.data_ptr(),
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, n_units, int(units_per_clip),
-            int(n_clips), int(T), S, L, 4, proj.stride(0), _stream_ptr())
+            int(n_clips), int(T), S, L, 4, proj.stride(0),
+            frame_table.data_ptr() if frame_table is not None else None, _stream_ptr())
     native.check(st, 'deform_attn_grid_fused')
     if return_stats:
         return out, smax, ssum
@@ -219,7 +225,7 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
 
 
 def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,
-                           n_clips, num_query, num_keypoints, return_stats=False):
+                           n_clips, num_query, num_keypoints, return_stats=False, frame_table=None):
     """Fused pose-aware deformable attention over T frames ([R3]).
 
     value [n_clips*T, S, 8, 32]; proj [n_clips*Q, >= T*8*L*K*3];
@@ -229,6 +235,7 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     if torch.is_grad_enabled() and not return_stats and \
             (value.requires_grad or proj.requires_grad or ref.requires_grad):
         from .fused_autograd import PoseFusedFunction
+        _require(frame_table is None, 'deform_attn_pose_fused: frame_table is an inference-only option')
         return PoseFusedFunction.apply(value, spatial_shapes, level_start_index, proj, ref, T,
                                        n_clips, int(num_query), int(num_keypoints))
     lib = native.load()
@@ -240,7 +247,11 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _dev(ref, 'ref', f32)
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_pose_fused: value must be [frames, S, 8, 32]')
-    _require(value.shape[0] == n_clips * T, 'deform_attn_pose_fused: value frames != n_clips*T')
+    if frame_table is not None:
+        _dev(frame_table, 'frame_table', torch.int32)
+        _require(frame_table.numel() == n_clips * T, 'deform_attn_pose_fused: frame_table [n_clips*T]')
+    else:
+        _require(value.shape[0] == n_clips * T, 'deform_attn_pose_fused: value frames != n_clips*T')
     S = value.shape[1]
     L = spatial_shapes.shape[0]
     Q, K = int(num_query), int(num_keypoints)
@@ -259,7 +270,8 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
             proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, int(n_clips), Q, int(T), S, L, K,
-            proj.stride(0), _stream_ptr())
+            proj.stride(0), frame_table.data_ptr() if frame_table is not None else None,
+            _stream_ptr())
     native.check(st, 'deform_attn_pose_fused')
     if return_stats:
         return out, smax, ssum

@@ -647,7 +647,11 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_kpt_branches'] = branches
         if frame_shard is not None:
             dec_kwargs['frame_shard'] = frame_shard
-        if self.hoist_value_proj and all(
+        cached = kwargs.pop('values_projected', None)   # streaming: per-frame caches + frame table
+        if cached is not None:
+            dec_kwargs['values_projected'] = cached
+            dec_kwargs['value_frame_table'] = kwargs.pop('value_frame_table')
+        elif self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
                 for l in self.decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(
@@ -707,7 +711,11 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_shard'] = frame_shard
         mem_bt = memory.permute(1, 2, 0, 3)                                   # [B, T, S, C]
         attn_mask = mask_bt if has_padding else None
-        if self.hoist_value_proj and all(
+        cached = kwargs.pop('values_projected', None)   # streaming: per-frame caches + frame table
+        if cached is not None:
+            dec_kwargs['values_projected'] = cached
+            dec_kwargs['value_frame_table'] = kwargs.pop('value_frame_table')
+        elif self.hoist_value_proj and all(
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformableAttention)
                 for l in self.refine_decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(

@@ -75,7 +75,7 @@ def test_capi_argument_errors():
     st = lib.pave_ms_deform_attn_forward_f32(p, p, p, p, p, p, 3, 1, 1, 4, 1, 1, 1, 2, None)
     assert st == -3  # batch 3 not divisible by im2col_step 2 (ms_deform_attn_cuda.cu:242-245)
     st = lib.pave_deform_attn_grid_fused_f32(p, p, p, p, p, None, None, p, None, None, 4, 4, 1, 1,
-                                             10, 3, 4, 384, None)
+                                             10, 3, 4, 384, None, None)
     assert st == -1 and b'L = 4' in lib.pave_last_error()
 
 

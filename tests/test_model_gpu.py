@@ -912,27 +912,32 @@ def test_simple_test_rescale_result_lists_vs_reference_golden(golden_dir):
     assert eb[0].shape == (0, 5) and ek[0].shape == (0, 15, 3)
 
 
-def test_streaming_windows_vs_oracle():
+@pytest.mark.parametrize('padded', [True, False])
+def test_streaming_windows_vs_oracle(padded):
     """f2 against the ORACLE (not the product's own per-window path): two windows of a 4-frame
     video decoded from the per-frame encoder-memory cache -- the edge-replicated first window
     [0, 0, 1] and an interior one [1, 2, 3] -- equal `oracle.videopose_simple_test` on the clips
-    built by the reference dataset's window rule (posetrack_video_pose.py:578-623)."""
+    built by the reference dataset's window rule (posetrack_video_pose.py:578-623).  Un-padded
+    frames also take the per-frame PROJECTED-VALUE cache of the five decoder layers, addressed by
+    the fused kernels through a frame table (no per-window re-projection)."""
     from pavenet_amd.streaming import VideoPoseStream
     N = 12
     m = _build(3, N)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    meta = dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3), scale_factor=(1., 1., 1., 1.))
+    ishape = (120, 150, 3) if padded else (128, 160, 3)
+    meta = dict(batch_input_shape=(128, 160), img_shape=ishape, scale_factor=(1., 1., 1., 1.))
     video = _t(seeded_array('stream.oracle.video', (4, 3, 128, 160)))
     stream = VideoPoseStream(m, meta, encode_chunk=3, decode_chunk=2)
     wins = stream.window_indices(4, 3)
     assert wins[0] == [0, 0, 1] and wins[2] == [1, 2, 3]
     slabs = stream.encode(video.cuda())
+    assert (stream._vcache is None) == padded
     cfg = dict(num_frames=3, num_keypoints=15, num_query=300, max_per_img=N)
     for c in (0, 2):
         taps = {}
         with torch.no_grad():
             eb, el, ek = R.videopose_simple_test(sd, cfg, video[wins[c]][None],
-                                                 img_shape=(120, 150, 3), taps=taps)
+                                                 img_shape=ishape, taps=taps)
         _close(torch.stack([slabs[i] for i in wins[c]]).cpu().numpy(),
                                    taps['memory'].numpy(), rtol=2e-3, atol=5e-4)
         res = stream.decode(slabs, [wins[c]], force_topk_proposals=taps['topk_idx'].cuda(),

@@ -1,6 +1,6 @@
 """Whole-video inference with the per-frame encoder-memory cache at full size:
 every frame of an N-frame 800x1344 video gets its T-frame window result; frames/s against
-running simple_test on every window.   python tools/bench_streaming.py [n_frames=28] [T=7] [gemm=bf16x3]"""
+running simple_test on every window.   python tools/bench_streaming.py [n_frames=28] [T=7] [gemm=bf16x3] [decode_chunk=14]"""
 import os
 import sys
 import time
@@ -24,7 +24,8 @@ def main():
     m = m.cuda().eval()
     meta = dict(batch_input_shape=(800, 1344), img_shape=(800, 1344, 3), scale_factor=(1., 1., 1., 1.))
     video = torch.randn(n, 3, 800, 1344, device='cuda')
-    stream = VideoPoseStream(m, meta, encode_chunk=14, decode_chunk=4)
+    dchunk = int(sys.argv[4]) if len(sys.argv) > 4 else 14
+    stream = VideoPoseStream(m, meta, encode_chunk=14, decode_chunk=dchunk)
     for _ in range(2):
         out = stream.infer_video(video)
     torch.cuda.synchronize()
