@@ -25,7 +25,11 @@
 // (A persistent form -- 2 blocks per CU walking an XCD-local tile list, the next tile's first three
 // slabs issued before the epilogue -- was built and measured 7-10 % SLOWER on every shape: the tile
 // loop costs 40 more VGPRs (spills around the epilogue) and, vmcnt being one in-order counter, the
-// next tile's first wait also drains the epilogue's stores.  One tile per block stays.)
+// next tile's first wait also drains the epilogue's stores.  One tile per block stays.
+// A v_mfma_f32_16x16x32_bf16 form (32-k stages, ring of 2, W fragments read quarter by quarter,
+// one barrier per 32 k) was built too: a timing-only swap of the MFMA shape had shown +4-5 %
+// (higher clock at equal pipe cycles), the real kernel ran equal at K >= 512 and 13 % slower at
+// K = 256 (224 live VGPRs, spills in the tail steps, a two-stage prologue).  Dropped.)
 // The DMA instructions are inline assembly (the compiler's wait-count pass would otherwise fence
 // every LDS read behind the youngest DMA); every wait on them is an explicit vmcnt here.  LDS
 // reads stay ordinary loads, so their lgkmcnt waits are the compiler's.  Results are bit-identical

@@ -80,7 +80,7 @@ def main():
         out = torch.empty(n, Ho, Wo, Cout, device=dev)
 
         def make(lib):
-            return lambda: lib.pave_conv3x3_split_f32(x.data_ptr(), wp.data_ptr(), bias.data_ptr(),
+            return lambda: lib.pave_conv3x3_split_f32(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), None,
                                                       out.data_ptr(), n, H, W, Cin, Cout, stride, 1, 3, st)
         cases.append((label, 2.0 * n * Ho * Wo * Cout * 9 * Cin, make, out))
 
