@@ -119,7 +119,9 @@ def spawn_ranks(args):
         print(f'bench.py: the {args.gpus}-rank child did not finish within {limit:.0f} s; killed',
               file=sys.stderr)
         return 124
-    sys.stdout.write(out or '')
+    # rank 0's JSON line goes to stdout, anything else the launcher or the ranks printed to stderr
+    for ln in (out or '').splitlines():
+        print(ln, file=sys.stdout if ln.startswith('{') else sys.stderr)
     sys.stdout.flush()
     if proc.returncode != 0:
         print(f'bench.py: the {args.gpus}-rank child exited with code {proc.returncode}', file=sys.stderr)

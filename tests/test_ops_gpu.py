@@ -214,7 +214,7 @@ def test_grid_fused_T1_unaligned_rows_take_the_per_query_kernel():
     out = torch.empty(U, 256, device='cuda')
     st = lib.pave_deform_attn_grid_fused_f32(
         vd.data_ptr(), sd.data_ptr(), ld.data_ptr(), pd.data_ptr(), rd.data_ptr(), None, None,
-        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride,
+        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride, None,
         torch.cuda.current_stream().cuda_stream)
     native.check(st, 'grid_fused (unaligned rows)')
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
