@@ -18,10 +18,8 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob('$R/gpurun_out/$OUT/p*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        if 'gemm_bf16x3' in r['Kernel_Name']:
+        if 'gemm_bf16x3' in r['Kernel_Name'] or 'gemm_q_' in r['Kernel_Name']:
             agg[r.get('Grid_Size', '?')][r['Counter_Name']].append(float(r['Counter_Value']))
-alg = {'10002432': ('FFN1 625044x256x1024', 0.640 + 0.0016, 2.560), '2500608': ('FFN2 625044x1024x256', 2.560 + 0.0016, 0.640),
-       '2500608b': None}
 for grid, d in agg.items():
     rd = sum(sorted(d['FETCH_SIZE'])[1:-1]) / max(1, len(d['FETCH_SIZE']) - 2) * 1024 * 2 / 1e9 if d.get('FETCH_SIZE') else float('nan')
     wr = sum(sorted(d['WRITE_SIZE'])[1:-1]) / max(1, len(d['WRITE_SIZE']) - 2) * 1024 / 1e9 if d.get('WRITE_SIZE') else float('nan')
