@@ -245,6 +245,17 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
         out = residual if (residual is not None and inplace_residual) else None
         return ops.gemm_bf16x3(x2, _split_weight(weight), bias, residual, relu=relu, out=out,
                                a_bias=a_bias, fp16=_GEMM['mode'] == 'fp16')
+    if (_GEMM['mode'] == 'bf16x3' and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2
+            and x2.is_contiguous() and a_bias is None and not torch.is_grad_enabled()
+            and weight.shape[1] % 32 == 0 and weight.shape[1] >= 64 and weight.shape[0] % 4 == 0
+            and x2.shape[0] >= min(_GEMM['min_rows'], 1024) and weight.shape[0] >= 4096):
+        # wide projections of the decoders (a few hundred query rows x ~10^4 offset / logit
+        # columns, OT:1722-1734): the 3-plane kernel with planes zero-padded to N % 64 == 0
+        from . import ops
+        wp = _split_cached(weight, 'gemm_pad', lambda planes: ops.split_weight_bf16x3(
+            weight.detach().contiguous(), planes, pad=True))
+        out = residual if (residual is not None and inplace_residual) else None
+        return ops.gemm_bf16x3(x2, wp, bias, residual, relu=relu, out=out, n_out=weight.shape[0])
     if a_bias is not None:
         x2 = torch.relu(x2 + a_bias)
     if residual is not None:

@@ -91,7 +91,8 @@ def _frame_branches(branches, lid, x, cat_dim):
     R = rows.shape[0]
     from .bricks import _GEMM, get_gemm_mode
     dims = [l[0].weight.shape for l in lins]                      # [(out, in)] per layer
-    if (get_gemm_mode() == 'bf16x3' and R >= _GEMM['min_rows'] and rows.is_contiguous()
+    # (T Linears per launch: worth it from a few thousand frame-rows on; tests force min_rows = 1)
+    if (get_gemm_mode() == 'bf16x3' and R * T >= min(_GEMM['min_rows'], 4096) and rows.is_contiguous()
             and dims[0][1] % 32 == 0 and dims[0][1] >= 64 and (T * dims[0][0]) % 64 == 0
             and all(d[1] % 32 == 0 and d[1] >= 64 for d in dims[1:])
             and all(d[0] % 64 == 0 for d in dims[1:-1]) and dims[-1][0] % 2 == 0):
