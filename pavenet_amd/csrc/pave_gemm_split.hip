@@ -791,7 +791,8 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: tensor too large");
-  if (g_diag_variant != 9)
+  // (the LDS-DMA kernel addresses the strided pixels with 32-bit byte offsets from x)
+  if (g_diag_variant != 9 && (long long)N * H * W * Cin * 4 < (1ll << 32))
     return pave_internal_gemm_q(x, nullptr, w_planes, bias, nullptr, 0, y, nullptr, 0, M, Cin, Cout, relu,
                                 3, H, W, Cin, Ho, Wo, stride, stream);
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};
