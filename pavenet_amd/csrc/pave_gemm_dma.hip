@@ -124,7 +124,15 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 //       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride);
 //       4 = rows [A | A2]: the first g.Cin columns of the K axis come from A [M, g.Cin], the rest
 //           from A2 [M, K - g.Cin] (two GEMMs sharing one accumulator: conv3 + downsample)
-template <int TN, int WN, int KIND, bool ABIAS, bool LNORM>
+// WIDE (TN = 8, WN = 1): the wave owns 32 rows x 256 columns -- one split of the A rows and one A
+// DMA feed 48 MFMAs instead of 24.  The 128 accumulator registers leave room for only a QUARTER
+// of a slab's W fragments (2 column tiles x 3 planes) twice over, so the fragments are read
+// quarter by quarter just ahead of their MFMAs, the ring has 2 stages (2 x 32 KiB: two blocks per
+// CU) and the barrier sits between the third and the fourth quarter: by then every fragment of
+// the slab is in registers, its stage takes the DMA of slab s + 2 (one slab = 48 MFMAs per wave of
+// latency cover), and the fourth quarter's MFMAs run over the reads and the split of slab s + 1.
+// Per accumulator the products keep the order of the narrow form: results are bit-identical.
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -141,8 +149,11 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int QMAX = (NDI + NWAVE - 1) / NWAVE;   // per wave and slab: at most / at least
   constexpr int QMIN = NDI / NWAVE;
   constexpr int QA = (NA + NWAVE - 1) / NWAVE;      // A instructions per wave: 2 (WN 1) | 1 (WN 2)
+  constexpr int NS = WIDE ? 2 : QNS;                // ring stages
   constexpr int EPI_OFF = 0;                        // per-wave epilogue chunks reuse the ring
-  constexpr int STAT_OFF = QNS * STAGE;             // LayerNorm row statistics
+  constexpr int STAT_OFF = NS * STAGE;              // LayerNorm row statistics (WN > 1)
+  constexpr int TQ = WIDE ? 2 : TN;                 // column tiles per W fragment set
+  static_assert(!WIDE || (TN == 8 && WN == 1 && !ABIAS && !LNORM), "wide form: 32 x 256 per wave");
   constexpr int ABOFF = STAT_OFF + (LNORM ? 2 * QBM * WN * 4 : 0);   // a_bias vector
   static_assert(NA % NWAVE == 0, "A DMA instructions divide evenly over the waves");
   static_assert(!LNORM || KIND == 0, "LayerNorm epilogue: plain row GEMM only");
@@ -259,18 +270,27 @@ __device__ __forceinline__ void gemm_q_body(
   f32x16 acc[TN];
   f32x4 raw[2];            // the lane's 8 fp32 of the next slab
   u32x4 apl[2][3];         // A planes: [set][plane]
-  u32x4 wf[2][3][TN];      // W fragments: [set][plane][column tile]
+  u32x4 wf[2][3][TQ];      // W fragments: [set][plane][column tile (of the quarter, WIDE)]
   const float* const ab_lds = reinterpret_cast<const float*>(smem + ABOFF);
 
-  auto read_frags = [&](const int stage, const int set) {
+  auto read_raw = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE;
     raw[0] = *reinterpret_cast<const f32x4*>(st + a_rd0);
     raw[1] = *reinterpret_cast<const f32x4*>(st + a_rd1);
+  };
+  // column tiles [TQ quarter, TQ quarter + TQ) of the stage's W planes
+  auto read_wq = [&](const int stage, const int quarter, const int set) {
+    const unsigned char* st = smem + stage * STAGE;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        wf[set][p][j] = *reinterpret_cast<const u32x4*>(st + w_rd + (p * BN + j * 32) * 32);
+      for (int j = 0; j < TQ; ++j)
+        wf[set][p][j] =
+            *reinterpret_cast<const u32x4*>(st + w_rd + (p * BN + (quarter * TQ + j) * 32) * 32);
+  };
+  auto read_frags = [&](const int stage, const int set) {
+    read_raw(stage);
+    read_wq(stage, 0, set);
   };
   auto split_raw = [&](const int slab, const int set) {
     f32x4 lo = raw[0], hi = raw[1];
@@ -290,25 +310,39 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int pa = 0; pa <= o; ++pa)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+      for (int j = 0; j < TQ; ++j) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             __builtin_bit_cast(bf16x8, apl[set][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
             acc[j], 0, 0, 0);
       }
   };
+  // WIDE: all six products of one quarter (A planes of set aset, W fragments of set wset)
+  auto mma_q = [&](const int aset, const int wset, const int quarter) {
+#pragma unroll
+    for (int o = 2; o >= 0; --o)
+#pragma unroll
+      for (int pa = 0; pa <= o; ++pa)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          acc[quarter * TQ + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, apl[aset][pa]),
+              __builtin_bit_cast(bf16x8, wf[wset][o - pa][j]), acc[quarter * TQ + j], 0, 0, 0);
+        }
+  };
 
   // ---- epilogue state
   constexpr int NPS = 4;                 // passes per accumulator tile: 8 rows x 8 float4 each
   const int erow = lane >> 3, ec4 = lane & 7;
-  float4 resv[TN][NPS];
-  auto prefetch_residual = [&](const int em0, const int en0) {
-    if (!residual) return;
-    // row-periodic table (row m adds residual[m % res_rows]): one modulo per lane and tile, the
-    // passes step the row by 8 with a wrap (res_rows >= 32: at most one wrap per step)
+  constexpr int RB = WIDE ? 4 : TN;      // residual tiles in registers (WIDE: four, rotating)
+  float4 resv[RB][NPS];
+  long long rrow[NPS];                   // residual row of the lane per pass
+  auto residual_rows = [&](const int em0) {
+    // row-periodic table (row m adds residual[m % res_rows]): one modulo per lane, the passes
+    // step the row by 8 with a wrap (res_rows >= 32: at most one wrap per step)
     const long long gm0 = (long long)em0 + wm * 32 + erow;
     const bool table = os.res_rows != 0;
     const bool stepwise = os.res_rows >= 32;
-    long long rbase = table ? (long long)((unsigned)gm0 % (unsigned)os.res_rows) : gm0;
+    const long long rbase = table ? (long long)((unsigned)gm0 % (unsigned)os.res_rows) : gm0;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       const long long gm = gm0 + ps * 8;
@@ -321,39 +355,48 @@ __device__ __forceinline__ void gemm_q_body(
           rr = (long long)((unsigned)gm % (unsigned)os.res_rows);
         }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-        resv[j][ps] = (gm < M && ncol < os.n_real)
-                          ? *reinterpret_cast<const float4*>(residual + rr * os.n_real + ncol)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      rrow[ps] = gm < M ? rr : -1;
     }
+  };
+  auto prefetch_residual_tile = [&](const int en0, const int j, const int buf) {
+    const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps)
+      resv[buf][ps] = (rrow[ps] >= 0 && ncol < os.n_real)
+                          ? *reinterpret_cast<const float4*>(residual + rrow[ps] * os.n_real + ncol)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto prefetch_residual = [&](const int em0, const int en0) {
+    if (!residual) return;
+    residual_rows(em0);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) prefetch_residual_tile(en0, j, j);
   };
 
   if (ABIAS) {
     float* ab = reinterpret_cast<float*>(smem + ABOFF);
     for (int i = tid; i < K; i += 64 * NWAVE) ab[i] = a_bias[i];
   }
-  // ---- three slabs in flight
   setup_tile(blockIdx.x);
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
   {
     const int em0 = m0, en0 = n0;
+    if constexpr (!WIDE) {
+      // ---- three slabs in flight
+      issue(0, 0);
+      issue(1, 1);
+      issue(2, 2);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    PAVE_QWAIT(2 * QMIN);                  // slab 0 has landed everywhere
-    read_frags(0, 0);
-    split_raw(0, 0);
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      PAVE_QWAIT(2 * QMIN);                  // slab 0 has landed everywhere
+      read_frags(0, 0);
+      split_raw(0, 0);
 
-    // ---- main loop, 6 slabs per trip (ring stage = slab % 3, register set = slab & 1).  FULL
-    // steps (no slab-count tests: one basic block, so the split of slab s + 1 is scheduled between
-    // the MFMAs of slab s) run while three more slabs follow; the guarded form runs up to the
-    // last slab but one.  nslabs is even, so the last slab's operands sit in register set 1.
+      // ---- main loop, 6 slabs per trip (ring stage = slab % 3, register set = slab & 1).  FULL
+      // steps (no slab-count tests: one basic block, so the split of slab s + 1 is scheduled
+      // between the MFMAs of slab s) run while three more slabs follow; the guarded form runs up
+      // to the last slab but one.  nslabs is even, so the last slab's operands sit in set 1.
 #define PAVE_QSTEP(I, FULL)                                                    \
   if (FULL || s + I < nslabs - 1) {                                            \
     constexpr int cur = (I) & 1, nxt = cur ^ 1;                                \
@@ -367,31 +410,80 @@ __device__ __forceinline__ void gemm_q_body(
     mma(cur, 1);                                                               \
     mma(cur, 0);                                                               \
   }
-    int s = 0;
-    for (; s + 9 <= nslabs; s += 6) {
-      PAVE_QSTEP(0, true)
-      PAVE_QSTEP(1, true)
-      PAVE_QSTEP(2, true)
-      PAVE_QSTEP(3, true)
-      PAVE_QSTEP(4, true)
-      PAVE_QSTEP(5, true)
-    }
-    for (; s < nslabs - 1; s += 6) {
-      PAVE_QSTEP(0, false)
-      PAVE_QSTEP(1, false)
-      PAVE_QSTEP(2, false)
-      PAVE_QSTEP(3, false)
-      PAVE_QSTEP(4, false)
-      PAVE_QSTEP(5, false)
-    }
-    // ---- last slab: every wave has read the last stage (the epilogue reuses the ring); the
-    // residual rows are fetched under the last MFMAs
-    PAVE_QWAIT(0);
-    prefetch_residual(em0, en0);
-    mma(1, 2);
-    mma(1, 1);
-    mma(1, 0);
+      int s = 0;
+      for (; s + 9 <= nslabs; s += 6) {
+        PAVE_QSTEP(0, true)
+        PAVE_QSTEP(1, true)
+        PAVE_QSTEP(2, true)
+        PAVE_QSTEP(3, true)
+        PAVE_QSTEP(4, true)
+        PAVE_QSTEP(5, true)
+      }
+      for (; s < nslabs - 1; s += 6) {
+        PAVE_QSTEP(0, false)
+        PAVE_QSTEP(1, false)
+        PAVE_QSTEP(2, false)
+        PAVE_QSTEP(3, false)
+        PAVE_QSTEP(4, false)
+        PAVE_QSTEP(5, false)
+      }
+      // ---- last slab: every wave has read the last stage (the epilogue reuses the ring); the
+      // residual rows are fetched under the last MFMAs
+      PAVE_QWAIT(0);
+      prefetch_residual(em0, en0);
+      mma(1, 2);
+      mma(1, 1);
+      mma(1, 0);
 #undef PAVE_QSTEP
+    } else {
+      // ---- two slabs in flight
+      issue(0, 0);
+      issue(1, 1);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      PAVE_QWAIT(QMIN);                      // slab 0 has landed everywhere
+      read_frags(0, 0);
+      split_raw(0, 0);
+      // ---- one slab: quarters 0..2 from the stage (stage = A plane set = slab & 1), then the
+      // barrier (slab s + 1 landed, the stage free for slab s + 2), quarter 3 over the first
+      // reads and the split of slab s + 1.  W sets alternate per quarter: 0 1 0 1.
+#define PAVE_WQ012(cur)                                                        \
+  read_wq(cur, 1, 1);                                                          \
+  mma_q(cur, 0, 0);                                                            \
+  read_wq(cur, 2, 0);                                                          \
+  mma_q(cur, 1, 1);                                                            \
+  read_wq(cur, 3, 1);                                                          \
+  mma_q(cur, 0, 2);                                                            \
+  PAVE_QWAIT(0);
+#define PAVE_WSTEP(I)                                                          \
+  {                                                                            \
+    constexpr int cur = (I) & 1, nxt = cur ^ 1;                                \
+    PAVE_WQ012(cur)                                                            \
+    issue(s + I + 2, cur);                                                     \
+    read_frags(nxt, 0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    mma_q(cur, 1, 3);                                                          \
+    split_raw(s + I + 1, nxt);                                                 \
+  }
+      // (nslabs is even and >= 4: the loop leaves exactly the last two slabs, written out below
+      // without slab-count tests)
+      for (int s = 0; s + 4 <= nslabs; s += 2) {
+        PAVE_WSTEP(0)
+        PAVE_WSTEP(1)
+      }
+      PAVE_WQ012(0)
+      read_frags(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_q(0, 1, 3);
+      split_raw(nslabs - 1, 1);
+      PAVE_WQ012(1)   // (every wave has read the last stage: the epilogue reuses the ring)
+      prefetch_residual(em0, en0);
+      mma_q(1, 1, 3);
+#undef PAVE_WQ012
+#undef PAVE_WSTEP
+    }
 
     // ---- epilogue: one 32 x 32 accumulator tile at a time through the wave's own LDS chunk,
     // float4 row segments (one full 128-byte line per row and pass)
@@ -420,13 +512,15 @@ __device__ __forceinline__ void gemm_q_body(
           float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
           v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
           if (residual) {
-            v.x += resv[j][ps].x, v.y += resv[j][ps].y, v.z += resv[j][ps].z, v.w += resv[j][ps].w;
+            const float4 rv = resv[j % RB][ps];
+            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
           }
           if (relu) {
             v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
           }
           if (gm < M && colok) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
         }
+        if (WIDE && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -458,12 +552,14 @@ __device__ __forceinline__ void gemm_q_body(
           float4 x = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
           x.x += b4.x, x.y += b4.y, x.z += b4.z, x.w += b4.w;
           if (residual) {
-            x.x += resv[j][ps].x, x.y += resv[j][ps].y, x.z += resv[j][ps].z, x.w += resv[j][ps].w;
+            const float4 rv = resv[j % RB][ps];
+            x.x += rv.x, x.y += rv.y, x.z += rv.z, x.w += rv.w;
           }
           if (gm >= M) x = make_float4(0.f, 0.f, 0.f, 0.f);
           v[j][ps] = x;
           rsum[ps] += (x.x + x.y) + (x.z + x.w);
         }
+        if (WIDE && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -494,24 +590,29 @@ __device__ __forceinline__ void gemm_q_body(
         if (ec4 == 0) st2[brow * WN + wn] = q;
       }
       PAVE_QBAR();
+      float rstd[NPS];
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int brow = wm * 32 + ps * 8 + erow;
-        const long long gm = (long long)em0 + brow;
         float q = 0.f;
 #pragma unroll
         for (int w = 0; w < WN; ++w) q += st2[brow * WN + w];
-        const float rstd = rsqrtf(q * (1.f / (float)BN) + ln.eps);
+        rstd[ps] = rsqrtf(q * (1.f / (float)BN) + ln.eps);
+      }
+      // column tile outermost: gamma / beta of one tile live at a time
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-          const float4 g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
-          const float4 be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
+      for (int j = 0; j < TN; ++j) {
+        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
+        const float4 be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
           float4 x = v[j][ps];
-          x.x = fmaf(x.x * rstd, g4.x, be4.x);
-          x.y = fmaf(x.y * rstd, g4.y, be4.y);
-          x.z = fmaf(x.z * rstd, g4.z, be4.z);
-          x.w = fmaf(x.w * rstd, g4.w, be4.w);
+          x.x = fmaf(x.x * rstd[ps], g4.x, be4.x);
+          x.y = fmaf(x.y * rstd[ps], g4.y, be4.y);
+          x.z = fmaf(x.z * rstd[ps], g4.z, be4.z);
+          x.w = fmaf(x.w * rstd[ps], g4.w, be4.w);
           if (gm < M) *reinterpret_cast<float4*>(out + gm * N + ncol) = x;
         }
       }
@@ -527,8 +628,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_q_body<TN, 1, KIND, ABIAS, false>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
                                          QLn{nullptr, nullptr, 0.f}, A2);
 }
-// 128 x 256 block on 8 waves (two per SIMD, one block per CU): the block owns whole rows of an
-// N = 256 output, LayerNorm runs in the epilogue
+// the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
+template <int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const QConv g, const QOut os, const float* __restrict__ A2) {
+  gemm_q_body<8, 1, KIND, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
+                                              QLn{nullptr, nullptr, 0.f}, A2);
+}
+// 128 x 256 block on 8 waves (two per SIMD, one block per CU), narrow form: the block owns whole
+// rows of an N = 256 output, LayerNorm runs in the epilogue.  (The wide form with this epilogue --
+// a wave owning whole rows, no statistics exchange -- keeps 8 x 16 result registers next to the
+// draining accumulators, spilled 45 dwords per lane and measured 1-5 % slower: not built.)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
@@ -689,6 +801,29 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
   return PAVE_OK;
 }
 
+constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
+
+template <int KIND>
+int launch_w(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
+             long long M, int K, int N, int relu, hipStream_t st, const QConv g, const QOut os,
+             const float* a2 = nullptr) {
+  const long long gx = ((M + QBM - 1) / QBM) * (N / 256);
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_w: grid too large");
+  auto kern = gemm_w_kernel<KIND>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), W_SMEM, st, a, w, bias, residual, out, (int)M,
+                     K, N, relu, g, os, a2);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
 }  // namespace
 
 // Internal entries (pave_gemm_split.hip dispatches here).  kind as the kernel's KIND; the geometry
@@ -720,6 +855,18 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
   if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2); \
   return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os)
+  // the wide form (32 x 256 per wave): whole 256-column tiles, about one tile per block slot
+  // of the chip (2 blocks x 256 CUs) -- below that the narrow form's twice as many tiles fill
+  // the CUs better
+  const int dv = pave_internal_diag_variant();
+  const long long wtiles = ((M + QBM - 1) / QBM) * (N / 256);
+  if (N % 256 == 0 && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
+      !(kind == 0 && W > 0 && W % 256 != 0) && (!out2 || n_split % 256 == 0)) {
+    if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
+    if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
+    if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2);
+    return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
+  }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO

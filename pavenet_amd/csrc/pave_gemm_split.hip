@@ -546,7 +546,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
                          // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never,
                          // 9 = first-generation kernels for every 3-plane form (A/B against
-                         // the LDS-DMA generation of pave_gemm_dma.hip, the default)
+                         // the LDS-DMA generation of pave_gemm_dma.hip, the default),
+                         // 8 = LDS-DMA generation without its wide tile form, 7 = wide
+                         // tile form wherever it applies (default: from 512 tiles up)
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {
@@ -736,6 +738,9 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
 }
 
 void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tools/)
+}
+int pave_internal_diag_variant() { return g_diag_variant; }
+extern "C" {
 
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,
                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,

@@ -12,5 +12,6 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
 int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, float* out, long long M,
                             int K, int N, void* stream);
+int pave_internal_diag_variant(); /* tools/ only: kernel-form override (pave_diag_gemm_variant) */
 int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bias, float* y, int N,
                             int H, int W, int relu, void* stream);

@@ -897,6 +897,68 @@ def test_gemm_generations_are_bit_identical(form):
         assert torch.equal(new, old), float((new - old).abs().max())
 
 
+@pytest.mark.parametrize('form', ['rows', 'rows_res', 'rows_padded', 'rows_k64', 'ex', 'strided',
+                                  'conv3x3', 'conv3x3_res', 'cat', 'grouped'])
+def test_gemm_wide_tile_form_is_bit_identical(form):
+    """The wide tile form of the LDS-DMA GEMM (a wave owns 32 rows x 256 columns, W fragments read
+    quarter by quarter, ring of 2) against the narrow form (32 x 128 per wave, ring of 3): same
+    products in the same order per accumulator -> bit-identical on every row source / epilogue,
+    ragged M and the shortest K (4 slabs) included."""
+    from pavenet_amd import native, ops
+    lib = native.load()
+    g = torch.Generator().manual_seed(100 + len(form))
+    dev = 'cuda'
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+    def run():
+        if form in ('rows', 'rows_res', 'rows_padded', 'rows_k64'):
+            M, K, N = (1237, 192, 512) if form != 'rows_k64' else (129, 64, 256)
+            n_out = 452 if form == 'rows_padded' else N
+            a = rnd(M, K)
+            wp = ops.split_weight_bf16x3(rnd(n_out, K, scale=0.05), pad=(form == 'rows_padded'))
+            b = rnd(n_out)
+            r = rnd(M, n_out) if form != 'rows' else None
+            if form == 'rows_padded':
+                assert wp.shape[2] == 512
+                return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True, n_out=n_out)
+            return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=(form == 'rows'))
+        if form == 'ex':
+            M, K, N, rows, ns = 901, 256, 768, 53, 256
+            a, wp, tab = rnd(M, K), ops.split_weight_bf16x3(rnd(N, K, scale=0.05)), rnd(rows, N)
+            return lambda: torch.cat(ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=rows, n_split=ns), 1)
+        if form == 'strided':
+            x = rnd(2, 128, 17, 23).contiguous(memory_format=torch.channels_last)
+            wp, b = ops.split_weight_bf16x3(rnd(256, 128, scale=0.05)), rnd(256)
+            return lambda: ops.conv1x1_strided_split(x, wp, b, stride=2, relu=True).contiguous()
+        if form in ('conv3x3', 'conv3x3_res'):
+            x = rnd(3, 48, 19, 27).contiguous(memory_format=torch.channels_last)
+            wp, b = ops.split_conv3x3_weight(rnd(256, 48, 3, 3, scale=0.04)), rnd(256)
+            r = rnd(3, 256, 19, 27).contiguous(memory_format=torch.channels_last) if form == 'conv3x3_res' else None
+            return lambda: ops.conv3x3_split(x, wp, b, stride=1, relu=True, residual=r).contiguous()
+        if form == 'cat':
+            M = 1111
+            a, a2 = rnd(M, 64), rnd(M, 128)
+            wp, b = ops.split_weight_bf16x3(rnd(256, 192, scale=0.05)), rnd(256)
+            return lambda: ops.gemm_bf16x3_cat(a, a2, wp, b, None, relu=True)
+        M, G, K, gn = 707, 3, 128, 256
+        a, wp, b = rnd(M, G * K), ops.split_weight_bf16x3(rnd(G * gn, K, scale=0.05)), rnd(G * gn)
+        return lambda: ops.gemm_bf16x3_grouped(a, wp, b, gn, relu=True)
+
+    fn = run()
+    try:
+        lib.pave_diag_gemm_variant(8)
+        narrow = fn().clone()
+        lib.pave_diag_gemm_variant(7)
+        wide = fn().clone()
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wide).all()
+    assert torch.equal(wide, narrow), float((wide - narrow).abs().max())
+
+
 @pytest.mark.parametrize('M,K,N,rows,nsplit', [(1000, 256, 640, 125, 256), (777, 64, 384, 0, 128),
                                                (300, 128, 256, 7, 0), (513, 256, 512, 0, 256)])
 def test_gemm_bf16x3_ex_row_table_and_two_outputs(M, K, N, rows, nsplit):

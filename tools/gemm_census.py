@@ -1,6 +1,6 @@
 """Per-shape census of the split-GEMM / convolution launches of one bench step (T = 7 x 4 clips,
 800x1344, --gemm bf16x3): HIP-event time, TFLOP/s and launch count per (entry point, M, K, N, form),
-in launch order.   python tools/gemm_census.py [steps=3]"""
+in launch order.   python tools/gemm_census.py [steps=3] [diag variant]"""
 import collections
 import os
 import sys
@@ -16,6 +16,9 @@ from pavenet_amd.weights import init_random_weights  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    if len(sys.argv) > 2:   # kernel-form override (pave_diag_gemm_variant), e.g. 8 = no wide tiles
+        from pavenet_amd import native
+        native.load().pave_diag_gemm_variant(int(sys.argv[2]))
     T, B, H, W = 7, 4, 800, 1344
     m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=20))
     init_random_weights(m, seed=0)
