@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 10
+#define PAVE_ABI_VERSION 11
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -347,6 +347,24 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,
                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                            int stride, int relu, int nplanes, void* stream);
+
+/*
+ * The same convolution (3 planes) with the K axis cut into parts -- for maps with FEW output pixels
+ * and many input channels, where the 128-row tiles alone leave most of the chip idle (the
+ * ChannelMapper's extra level: 3x3 / stride 2, 2048 -> 256 on the C5 map,
+ * third_party/mmdetection/mmdet/models/necks/channel_mapper.py:84-97).  Each part is computed by
+ * its own workgroups into `workspace` ([parts][N Ho Wo][Cout] fp32), a second launch adds the
+ * parts IN ORDER (deterministic), then bias, residual and ReLU.
+ *   pave_conv3x3_splitk_workspace_bytes: the workspace the shape needs; 0 = the shape has no
+ *   split-K plan (enough tiles or a short K): call pave_conv3x3_split_f32.
+ *   pave_conv3x3_splitk_f32: workspace_bytes >= that value; the workspace is free for reuse in
+ *   stream order after the call.
+ */
+long long pave_conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride);
+int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* bias,
+                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                            int stride, int relu, void* workspace, long long workspace_bytes,
+                            void* stream);
 
 /*
  * 1x1 convolution with a stride on an NHWC map (the ResNet downsample branch,

@@ -59,7 +59,8 @@ struct QOut {    // epilogue options: second output from column nsplit on, row-p
   int nsplit;    // out / bias / residual have n_real columns, the columns beyond are not stored)
   int res_rows;
   int n_real;
-};
+  int ks_slabs;  // split-K (grid.y parts): K slabs per part (even, >= 4), 0 = whole K.  Part y
+};               // writes its raw partial sums to out + y M n_real (bias / residual / relu unset)
 struct QLn {     // LayerNorm over the output row (LNORM forms, N == block width)
   const float* gamma;
   const float* beta;
@@ -170,7 +171,9 @@ __device__ __forceinline__ void gemm_q_body(
   // row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once)
   const int per = ttot >> 3, rem = ttot & 7;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int nslabs = K / 16;
+  // split-K: this block's part of the K axis
+  const int s0 = os.ks_slabs > 0 ? (int)blockIdx.y * os.ks_slabs : 0;
+  const int nslabs = os.ks_slabs > 0 ? min(os.ks_slabs, K / 16 - s0) : K / 16;
   const long long w_slab = (long long)3 * N * 32;   // bytes per K slab of the weight planes
   const unsigned char* const w_base = reinterpret_cast<const unsigned char*>(Wp);
 
@@ -230,7 +233,8 @@ __device__ __forceinline__ void gemm_q_body(
       w_voff[q - QA] = (unsigned)((((long long)p * N + n0 + row) * 32 + h * 16));
     }
   };
-  auto issue = [&](const int slab, const int stage) {
+  auto issue = [&](const int rel, const int stage) {
+    const int slab = rel + s0;
     const unsigned sl = lds0 + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
@@ -489,7 +493,8 @@ __device__ __forceinline__ void gemm_q_body(
     // float4 row segments (one full 128-byte line per row and pass)
     float* Cs = reinterpret_cast<float*>(smem + EPI_OFF) + wave * 32 * QCST;
     const bool seg2 = os.out2 != nullptr && en0 >= os.nsplit;
-    float* const obase = seg2 ? os.out2 : out;
+    float* const obase = seg2 ? os.out2
+                              : out + (os.ks_slabs > 0 ? (long long)blockIdx.y * M * os.n_real : 0);
     const int ldo = os.out2 == nullptr ? os.n_real : (seg2 ? N - os.nsplit : os.nsplit);
     const int csh = seg2 ? os.nsplit : 0;
     if constexpr (!LNORM) {
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
   gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
-                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N}, ln);
+                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
 
 // ---------------------------------------------------------------------------
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(192) void stem7x7_q_kernel(
 template <int TN, int KIND, bool ABIAS>
 int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
-             const QOut os, const float* a2 = nullptr) {
+             const QOut os, const float* a2 = nullptr, int ksplit = 1) {
   constexpr int BN = TN * 32;
   constexpr int STAGE = QBM * 64 + 3 * BN * 32;
   const int smem = QNS * STAGE + (ABIAS ? K * 4 : 0);
@@ -794,11 +799,36 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_q: cannot raise dynamic LDS limit");
     attr_smem = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, st, a, w, bias, residual, out, (int)M, K,
-                     N, relu, a_bias, g, os, a2);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), smem, st, a, w, bias,
+                     residual, out, (int)M, K, N, relu, a_bias, g, os, a2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
+}
+
+// split-K second pass: out = act(sum over the parts IN ORDER + bias + residual), float4 per lane
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    const float* __restrict__ ws, const int parts, const long long total4, const int n4,
+    const float* __restrict__ bias, const float* __restrict__ residual, const int relu,
+    float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  float4 v = w4[i];
+  for (int p = 1; p < parts; ++p) {
+    const float4 t = w4[p * total4 + i];
+    v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+  }
+  if (bias) {
+    const float4 b = reinterpret_cast<const float4*>(bias)[i % n4];
+    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  }
+  if (residual) {
+    const float4 r = reinterpret_cast<const float4*>(residual)[i];
+    v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+  }
+  if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+  reinterpret_cast<float4*>(out)[i] = v;
 }
 
 constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
@@ -806,7 +836,7 @@ constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 
 template <int KIND>
 int launch_w(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, hipStream_t st, const QConv g, const QOut os,
-             const float* a2 = nullptr) {
+             const float* a2 = nullptr, int ksplit = 1) {
   const long long gx = ((M + QBM - 1) / QBM) * (N / 256);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_w: grid too large");
   auto kern = gemm_w_kernel<KIND>;
@@ -817,8 +847,8 @@ int launch_w(const float* a, const uint16_t* w, const float* bias, const float* 
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), W_SMEM, st, a, w, bias, residual, out, (int)M,
-                     K, N, relu, g, os, a2);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), W_SMEM, st, a, w, bias,
+                     residual, out, (int)M, K, N, relu, g, os, a2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -826,19 +856,56 @@ int launch_w(const float* a, const uint16_t* w, const float* bias, const float* 
 
 }  // namespace
 
+// Split-K plan of an [M, Kp] x [Np, Kp] product: how many parts the K axis is cut into (1 = none)
+// and the slabs per part.  Worth it when the tiles alone leave most of the 512 block slots of the
+// chip empty and K is long; every part gets an even number >= 32 of slabs.
+void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks_slabs) {
+  const long long tiles = ((M + QBM - 1) / QBM) * (Np % 256 == 0 ? Np / 256 : (Np + 127) / 128);
+  const int nsl = Kp / 16;
+  *ksplit = 1, *ks_slabs = 0;
+  if (tiles >= 200 || nsl < 128 || pave_internal_diag_variant() == 6) return;
+  int parts = (int)(480 / tiles);
+  if (parts > 8) parts = 8;
+  if (parts > nsl / 32) parts = nsl / 32;
+  if (parts < 2) return;
+  int per = ((nsl + parts - 1) / parts + 1) & ~1;
+  for (;; per += 2) {   // the last part keeps >= 4 slabs (nsl and per are even: its size is even)
+    parts = (nsl + per - 1) / per;
+    if (nsl - (parts - 1) * per >= 4) break;
+  }
+  if (parts < 2) return;
+  *ksplit = parts, *ks_slabs = per;
+}
+int pave_internal_splitk_reduce(const float* ws, int parts, long long M, int n, const float* bias,
+                                const float* residual, int relu, float* out, void* stream) {
+  const long long total4 = M * n / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), ws, parts, total4, n / 4, bias, residual, relu,
+                     out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
 // Internal entries (pave_gemm_split.hip dispatches here).  kind as the kernel's KIND; the geometry
 // is ignored for kind 0.
 int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
                          const float* residual, long long residual_rows, float* out, float* out2,
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
-                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real) {
+                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real,
+                         int ksplit, int ks_slabs) {
   const QConv g{H, W, Cin, Ho, Wo, stride};
   const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
   if (narrow) N = -N;
   if (n_real <= 0) n_real = N;
   if (n_real > N || n_real % 4 != 0 || (out2 && n_real != N))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: n_real %% 4 == 0, n_real <= N (== N with two outputs)");
-  const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows, n_real};
+  if (ksplit > 1 && (bias || residual || out2 || a_bias || relu || ks_slabs < 4 || ks_slabs % 2 != 0 ||
+                     (long long)(ksplit - 1) * ks_slabs + 4 > K / 16 || (long long)ksplit * ks_slabs < K / 16))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: split-K parts are raw partial sums of >= 4 slabs");
+  if (ksplit < 1) ksplit = 1;
+  const QOut os{out2, out2 ? n_split : 0, residual_rows >= M ? 0 : (int)residual_rows, n_real,
+                ksplit > 1 ? ks_slabs : 0};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (K % 32 != 0 || K < 64) return pave_internal_fail(PAVE_E_ARG, "gemm_q: K %% 32 == 0, K >= 64");
@@ -850,22 +917,22 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
 #define PAVE_QGO(TN_)                                                                               \
   if (kind == 0) {                                                                                  \
     if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
-    return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);    \
+    return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
   }                                                                                                 \
-  if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
-  if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2); \
-  return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os)
+  if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
+  if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2, ksplit); \
+  return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit)
   // the wide form (32 x 256 per wave): whole 256-column tiles, about one tile per block slot
   // of the chip (2 blocks x 256 CUs) -- below that the narrow form's twice as many tiles fill
   // the CUs better
   const int dv = pave_internal_diag_variant();
-  const long long wtiles = ((M + QBM - 1) / QBM) * (N / 256);
+  const long long wtiles = ((M + QBM - 1) / QBM) * (N / 256) * ksplit;
   if (N % 256 == 0 && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
       !(kind == 0 && W > 0 && W % 256 != 0) && (!out2 || n_split % 256 == 0)) {
-    if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
-    if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
-    if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2);
-    return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os);
+    if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
+    return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
   }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }

@@ -784,6 +784,40 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
 #undef PAVE_CV
 }
 
+long long pave_conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) ||
+      Cin % 16 != 0 || Cout % 4 != 0 || g_diag_variant == 9)
+    return 0;
+  const long long M = (long long)N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+  int parts, per;
+  pave_internal_splitk_plan(M, (9 * Cin + 31) / 32 * 32, (Cout + 63) / 64 * 64, &parts, &per);
+  return parts > 1 ? (long long)parts * M * Cout * 4 : 0;
+}
+
+int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* bias,
+                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                            int stride, int relu, void* workspace, long long workspace_bytes,
+                            void* stream) {
+  if (!x || !w_planes || !y || !workspace)
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: null pointer");
+  const long long need = pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride);
+  if (need == 0 || workspace_bytes < need)
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: shape has no split-K plan (use pave_conv3x3_split_f32) "
+                                          "or the workspace is smaller than pave_conv3x3_splitk_workspace_bytes");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  if ((long long)N * H * W * Cin >= (1ll << 40))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: tensor too large");
+  const int Kp = (9 * Cin + 31) / 32 * 32, Np = (Cout + 63) / 64 * 64;
+  int parts, per;
+  pave_internal_splitk_plan(M, Kp, Np, &parts, &per);
+  float* ws = static_cast<float*>(workspace);
+  const int rc = pave_internal_gemm_q(x, nullptr, w_planes, nullptr, nullptr, 0, ws, nullptr, 0, M, Kp, Np, 0,
+                                      1, H, W, Cin, Ho, Wo, stride, stream, nullptr, Cout, parts, per);
+  if (rc != PAVE_OK) return rc;
+  return pave_internal_splitk_reduce(ws, parts, M, Cout, bias, residual, relu, y, stream);
+}
+
 int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                    int N, int H, int W, int Cin, int Cout, int stride, int relu,
                                    void* stream) {

@@ -8,7 +8,11 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
                          const float* residual, long long residual_rows, float* out, float* out2,
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
                          int Cin, int Ho, int Wo, int stride, void* stream, const float* a2 = nullptr,
-                         int n_real = 0);
+                         int n_real = 0, int ksplit = 1, int ks_slabs = 0);
+// split-K (few output rows, long K): plan, and the ordered sum of the parts + bias / residual / ReLU
+void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks_slabs);
+int pave_internal_splitk_reduce(const float* ws, int parts, long long M, int n, const float* bias,
+                                const float* residual, int relu, float* out, void* stream);
 int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, float* out, long long M,
                             int K, int N, void* stream);

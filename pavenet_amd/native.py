@@ -45,13 +45,14 @@ SIGNATURES = {
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
+    'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
 # every symbol include/pave_hip.h declares
-EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error')
+EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 10  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 11  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):
@@ -77,6 +78,8 @@ def load():
     lib.pave_abi_version.argtypes = []
     lib.pave_last_error.restype = ctypes.c_char_p
     lib.pave_last_error.argtypes = []
+    lib.pave_conv3x3_splitk_workspace_bytes.restype = ctypes.c_longlong
+    lib.pave_conv3x3_splitk_workspace_bytes.argtypes = [_c_int] * 6
     have = lib.pave_abi_version()
     if have != ABI_VERSION:   # a stale .so called with the wrong argument list corrupts memory
         raise NativeLibraryError(

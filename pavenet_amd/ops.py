@@ -865,6 +865,22 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False, resi
                  and residual.is_contiguous(memory_format=torch.channels_last),
                  'conv3x3_split: residual [N, Cout, Ho, Wo] channels_last')
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    # few output pixels, many input channels: the split-K form (parts of the K axis on their own
+    # workgroups, ordered sum in a second launch); the workspace comes from torch's stream-aware
+    # caching allocator
+    ws_bytes = lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, int(stride)) \
+        if w_planes.shape[1] == 3 and not fp16 else 0
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin,
+                                                 (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride} split-K')):
+            st = lib.pave_conv3x3_splitk_f32(
+                x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+                residual.data_ptr() if residual is not None else None,
+                y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), ws.data_ptr(), ws_bytes,
+                _stream_ptr())
+        native.check(st, 'conv3x3_splitk')
+        return y.permute(0, 3, 1, 2)
     with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin, (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}')):
         st = lib.pave_conv3x3_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,

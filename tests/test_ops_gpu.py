@@ -801,6 +801,49 @@ def test_conv3x3_split_padded_channels_with_residual_vs_fp64(N, H, W, Cin, Cout,
     assert torch.equal(bad, expn)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 25, 42, 512, 256, 2), (1, 13, 21, 256, 128, 1),
+                                                   (3, 9, 11, 320, 100, 1), (1, 14, 14, 272, 64, 2)])
+def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
+    """The split-K form of the 3-plane 3x3 convolution (few output pixels, long K: the
+    ChannelMapper's extra level, channel_mapper.py:84-97): the plan must exist for these shapes,
+    the parts are summed in a fixed order (two runs are bit-identical), and the result -- bias,
+    residual, ReLU applied by the second launch -- meets the same fp64 bound as the one-pass kernel,
+    to which it is compared too (diag variant 6 = no split-K plan)."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    lib = native.load()
+    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) > 0
+    g = torch.Generator().manual_seed(Cin * Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin**0.5)
+    b = torch.randn(Cout, generator=g)
+    exp = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    r = torch.randn(exp.shape, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    rd = r.cuda().contiguous(memory_format=torch.channels_last)
+    wp = split_conv3x3_weight(w.cuda())
+    y = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout)
+    assert tuple(y.shape) == tuple(exp.shape)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(y, conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout))
+    y2 = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=True, residual=rd, cout=Cout)
+    np.testing.assert_allclose(y2.cpu().numpy(), torch.relu(exp + r.double()).numpy(), rtol=1e-5, atol=2e-5)
+    try:
+        lib.pave_diag_gemm_variant(6)
+        assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == 0
+        one = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout)
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    np.testing.assert_allclose(y.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    # a NaN pixel poisons exactly the outputs whose window holds it, in every part
+    xn = x.clone()
+    xn[0, Cin - 1, 2, 2] = float('nan')
+    yn = conv3x3_split(xn.cuda().contiguous(memory_format=torch.channels_last), wp, None, stride=stride,
+                       cout=Cout)
+    expn = torch.isnan(torch.nn.functional.conv2d(xn, w, None, stride, 1)[0]).any(0)
+    assert torch.equal(torch.isnan(yn[0]).any(0).cpu(), expn)
+
+
 @pytest.mark.parametrize('M,K,N', [(700, 96, 48), (333, 192, 96), (129, 384, 192), (1000, 64, 36)])
 def test_gemm_bf16x3_padded_output_width_vs_fp64(M, K, N):
     """Row GEMM with N % 64 != 0 (HRNet fuse-layer 1x1 convolutions 96 -> 48 etc.): planes padded
