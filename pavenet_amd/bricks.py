@@ -312,6 +312,21 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
     return (out, None) if pos_rows is not None else out
 
 
+def linear_norm(x, linear, norm):
+    """LayerNorm(Linear(x)) on [..., C] rows: ONE launch of the Linear + LayerNorm kernel in the
+    exact split mode (256-wide rows, device fp32, no grad), plain torch modules otherwise."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and linear.out_features == 256
+            and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (256,)
+            and norm.weight is not None and norm.bias is not None and x2.is_contiguous()
+            and not torch.is_grad_enabled() and split_gemm_ok(x2, linear.weight)):
+        from . import ops
+        t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, None, norm.weight,
+                               norm.bias, norm.eps)
+        return t.view(*x.shape[:-1], 256)
+    return norm(linear(x))
+
+
 class ConvModule(nn.Module):
     """conv -> norm -> act with mmcv's attribute names (``conv``, ``gn`` / ``bn``)."""
 

@@ -644,8 +644,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 // 128 x 256 block on 8 waves (two per SIMD, one block per CU), narrow form: the block owns whole
 // rows of an N = 256 output, LayerNorm runs in the epilogue.  (The wide form with this epilogue --
-// a wave owning whole rows, no statistics exchange -- keeps 8 x 16 result registers next to the
-// draining accumulators, spilled 45 dwords per lane and measured 1-5 % slower: not built.)
+// a wave owning whole rows, no statistics exchange -- was built twice: with the 8 x 16 result
+// registers next to the draining accumulators it spilled 45 dwords per lane and ran 1-5 % slower;
+// with three sweeps of the accumulators through the LDS chunk (sum, centred squares, normalise)
+// it ran EQUAL, 1.736 vs 1.743 ms at K = 1024 and 0.612 vs 0.615 ms at K = 256: these launches sit
+// on a mixed HBM / MFMA bound that the tile form does not move.  Not kept.)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .bricks import (BaseModule, SourceKey, TransformerLayerSequence, batch_first, inverse_sigmoid,
+                     linear_norm,
                      seq_first_view, xavier_init)
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
@@ -431,7 +432,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             if cached is not None:   # the grid depends on the level sizes only
                 output_proposals, valid = cached
                 output_memory = memory.masked_fill(~valid, float(0))
-                output_memory = self.enc_output_norm(self.enc_output(output_memory))
+                output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
                 return output_memory, output_proposals
         proposals = []
         _cur = 0
