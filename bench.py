@@ -149,7 +149,8 @@ def file_git_blob_sha1(path):
 
 
 # launches of the split-operand MFMA GEMM family (pavenet_amd/csrc/pave_gemm_split.hip)
-SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided', 'conv7x7_stem')
+SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided', 'conv7x7_stem',
+                   'bottleneck_chain')
 
 
 def algorithmic_bytes_encoder_launch(n_frames):

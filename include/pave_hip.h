@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 11
+#define PAVE_ABI_VERSION 12
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -365,6 +365,30 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
                             const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                             int stride, int relu, void* workspace, long long workspace_bytes,
                             void* stream);
+
+/*
+ * ResNet Bottleneck of the 64-channel stage from its 3x3 convolution on, CHAINED with the next
+ * block's conv1, in ONE launch (third_party/mmdetection/mmdet/models/backbones/resnet.py:263-300
+ * Bottleneck.forward: conv2 + bn2 + relu -> conv3 + bn3 -> + identity | downsample(x) -> relu; then
+ * the following block's conv1 + bn1 + relu), BatchNorms folded, NHWC fp32, M = N H W pixels:
+ *   c2  = relu(conv3x3_pad1(c1 [N, H, W, 64]; w2_planes) + b2)            -> c2  [M, 64] (scratch)
+ *   out = relu([c2 | a2] @ W3^T + b3 + residual)                          -> out [M, 256]
+ *         a2 [M, k2] (k2 %% 32 == 0): the block input of a stride-1 downsample block, W3 = the
+ *         [256, 64 + k2] row-concatenated conv3 | downsample weight, b3 = both biases; else
+ *         residual [M, 256] = the block input (may alias out), a2 == NULL, k2 == 0
+ *   c1n = relu(out @ W1n^T + b1n)                                         -> c1n [M, cn], cn = 64 | 128
+ *         (w1n_planes == NULL, cn == 0: the launch stops after `out`)
+ * w2_planes as pave_conv3x3_split_f32's (3 planes), w3_planes / w1n_planes as
+ * pave_gemm_bf16x3_f32's (3 planes).  Every value equals what pave_conv3x3_split_f32,
+ * pave_gemm_bf16x3_cat_f32 / pave_gemm_bf16x3_f32 give launched one after the other (same
+ * kernels bodies, same tiles) -- the chain exists for time: a workgroup carries one 128-pixel tile
+ * through the three GEMMs, so the HBM-bound conv3 + identity phase of one workgroup overlaps the
+ * MFMA-bound phases of its neighbours and conv1 reads `out` back from L2.
+ */
+int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const float* b2, float* c2,
+                              const void* w3_planes, const float* b3, const float* residual,
+                              const float* a2, int k2, float* out, const void* w1n_planes,
+                              const float* b1n, float* c1n, int cn, int N, int H, int W, void* stream);
 
 /*
  * 1x1 convolution with a stride on an NHWC map (the ResNet downsample branch,

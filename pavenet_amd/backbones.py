@@ -118,6 +118,9 @@ class ResNet(BaseModule):
         # 512: 0.64 vs 0.58)
         self.fused_tail_max_k = 256
         self.fused_ds_max_k = 128     # conv3 + downsample in one kernel up to this K1 + K2 (layer1.0)
+        # 64-channel stage (layer1) in the exact split mode: one launch per Bottleneck from its 3x3
+        # on, chained with the next block's conv1 (ops.bottleneck_chain); attribute = A/B switch
+        self.chain_stage64 = True
         # 3x3 convolutions: MIOpen's searched fp32 kernels are 10-30 % faster than the
         # hand-written MFMA implicit GEMM (tools/bench_conv.py) but NOT run-to-run deterministic
         # (tools/debug_determinism.py); True routes them through pave_conv3x3_nhwc_f32
@@ -209,7 +212,66 @@ class ResNet(BaseModule):
         n, h, w = nhw
         return rows.view(n, h, w, rows.shape[-1]).permute(0, 3, 1, 2)  # channels_last 4-D
 
-    def _bottleneck_gemm(self, blk, x, f, name, bi, inplace_identity=False):
+    def _stage64_chain_ok(self, name, x, f):
+        from .bricks import _GEMM, get_gemm_mode
+        blocks = list(getattr(self, name))
+        if blocks[0].downsample is not None and (name, 0, 'tail_ds_kn') not in f:
+            return False
+        if not (self.chain_stage64 and get_gemm_mode() == 'bf16x3' and not torch.is_grad_enabled()
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and x.shape[0] * x.shape[2] * x.shape[3] >= _GEMM['min_rows']
+                and all(isinstance(b, Bottleneck) for b in blocks)):
+            return False
+        for bi, blk in enumerate(blocks):
+            c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+            if not (c1.out_channels == 64 and c1.stride == (1, 1)
+                    and tuple(c2.weight.shape) == (64, 64, 3, 3) and c2.stride == (1, 1)
+                    and c2.dilation == (1, 1) and c2.padding == (1, 1) and c2.groups == 1
+                    and tuple(c3.weight.shape[:2]) == (256, 64)):
+                return False
+            if blk.downsample is not None and not (
+                    bi == 0 and blk.downsample[0].stride == (1, 1)
+                    and blk.downsample[0].in_channels == 64):
+                return False
+            if blk.downsample is None and c1.in_channels != 256:
+                return False
+        return blocks[0].conv1.in_channels == x.shape[1] and x.shape[1] % 64 == 0
+
+    def _stage64_chain(self, name, x, f, next_conv1):
+        """The 64-channel stage with ONE launch per Bottleneck from its 3x3 convolution on
+        (conv2 -> conv3 + identity | downsample -> ReLU -> the NEXT block's conv1,
+        pave_bottleneck_chain_f32); only the first conv1 is a launch of its own.  next_conv1 =
+        the folded (weight, bias) of the following stage's first conv1 (64 | 128 outputs) or None.
+        Returns (stage output, that conv1's output or None)."""
+        from . import ops
+        from .bricks import _split_cached, _split_weight, linear_rows, split_conv_weight
+        blocks = list(getattr(self, name))
+        rows, nhw = self._as_rows(x)
+        w1, b1 = f[(name, 0, 'conv1')]
+        c1 = self._as_map(linear_rows(rows, w1.flatten(1), b1, relu=True), nhw)
+        out = None
+        for bi, blk in enumerate(blocks):
+            w2, b2 = f[(name, bi, 'conv2')]
+            w3, b3 = f[(name, bi, 'conv3')]
+            nxt = f[(name, bi + 1, 'conv1')] if bi + 1 < len(blocks) else next_conv1
+            wnp = _split_weight(nxt[0].flatten(1)) if nxt is not None else None
+            bnx = nxt[1] if nxt is not None else None
+            if blk.downsample is not None:
+                tail = f[(name, bi, 'tail_ds_kn')]     # [W3; Wd] as [K, N], b3 + bd
+                w3p = _split_cached(tail[0], 'tail_cat', lambda planes: ops.split_weight_bf16x3(
+                    tail[0].t().contiguous(), planes))
+                out, c1 = ops.bottleneck_chain(c1, split_conv_weight(w2), b2, w3p, tail[1], a2=x,
+                                               w1n_planes=wnp, b1n=bnx)
+            else:
+                # blocks after the first overwrite the previous block's output (a temporary)
+                res = out if out is not None else x
+                out, c1 = ops.bottleneck_chain(c1, split_conv_weight(w2), b2,
+                                               _split_weight(w3.flatten(1)), b3, residual=res,
+                                               w1n_planes=wnp, b1n=bnx,
+                                               out=res if out is not None else None)
+        return out, c1
+
+    def _bottleneck_gemm(self, blk, x, f, name, bi, inplace_identity=False, c1=None):
         """Bottleneck on the NHWC map: conv1 as a hipBLASLt row GEMM (bias + ReLU epilogue), the
         3x3 through MIOpen, and the tail `bn2 -> relu -> conv3 -> bn3 -> + identity |
         downsample(x) -> relu` as ONE hand-written MFMA kernel (pave_rows_gemm_bias_res_act_f32)
@@ -218,9 +280,12 @@ class ResNet(BaseModule):
         from . import ops
         from .bricks import linear_rows, split_conv_weight, split_gemm_ok
         rows, nhw = self._as_rows(x)
-        w1, b1 = f[(name, bi, 'conv1')]
-        y = linear_rows(rows, w1.flatten(1), b1, relu=True)               # conv1 + bn1 + relu
-        y = self._as_map(y, nhw)
+        if c1 is not None:
+            y = c1                          # computed by the previous stage's last chained launch
+        else:
+            w1, b1 = f[(name, bi, 'conv1')]
+            y = linear_rows(rows, w1.flatten(1), b1, relu=True)           # conv1 + bn1 + relu
+            y = self._as_map(y, nhw)
         w2, b2 = f[(name, bi, 'conv2')]
         c2 = blk.conv2
         w3, b3 = f[(name, bi, 'conv3')]
@@ -339,12 +404,26 @@ class ResNet(BaseModule):
         else:
             x = self.maxpool(F.relu_(F.conv2d(x, w, b, 2, 3)))
         outs = []
+        pre_c1 = None       # the coming block's conv1 output, when the previous launch chained it
         for i, name in enumerate(self.res_layers):
+            if gemm_path and self._stage64_chain_ok(name, x, f):
+                nxt = None
+                if i + 1 < len(self.res_layers):
+                    nb = getattr(self, self.res_layers[i + 1])[0]
+                    if isinstance(nb, Bottleneck) and nb.conv1.stride == (1, 1) and \
+                            nb.conv1.in_channels == 256 and nb.conv1.out_channels in (64, 128):
+                        nxt = f[(self.res_layers[i + 1], 0, 'conv1')]
+                x, pre_c1 = self._stage64_chain(name, x, f, nxt)
+                if i in self.out_indices:
+                    outs.append(x)
+                continue
             for bi, blk in enumerate(getattr(self, name)):
                 if gemm_path and isinstance(blk, Bottleneck):
                     # blocks after the first of a stage read a temporary (the previous
                     # block's output, never a stage output): accumulate into it
-                    x = self._bottleneck_gemm(blk, x, f, name, bi, inplace_identity=bi > 0)
+                    x = self._bottleneck_gemm(blk, x, f, name, bi, inplace_identity=bi > 0,
+                                              c1=pre_c1)
+                    pre_c1 = None
                     continue
                 identity = x
                 y = x

@@ -53,6 +53,7 @@ constexpr int QCST = 36;   // epilogue chunk (32 rows x 32 columns per wave) row
 
 struct QConv {   // convolution forms: NHWC geometry
   int H, W, Cin, Ho, Wo, stride;
+  unsigned rcp;  // 3x3 form: ceil(2^32 / (Cin / 16)) (0 when Cin == 16): slab -> tap by multiply-high
 };
 struct QOut {    // epilogue options: second output from column nsplit on, row-periodic residual,
   float* out2;   // real output width n_real <= N (N = the width of the zero-padded weight planes:
@@ -110,6 +111,16 @@ __device__ __forceinline__ void dma16_flat(const void* vaddr, unsigned lds_addr)
                : "v"(vaddr), "s"(lds_addr)
                : "memory");
 }
+// the same through a buffer resource (base, size): a lane whose byte offset lies beyond the size
+// reads ZEROS -- the zero padding of the 3x3 form costs one select per lane instead of a second
+// address
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_buf(unsigned voff, i32x4 rsrc, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voff), "s"(rsrc), "s"(lds_addr)
+               : "memory");
+}
 // every DMA older than the NV youngest vector-memory operations of this wave has landed, every LDS
 // read of this wave has returned; then the workgroup barrier
 #define PAVE_QWAIT(NV) \
@@ -121,7 +132,8 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
 //           is cut into groups of g.W columns, group i multiplies columns [i K, (i + 1) K) of A by its
-//           own [g.W, K] weight -- T per-frame Linears of one layer as ONE launch);  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map;
+//           own [g.W, K] weight -- T per-frame Linears of one layer as ONE launch);  1 = 3x3 / pad 1 implicit GEMM over (tap, cin) of an NHWC map
+//           smaller than 4 GiB (buffer-addressed: out-of-image taps are out-of-range lanes);  2 = the same for larger maps (64-bit lane addresses, a zero chunk for the padding);
 //       3 = rows = strided pixels of an NHWC map (1x1 convolution with a stride);
 //       4 = rows [A | A2]: the first g.Cin columns of the K axis come from A [M, g.Cin], the rest
 //           from A2 [M, K - g.Cin] (two GEMMs sharing one accumulator: conv3 + downsample)
@@ -158,6 +170,7 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int ABOFF = STAT_OFF + (LNORM ? 2 * QBM * WN * 4 : 0);   // a_bias vector
   static_assert(NA % NWAVE == 0, "A DMA instructions divide evenly over the waves");
   static_assert(!LNORM || KIND == 0, "LayerNorm epilogue: plain row GEMM only");
+  static_assert(KIND >= 0 && KIND <= 4, "row source");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,8 +195,18 @@ __device__ __forceinline__ void gemm_q_body(
   unsigned a_voff[QA];       // KIND 0 / 3 / 4: byte offset of the lane's chunk from the slab base
   unsigned a2_voff[QA];      // KIND 4: the same inside A2
   const unsigned char* a2_base = reinterpret_cast<const unsigned char*>(A2);
-  int a_iy0[QA], a_ix0[QA];  // KIND 1: top-left input pixel of the lane's output pixel
-  const float* a_img[QA];    // KIND 1: image base + chunk offset
+  int a_iy0[QA], a_ix0[QA];  // KIND 2: top-left input pixel of the lane's output pixel
+  const float* a_img[QA];    // KIND 2: image base + chunk offset
+  unsigned a_mask[QA];       // KIND 1: bit t = tap t of the lane's pixel lies inside the image
+  i32x4 a_rsrc;              // KIND 1: buffer resource of the whole map
+  if (KIND == 1) {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(A);
+    a_rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ab);
+    a_rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ab >> 32) & 0xffff);
+    // bytes of the whole map (the launcher takes this form below 4 GiB only)
+    a_rsrc.z = __builtin_amdgcn_readfirstlane((M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 4);
+    a_rsrc.w = 0x00020000;
+  }
   unsigned w_voff[QMAX - QA];
   const unsigned char* a_base = reinterpret_cast<const unsigned char*>(A);
 
@@ -211,6 +234,17 @@ __device__ __forceinline__ void gemm_q_body(
         const int oy = (int)(gy - (unsigned)n * (unsigned)g.Ho);
         if (KIND == 3) {
           a_voff[q] = (unsigned)(((((long long)n * g.H + oy * g.stride) * g.W + ox * g.stride) * K + c * 4) * 4);
+        } else if (KIND == 1) {
+          const int iy0 = oy * g.stride - 1, ix0 = ox * g.stride - 1;
+          // byte offset of tap (0, 0), chunk c (mod 2^32: may lie before the map for a padded tap)
+          a_voff[q] = (unsigned)(((((long long)n * g.H + iy0) * g.W + ix0) * g.Cin + c * 4) * 4);
+          unsigned mk = 0;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+            mk |= (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? (1u << t) : 0u;
+          }
+          a_mask[q] = mk;
         } else {
           a_iy0[q] = oy * g.stride - 1;
           a_ix0[q] = ox * g.stride - 1;
@@ -240,6 +274,15 @@ __device__ __forceinline__ void gemm_q_body(
     for (int q = 0; q < QA; ++q) {
       const unsigned dst = sl + (wave + NWAVE * q) * 1024;
       if (KIND == 1) {
+        // (scalar) a slab lies inside one tap: tap = slab / (Cin / 16) by reciprocal multiply
+        const int tap = g.rcp ? (int)__umulhi((unsigned)slab, g.rcp) : slab;
+        const int c0 = (slab - tap * (g.Cin >> 4)) * 16;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // (tap < 16)
+        const unsigned toff = (unsigned)(((ky * g.W + kx) * g.Cin + c0) * 4);
+        // (tap >= 9: the zero slab that pads K = 9 Cin to a multiple of 32 -- no mask bit)
+        const bool ok = (a_mask[q] >> tap) & 1u;
+        dma16_buf(ok ? a_voff[q] + toff : 0x80000000u, a_rsrc, dst);
+      } else if (KIND == 2) {
         const int k0 = slab * 16;
         const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // (scalar) a slab lies inside one tap
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -642,6 +685,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_q_body<8, 1, KIND, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
                                               QLn{nullptr, nullptr, 0.f}, A2);
 }
+// ---------------------------------------------------------------------------
+// ResNet Bottleneck (64-channel stage) from its 3x3 convolution on, chained with the NEXT block's
+// conv1 -- three GEMMs of ONE 128-pixel row tile back to back in one workgroup:
+//   c2  = relu(conv3x3(c1) + b2)                         [M, 64]    K = 576   (narrow form)
+//   out = relu([c2 | a2] @ W3^T + b3 + residual)         [M, 256]   K = 64 | 64 + k2 (wide form)
+//   c1n = relu(out @ W1n^T + b1n)                        [M, 64 | 128]   K = 256  (narrow form)
+// (third_party/mmdetection/mmdet/models/backbones/resnet.py:263-300 Bottleneck.forward, conv2 ->
+// conv3 -> + identity | downsample -> relu, then the next block's conv1).  The tile's c2 and out
+// rows go through global memory (written, re-read by LDS-DMA after a workgroup barrier: they come
+// back from L2), so the three row GEMMs are the unchanged bodies above.  Why one launch: on the
+// 1.9 M-pixel layer1 maps conv3 + identity is HBM-bound (4.3 GB per launch), the 3x3 and conv1 are
+// MFMA- / issue-bound; chained, the workgroups of a CU sit in different phases and the two resources
+// overlap, and conv1 reads `out` from L2 instead of HBM.
+// ---------------------------------------------------------------------------
+struct ChainArgs {
+  const float* c1; const uint16_t* w2; const float* b2; float* c2;
+  const uint16_t* w3; const float* b3; const float* residual; const float* a2; float* out;
+  const uint16_t* w1n; const float* b1n; float* c1n;
+  int M, H, W, K3, k1;
+};
+__device__ __forceinline__ void chain_sync() {
+  // The tile's rows are written and re-read by waves of ONE workgroup = one CU: its stores have
+  // reached L2 (write-through L1, vmcnt(0)) and the CU's own L1 stays coherent with its stores,
+  // so workgroup scope is enough.  (Agent scope writes back / invalidates the whole L2 of the
+  // XCD per tile: measured 3x slower.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int KIND2, int TN3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_chain_kernel(
+    const ChainArgs p) {
+  const QLn ln0{nullptr, nullptr, 0.f};
+  gemm_q_body<2, 1, 1, false, false>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
+                                     QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30}, QOut{nullptr, 0, 0, 64, 0}, ln0);
+  chain_sync();
+  gemm_q_body<8, 1, KIND2, false, false, true>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
+                                               nullptr, QConv{0, 0, p.k1, 0, 0, 0},
+                                               QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2);
+  if constexpr (TN3 > 0) {
+    chain_sync();
+    gemm_q_body<(TN3 > 0 ? TN3 : 2), 1, 0, false, false>(
+        p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, TN3 * 32, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
+        QOut{nullptr, 0, 0, TN3 * 32, 0}, ln0);
+  }
+}
+
 // 128 x 256 block on 8 waves (two per SIMD, one block per CU), narrow form: the block owns whole
 // rows of an N = 256 output, LayerNorm runs in the epilogue.  (The wide form with this epilogue --
 // a wave owning whole rows, no statistics exchange -- was built twice: with the 8 x 16 result
@@ -897,7 +987,8 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
                          int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
                          int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real,
                          int ksplit, int ks_slabs) {
-  const QConv g{H, W, Cin, Ho, Wo, stride};
+  const QConv g{H, W, Cin, Ho, Wo, stride,
+                (kind == 1 && Cin > 16) ? (unsigned)(((1ull << 32) + (Cin >> 4) - 1) / (unsigned)(Cin >> 4)) : 0u};
   const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
   if (narrow) N = -N;
   if (n_real <= 0) n_real = N;
@@ -917,11 +1008,16 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (kind == 1 && Cin % 16 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 16 == 0");
   if (kind == 4 && (!a2 || Cin <= 0 || Cin >= K || Cin % 16 != 0))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: two-source rows need a2 and 0 < K1 < K, K1 %% 16 == 0");
+  // 3x3 form: buffer-addressed below 4 GiB of map (a lane's byte offset is 32 bits wide)
+  // (diag variant 5: the 64-bit lane-address form everywhere, for A/B)
+  const bool big3 = kind == 1 && ((M / ((long long)Ho * Wo)) * H * W * Cin * 4 >= (1ll << 32) - 65536 ||
+                                  pave_internal_diag_variant() == 5);
 #define PAVE_QGO(TN_)                                                                               \
   if (kind == 0) {                                                                                  \
     if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
     return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
   }                                                                                                 \
+  if (kind == 1 && big3) return launch_q<TN_, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
   if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
   if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2, ksplit); \
   return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit)
@@ -933,6 +1029,7 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (N % 256 == 0 && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
       !(kind == 0 && W > 0 && W % 256 != 0) && (!out2 || n_split % 256 == 0)) {
     if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 1 && big3) return launch_w<2>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
     if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
     if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
     return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
@@ -965,6 +1062,52 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
+}
+
+template <int KIND2, int TN3>
+static int launch_chain(const ChainArgs& p, hipStream_t st) {
+  auto kern = bottleneck_chain_kernel<KIND2, TN3>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "bottleneck_chain: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + QBM - 1) / QBM)), dim3(256), W_SMEM, st, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const float* b2, float* c2,
+                                         const void* w3_planes, const float* b3, const float* residual,
+                                         const float* a2, int k2, float* out, const void* w1n_planes,
+                                         const float* b1n, float* c1n, int cn, int N, int H, int W,
+                                         void* stream) {
+  if (!c1 || !w2_planes || !c2 || !w3_planes || !out)
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || (long long)N * H * W >= (1ll << 31) / 256)
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: bad sizes (N H W < 2^23 pixels)");
+  if ((a2 != nullptr) != (k2 > 0) || (a2 && (k2 % 32 != 0 || k2 > 960)) || (a2 && residual))
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: a2 [M, k2] (k2 %% 32 == 0) replaces the residual");
+  if ((w1n_planes != nullptr) != (cn > 0) || (w1n_planes && (!c1n || (cn != 64 && cn != 128))))
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: next conv1 with 64 or 128 output channels, or none");
+  if (pave_internal_diag_variant() == 9)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "bottleneck_chain: LDS-DMA generation only");
+  ChainArgs p{c1, static_cast<const uint16_t*>(w2_planes), b2, c2,
+              static_cast<const uint16_t*>(w3_planes), b3, residual, a2, out,
+              static_cast<const uint16_t*>(w1n_planes), b1n, c1n,
+              N * H * W, H, W, 64 + k2, 64};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a2) {
+    if (cn == 64) return launch_chain<4, 2>(p, st);
+    if (cn == 128) return launch_chain<4, 4>(p, st);
+    return launch_chain<4, 0>(p, st);
+  }
+  if (cn == 64) return launch_chain<0, 2>(p, st);
+  if (cn == 128) return launch_chain<0, 4>(p, st);
+  return launch_chain<0, 0>(p, st);
 }
 
 // Stem: w_stem = the 11-slab (c, ky, kx' = kx + 1) planes [11][3][64][16]; requires W % 4 == 0 and

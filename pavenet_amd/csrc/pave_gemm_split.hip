@@ -547,6 +547,8 @@ int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-ro
                          // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never,
                          // 9 = first-generation kernels for every 3-plane form (A/B against
                          // the LDS-DMA generation of pave_gemm_dma.hip, the default),
+                         // 5 = 3x3 form with 64-bit lane addresses (not buffer-addressed),
+                         // 6 = no split-K plan,
                          // 8 = LDS-DMA generation without its wide tile form, 7 = wide
                          // tile form wherever it applies (default: from 512 tiles up)
 

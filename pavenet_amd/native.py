@@ -45,6 +45,7 @@ SIGNATURES = {
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
+    'pave_bottleneck_chain_f32': [_vp] * 8 + [_c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp],
     'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
@@ -52,7 +53,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 11  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 12  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

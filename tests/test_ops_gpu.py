@@ -844,6 +844,89 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     assert torch.equal(torch.isnan(yn[0]).any(0).cpu(), expn)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 19, 27, 64, 64, 1), (1, 33, 21, 48, 256, 2),
+                                                   (3, 9, 11, 128, 128, 1), (2, 8, 8, 16, 36, 1)])
+def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stride):
+    """The 3x3 form reads the map through a buffer resource (out-of-image taps = out-of-range lanes
+    that read zeros); maps of 4 GiB and more take 64-bit lane addresses and a zero chunk (diag
+    variant 5 forces that form).  Same operands, same order: bit-identical, borders, image
+    boundaries inside a tile and a NaN pixel included."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    lib = native.load()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x[0, 1, 0, 0] = float('nan')
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wp = split_conv3x3_weight((torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda())
+    b = torch.randn(Cout, generator=g).cuda()
+    try:
+        lib.pave_diag_gemm_variant(5)
+        flat = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout).clone()
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    buf = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(buf), torch.isnan(flat))
+    assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(flat))
+    assert int(torch.isnan(buf[0]).any(0).sum()) <= 4     # only the windows holding the NaN pixel
+
+
+@pytest.mark.parametrize('form', ['identity_next64', 'identity_inplace_next128', 'downsample_next64',
+                                  'identity_last'])
+def test_bottleneck_chain_equals_separate_launches(form):
+    """pave_bottleneck_chain_f32 (3x3 -> conv3 + identity | downsample -> next conv1 of one
+    128-pixel tile per workgroup, the intermediate rows re-read through L2) must give exactly what
+    the three entry points give launched one after the other, ragged last tile included, and the
+    in-place form (out aliases the identity) too."""
+    from pavenet_amd import ops
+    g = torch.Generator().manual_seed(len(form))
+    dev = 'cuda'
+    N, H, W = 2, 19, 27
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+    def cl(t):
+        return t.contiguous(memory_format=torch.channels_last)
+
+    c1 = cl(torch.relu(rnd(N, 64, H, W)))
+    w2p, b2 = ops.split_conv3x3_weight(rnd(64, 64, 3, 3, scale=0.05)), rnd(64, scale=0.1)
+    down = form.startswith('downsample')
+    k2 = 64 if down else 0
+    w3p, b3 = ops.split_weight_bf16x3(rnd(256, 64 + k2, scale=0.08)), rnd(256, scale=0.1)
+    cn = 0 if form.endswith('last') else (128 if form.endswith('128') else 64)
+    w1np = ops.split_weight_bf16x3(rnd(cn, 256, scale=0.05)) if cn else None
+    b1n = rnd(cn, scale=0.1) if cn else None
+    x_in = cl(rnd(N, 64 if down else 256, H, W))
+
+    # separate launches
+    c2 = ops.conv3x3_split(c1, w2p, b2, stride=1, relu=True)
+    c2rows = c2.permute(0, 2, 3, 1).reshape(-1, 64)
+    xrows = x_in.permute(0, 2, 3, 1).reshape(-1, x_in.shape[1])
+    if down:
+        exp_out = ops.gemm_bf16x3_cat(c2rows, xrows, w3p, b3, None, relu=True)
+    else:
+        exp_out = ops.gemm_bf16x3(c2rows, w3p, b3, xrows, relu=True)
+    exp_c1n = ops.gemm_bf16x3(exp_out, w1np, b1n, None, relu=True) if cn else None
+
+    inplace = 'inplace' in form
+    res = x_in.clone(memory_format=torch.channels_last) if inplace else x_in
+    out, c1n = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=None if down else res,
+                                    a2=x_in if down else None, w1n_planes=w1np, b1n=b1n,
+                                    out=res if inplace else None)
+    torch.cuda.synchronize()
+    if inplace:
+        assert out.data_ptr() == res.data_ptr()
+    assert torch.equal(out.permute(0, 2, 3, 1).reshape(-1, 256), exp_out)
+    if cn:
+        assert torch.equal(c1n.permute(0, 2, 3, 1).reshape(-1, cn), exp_c1n)
+    else:
+        assert c1n is None
+    with pytest.raises(RuntimeError):
+        ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=res, a2=x_in if down else cl(rnd(N, 64, H, W)))
+
+
 @pytest.mark.parametrize('M,K,N', [(700, 96, 48), (333, 192, 96), (129, 384, 192), (1000, 64, 36)])
 def test_gemm_bf16x3_padded_output_width_vs_fp64(M, K, N):
     """Row GEMM with N % 64 != 0 (HRNet fuse-layer 1x1 convolutions 96 -> 48 etc.): planes padded
