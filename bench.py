@@ -148,7 +148,7 @@ def file_git_blob_sha1(path):
     return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
 
 
-# launches of the split-operand MFMA GEMM family (pavenet_amd/csrc/pave_gemm_split.hip)
+# launches of the split-operand MFMA GEMM family (pavenet_amd/csrc/pave_gemm_dma.hip, pave_gemm_split.hip)
 SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided', 'conv7x7_stem',
                    'bottleneck_chain')
 
@@ -425,8 +425,11 @@ def main():
             d[2] += fl
         roofline_mfma = dict(
             bound='mfma',
-            kernel='gemm_bf16x3_kernel_occ2 / _w8 family (pave_gemm_split.hip): every Linear / FFN / '
-                   '1x1, 3x3, 7x7 convolution launch of the step',
+            kernel='gemm_q / gemm_w / gemm_q_ln / bottleneck_chain / stem7x7_q kernels '
+                   '(pave_gemm_dma.hip, the LDS-DMA split GEMM): every Linear / FFN / 1x1, 3x3, 7x7 '
+                   'convolution launch of the step' if args.gemm == 'bf16x3' else
+                   'split-operand GEMM family (pave_gemm_split.hip): every Linear / FFN / 1x1, 3x3, 7x7 '
+                   'convolution launch of the step',
             achieved=round(tot_f / tot_t / 1e12, 1), peak=round(peak, 1), unit='TFLOP/s',
             frac=round(tot_f / tot_t / 1e12 / peak, 4), traffic=None,
             achieved_is='sum of 2*M*N*K over the launches (real K of the stem: 147) / sum of their '
