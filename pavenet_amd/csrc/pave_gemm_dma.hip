@@ -150,7 +150,8 @@ __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const QLn ln,
-    const float* __restrict__ A2 = nullptr) {
+    const float* __restrict__ A2 = nullptr, const int tile_m0 = -1, const int tile_n0 = 0) {
+  // (tile_m0 >= 0: the caller names the tile -- kernels that run several bodies per block)
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
   constexpr int A_STAGE = QBM * 64;          // raw fp32: 128 rows x 64 B
@@ -215,6 +216,7 @@ __device__ __forceinline__ void gemm_q_body(
     const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
     m0 = (lb / ntiles) * QBM;
     n0 = (lb % ntiles) * BN;
+    if (tile_m0 >= 0) m0 = tile_m0, n0 = tile_n0;
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int d = wave + NWAVE * q;
@@ -685,6 +687,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_q_body<8, 1, KIND, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
                                               QLn{nullptr, nullptr, 0.f}, A2);
 }
+// mixed tiles for N % 256 == 128 (the encoder's merged projection, N = 640): the first N / 256 column
+// tiles of a row tile run the wide body, its last 128 columns the narrow one; the blocks of a row
+// tile stay neighbours on one XCD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wn_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const QConv g, const QOut os) {
+  const int nw = N / 256, ntl = nw + 1;
+  const int ttot = ((M + QBM - 1) / QBM) * ntl;
+  const int per = ttot >> 3, rem = ttot & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  const int row = lb / ntl, c = lb - row * ntl;
+  const QLn ln0{nullptr, nullptr, 0.f};
+  if (c < nw)
+    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
+                                             nullptr, row * QBM, c * 256);
+  else
+    gemm_q_body<4, 1, 0, false, false>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
+                                       nullptr, row * QBM, nw * 256);
+}
 // ---------------------------------------------------------------------------
 // ResNet Bottleneck (64-channel stage) from its 3x3 convolution on, chained with the NEXT block's
 // conv1 -- three GEMMs of ONE 128-pixel row tile back to back in one workgroup:
@@ -1033,6 +1056,23 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
     if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
     if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
     return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+  }
+  if (kind == 0 && N % 256 == 128 && N >= 384 && !narrow && !a_bias && dv != 8 && W == 0 && ksplit == 1 &&
+      (((M + QBM - 1) / QBM) * (N / 256 + 1) >= 400 || dv == 7) && (!out2 || n_split % 256 == 0)) {
+    const long long gx = ((M + QBM - 1) / QBM) * (N / 256 + 1);
+    if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_wn: grid too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+        return pave_internal_fail(PAVE_E_LAUNCH, "gemm_wn: cannot raise dynamic LDS limit");
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_wn_kernel, dim3((unsigned)gx), dim3(256), W_SMEM, st, a, w, bias, residual, out,
+                       (int)M, K, N, relu, g, os);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+    return PAVE_OK;
   }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }

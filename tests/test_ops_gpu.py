@@ -1023,7 +1023,7 @@ def test_gemm_generations_are_bit_identical(form):
         assert torch.equal(new, old), float((new - old).abs().max())
 
 
-@pytest.mark.parametrize('form', ['rows', 'rows_res', 'rows_padded', 'rows_k64', 'ex', 'strided',
+@pytest.mark.parametrize('form', ['rows', 'rows_res', 'rows_padded', 'rows_k64', 'ex', 'ex640', 'rows_n384', 'strided',
                                   'conv3x3', 'conv3x3_res', 'cat', 'grouped'])
 def test_gemm_wide_tile_form_is_bit_identical(form):
     """The wide tile form of the LDS-DMA GEMM (a wave owns 32 rows x 256 columns, W fragments read
@@ -1050,10 +1050,14 @@ def test_gemm_wide_tile_form_is_bit_identical(form):
                 assert wp.shape[2] == 512
                 return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True, n_out=n_out)
             return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=(form == 'rows'))
-        if form == 'ex':
-            M, K, N, rows, ns = 901, 256, 768, 53, 256
+        if form in ('ex', 'ex640'):
+            # (N = 640: wide tiles for the first 512 columns, a narrow one for the last 128, one launch)
+            M, K, N, rows, ns = 901, 256, (768 if form == 'ex' else 640), 53, 256
             a, wp, tab = rnd(M, K), ops.split_weight_bf16x3(rnd(N, K, scale=0.05)), rnd(rows, N)
             return lambda: torch.cat(ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=rows, n_split=ns), 1)
+        if form == 'rows_n384':
+            a, wp, b, r = rnd(517, 128), ops.split_weight_bf16x3(rnd(384, 128, scale=0.05)), rnd(384), rnd(517, 384)
+            return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True)
         if form == 'strided':
             x = rnd(2, 128, 17, 23).contiguous(memory_format=torch.channels_last)
             wp, b = ops.split_weight_bf16x3(rnd(256, 128, scale=0.05)), rnd(256)
