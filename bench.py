@@ -309,14 +309,14 @@ def main():
     host_bufs = {}
 
     def to_host(packed, slot):
-        """results on the host, as simple_test returns them; slot >= 0: asynchronous copy into a
-        pinned buffer (the caller waits on the stream's event)"""
-        if slot < 0:
-            return packed.cpu()
+        """results on the host, as simple_test returns them, in a pinned buffer; slot >= 0: the copy
+        is asynchronous (the caller waits on the stream's event)"""
         buf = host_bufs.get(slot)
         if buf is None or buf.shape != packed.shape:
             buf = host_bufs[slot] = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
         buf.copy_(packed, non_blocking=True)
+        if slot < 0:    # single stream: the step ends when its results are on the host (pinned
+            torch.cuda.current_stream().synchronize()   # buffer: no staging copy through pageable memory)
         return buf
 
     def step(slot=-1):
@@ -403,6 +403,7 @@ def main():
         native_dt, _, _ = timed(False)
         set_gemm_mode(args.gemm)
     dt, events, last = timed(True)
+    last = last.clone()     # (the pinned result buffer is reused by later runs)
     ev_steps_main = (min(3, args.steps) if (graphed is None and not args.no_events) else 0)
     pipe_dt = None
     if args.pipeline == 1 and world == 1 and graphed is None and not args.no_native_side:

@@ -143,8 +143,8 @@ class ResNet(BaseModule):
 
     # -- folded inference path ----------------------------------------------
     def _params_key(self):
-        from .bricks import SourceKey
-        return SourceKey(list(self.parameters()) + list(self.buffers()))
+        from .bricks import SourceKey, module_tensors
+        return SourceKey(module_tensors(self))
 
     def _build_folded(self):
         key = self._params_key()

@@ -171,6 +171,21 @@ class SourceKey:
     __hash__ = None
 
 
+def module_tensors(module):
+    """Every parameter and buffer of a module tree, in a fixed order -- what `list(m.parameters()) +
+    list(m.buffers())` holds (without de-duplication), but by walking `_modules / _parameters /
+    _buffers` directly: the generator chain of nn.Module costs ~0.5 ms on a ResNet-50, which sits on
+    the critical path before a step's first kernel launch."""
+    out = []
+    stack = [module]
+    while stack:
+        m = stack.pop()
+        out.extend(t for t in m._parameters.values() if t is not None)
+        out.extend(t for t in m._buffers.values() if t is not None)
+        stack.extend(c for c in m._modules.values() if c is not None)
+    return out
+
+
 def _split_slots(weight):
     """Cache dict that LIVES ON the tensor owning the storage (the Parameter, or the folded-BN
     weight kept in ResNet._folded / on the conv module): it dies with that tensor.  An address is
