@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 12
+#define PAVE_ABI_VERSION 13
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -136,6 +136,17 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
  */
 int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, float* y,
                            long long rows, int C, int relu, void* stream);
+/*
+ * HRNet fuse layer (third_party/mmdetection/mmdet/models/backbones/hrnet.py:197-214:
+ * `y = 0; for j: y += x[j] if i == j else fuse_layers[i][j](x[j])`, `relu(y)`), NHWC fp32, one pass:
+ *   y[n, h, w, :] = act(s0[n, h >> sh0, w >> sh0, :] + s1[...] + s2[...] + s3[...])   (in this order)
+ * source k is a [N, H >> sh_k, W >> sh_k, C] map -- the nearest-neighbour nn.Upsample(scale_factor =
+ * 2^sh_k) that ends the coarser branches' fuse path is folded into the read; s1..s3 may be NULL.
+ * y may alias a source with sh == 0.  C %% 4 == 0, 2^sh_k divides H and W.
+ */
+int pave_fuse_sum_nhwc_f32(const float* s0, int sh0, const float* s1, int sh1, const float* s2, int sh2,
+                           const float* s3, int sh3, float* y, int N, int H, int W, int C, int relu,
+                           void* stream);
 int pave_bias_add_layernorm_f32(const float* x, const float* bias, const float* res,
                                 const float* gamma, const float* beta, float* y, long long rows,
                                 int C, float eps, void* stream);

@@ -635,14 +635,31 @@ class HRModule(nn.Module):
             from . import ops
             x_fuse = []
             for i in range(len(self.fuse_layers)):
-                acc = None      # sum of the (fresh) cross-resolution terms
+                terms = []      # (map, log2 of the nearest-neighbour up-sampling still to apply)
                 for j in range(self.num_branches):
+                    fl = self.fuse_layers[i][j]
                     if j == i:
-                        continue
-                    t = _Folded.seq(self.fuse_layers[i][j], x[j])
-                    acc = t if acc is None else acc.add_(t)
-                # + the branch's own map, ReLU: one pass
-                x_fuse.append(ops.bias_act_rows_(acc, None, x[i], relu=True))
+                        terms.append((x[i], 0))
+                    elif j > i and len(fl) == 3 and isinstance(fl[2], nn.Upsample) \
+                            and fl[2].mode == 'nearest' and fl[2].scale_factor == 2 ** (j - i):
+                        # 1x1 conv + BN at the coarse resolution; the up-sampling is folded
+                        # into the fused sum's read
+                        terms.append((_Folded.conv_bn(x[j], fl[0], fl[1]), j - i))
+                    else:
+                        terms.append((_Folded.seq(fl, x[j]), 0))
+                if len(terms) <= 4 and all(
+                        t.is_contiguous(memory_format=torch.channels_last)
+                        and t.shape[2] << sh == x[i].shape[2] and t.shape[3] << sh == x[i].shape[3]
+                        and t.shape[1] % 4 == 0 for t, sh in terms):
+                    # sum over the branches in the reference's order + ReLU: one pass
+                    x_fuse.append(ops.fuse_sum_nhwc(terms, relu=True))
+                    continue
+                acc = None
+                for (t, sh), j in zip(terms, range(self.num_branches)):
+                    if sh:
+                        t = F.interpolate(t, scale_factor=2 ** sh, mode='nearest')
+                    acc = t if acc is None else acc + t
+                x_fuse.append(F.relu(acc))
             return x_fuse
         x_fuse = []
         for i in range(len(self.fuse_layers)):

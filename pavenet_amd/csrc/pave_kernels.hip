@@ -548,6 +548,46 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
 //                     One wave per row (C <= 1024, C % 4 == 0): float4 loads, two-pass
 //                     mean / variance in registers, wave64 xor-shuffle reductions.
 // ---------------------------------------------------------------------------
+// fuse_sum:           y[n, h, w, :] = act(sum_k src_k[n, h >> s_k, w >> s_k, :]) in the order k = 0 .. 3:
+//                     HRNet's fuse layer (hrnet.py:197-214: y += fuse_layers[i][j](x[j]) over the
+//                     branches, nearest-neighbour up-sampling of the coarser ones, ReLU) as ONE pass
+//                     instead of an up-sampling kernel and an add per term.
+struct FuseSrc {
+  const float* p[4];
+  int sh[4];
+};
+__global__ __launch_bounds__(256) void fuse_sum_kernel(const FuseSrc src, float* __restrict__ y,
+                                                       const long long n4, const int H, const int W,
+                                                       const int c4, const int relu) {
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / c4;
+    const int c = (int)(i - pix * c4);
+    const long long row = pix / W;
+    const int w = (int)(pix - row * W);
+    const long long n = row / H;
+    const int h = (int)(row - n * H);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!src.p[k]) continue;
+      const int sh = src.sh[k];
+      const long long si = ((n * (H >> sh) + (h >> sh)) * (W >> sh) + (w >> sh)) * c4 + c;
+      const float4 t = reinterpret_cast<const float4*>(src.p[k])[si];
+      if (first) {
+        v = t;      // (0 + t == t: the reference starts its sum at 0)
+        first = false;
+      } else {
+        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+      }
+    }
+    if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    y4[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void bias_act_rows_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ res,
@@ -1586,6 +1626,31 @@ int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, 
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(bias_act_rows_kernel, dim3((unsigned)nb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, bias, res, y, n4, C >> 2, relu);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_fuse_sum_nhwc_f32(const float* s0, int sh0, const float* s1, int sh1, const float* s2, int sh2,
+                           const float* s3, int sh3, float* y, int N, int H, int W, int C, int relu,
+                           void* stream) {
+  if (!y || !s0) return fail(PAVE_E_ARG, "fuse_sum: null pointer (the first source is mandatory)");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3))
+    return fail(PAVE_E_ARG, "fuse_sum: bad sizes (C must be a positive multiple of 4)");
+  const float* ps[4] = {s0, s1, s2, s3};
+  const int shs[4] = {sh0, sh1, sh2, sh3};
+  FuseSrc src;
+  for (int k = 0; k < 4; ++k) {
+    src.p[k] = ps[k];
+    src.sh[k] = ps[k] ? shs[k] : 0;
+    if (ps[k] && (shs[k] < 0 || shs[k] > 8 || (H & ((1 << shs[k]) - 1)) || (W & ((1 << shs[k]) - 1))))
+      return fail(PAVE_E_ARG, "fuse_sum: a source's up-sampling factor 2^s must divide H and W (0 <= s <= 8)");
+  }
+  const long long n4 = (long long)N * H * W * (C >> 2);
+  long long nb = (n4 + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(fuse_sum_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, y, n4, H, W, C >> 2, relu);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -19,6 +19,7 @@ SIGNATURES = {
     'pave_ms_deform_attn_forward_f64': [_vp] * 6 + [_c_int] * 8 + [_vp],
     'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp, _vp],
     'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp, _vp],
+    'pave_fuse_sum_nhwc_f32': [_vp, _c_int] * 4 + [_vp] + [_c_int] * 5 + [_vp],
     'pave_bias_act_rows_f32': [_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_bias_add_layernorm_f32': [_vp] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _vp],
     'pave_bias_add_layernorm_pos_f32': [_vp] * 7 + [ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int,
@@ -53,7 +54,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 12  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 13  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

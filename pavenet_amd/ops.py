@@ -301,6 +301,32 @@ def oks_nms(kpts, scores, sigmas, thresh):
     return keep, order
 
 
+def fuse_sum_nhwc(terms, relu=True):
+    """HRNet fuse layer in one pass (pave_fuse_sum_nhwc_f32): terms = [(map, shift), ...] (1..4), map
+    [N, C, H >> shift, W >> shift] fp32 channels_last; returns relu(sum of the maps, the coarser ones
+    read through a nearest-neighbour up-sampling by 2^shift) [N, C, H, W] channels_last, summed in
+    the order given (hrnet.py:197-214)."""
+    lib = native.load()
+    _require(1 <= len(terms) <= 4, 'fuse_sum_nhwc: 1..4 terms')
+    t0, s0 = terms[0]
+    N, C = t0.shape[0], t0.shape[1]
+    H, W = t0.shape[2] << s0, t0.shape[3] << s0
+    args = []
+    for t, sh in terms:
+        _require(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4
+                 and t.is_contiguous(memory_format=torch.channels_last)
+                 and tuple(t.shape) == (N, C, H >> sh, W >> sh) and (H >> sh) << sh == H
+                 and (W >> sh) << sh == W,
+                 'fuse_sum_nhwc: terms [N, C, H >> s, W >> s] fp32 channels_last')
+        args += [t.data_ptr(), int(sh)]
+    args += [None, 0] * (4 - len(terms))
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=t0.device)
+    with torch.cuda.device(t0.device), _Timed('fuse_sum'):
+        st = lib.pave_fuse_sum_nhwc_f32(*args, y.data_ptr(), N, H, W, C, int(bool(relu)), _stream_ptr())
+    native.check(st, 'fuse_sum_nhwc')
+    return y.permute(0, 3, 1, 2)
+
+
 def bias_act_rows_(x, bias=None, res=None, relu=True):
     """In place: x[r, c] = act(x[r, c] + bias[c] + res[r, c]) over the last (channel) dim.
     `x` must be dense with channels innermost (token matrix, or an NHWC / channels_last map)."""

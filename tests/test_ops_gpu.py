@@ -844,6 +844,28 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     assert torch.equal(torch.isnan(yn[0]).any(0).cpu(), expn)
 
 
+@pytest.mark.parametrize('shifts', [(0,), (0, 1), (1, 0, 2), (0, 0, 1, 3), (2, 1, 0, 0)])
+def test_fuse_sum_nhwc_equals_upsample_add_relu(shifts):
+    """pave_fuse_sum_nhwc_f32 (HRNet fuse layer, hrnet.py:197-214): the sum over the branches in the
+    reference's order, the coarser terms read through a nearest-neighbour up-sampling, + ReLU, in
+    one pass -- bit-identical to F.interpolate + add + relu."""
+    from pavenet_amd.ops import fuse_sum_nhwc
+    g = torch.Generator().manual_seed(sum(shifts) + len(shifts))
+    N, C, H, W = 2, 48, 16, 24
+    terms = [(torch.randn(N, C, H >> s, W >> s, generator=g).cuda().contiguous(
+        memory_format=torch.channels_last), s) for s in shifts]
+    y = 0
+    for t, s in terms:
+        y = y + (torch.nn.functional.interpolate(t, scale_factor=2 ** s, mode='nearest') if s else t)
+    exp = torch.relu(y)
+    out = fuse_sum_nhwc(terms, relu=True)
+    assert out.is_contiguous(memory_format=torch.channels_last) and tuple(out.shape) == (N, C, H, W)
+    assert torch.equal(out, exp)
+    assert torch.equal(fuse_sum_nhwc(terms, relu=False), y)
+    with pytest.raises(RuntimeError):
+        fuse_sum_nhwc([(terms[0][0], terms[0][1]), (terms[0][0][:, :, :-1], 0)])
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 19, 27, 64, 64, 1), (1, 33, 21, 48, 256, 2),
                                                    (3, 9, 11, 128, 128, 1), (2, 8, 8, 16, 36, 1)])
 def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stride):
