@@ -670,8 +670,10 @@ __device__ __forceinline__ void gemm_q_body(
   }
 }
 
+// (64-column tiles, TN = 2: 136 VGPRs and 42 KB of LDS -- three blocks per CU; these launches are
+// issue-bound, not MFMA-bound, and take the extra wave per SIMD)
 template <int TN, int KIND, bool ABIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2))) void gemm_q_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const float* __restrict__ A2) {
