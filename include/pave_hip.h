@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 13
+#define PAVE_ABI_VERSION 14
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -383,6 +383,8 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
  * Bottleneck.forward: conv2 + bn2 + relu -> conv3 + bn3 -> + identity | downsample(x) -> relu; then
  * the following block's conv1 + bn1 + relu), BatchNorms folded, NHWC fp32, M = N H W pixels:
  *   c2  = relu(conv3x3_pad1(c1 [N, H, W, 64]; w2_planes) + b2)            -> c2  [M, 64] (scratch)
+ *         c1 == NULL and w2_planes == NULL: the launch starts at conv3 and c2 [M, 64] is its INPUT
+ *         (the 3x3 -- pave_conv3x3_split_f32 -- was a launch of its own)
  *   out = relu([c2 | a2] @ W3^T + b3 + residual)                          -> out [M, 256]
  *         a2 [M, k2] (k2 %% 32 == 0): the block input of a stride-1 downsample block, W3 = the
  *         [256, 64 + k2] row-concatenated conv3 | downsample weight, b3 = both biases; else

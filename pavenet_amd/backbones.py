@@ -121,6 +121,9 @@ class ResNet(BaseModule):
         # 64-channel stage (layer1) in the exact split mode: one launch per Bottleneck from its 3x3
         # on, chained with the next block's conv1 (ops.bottleneck_chain); attribute = A/B switch
         self.chain_stage64 = True
+        # ... with the 3x3 as a launch of its own (three blocks per CU) and the chain from conv3 on
+        # ('tail'), or the 3x3 as the chain's first phase ('full'); measured: see DESIGN.md 4.2
+        self.chain_mode = 'tail'
         # 3x3 convolutions: MIOpen's searched fp32 kernels are 10-30 % faster than the
         # hand-written MFMA implicit GEMM (tools/bench_conv.py) but NOT run-to-run deterministic
         # (tools/debug_determinism.py); True routes them through pave_conv3x3_nhwc_f32
@@ -256,19 +259,23 @@ class ResNet(BaseModule):
             nxt = f[(name, bi + 1, 'conv1')] if bi + 1 < len(blocks) else next_conv1
             wnp = _split_weight(nxt[0].flatten(1)) if nxt is not None else None
             bnx = nxt[1] if nxt is not None else None
+            if self.chain_mode == 'tail':
+                y = ops.conv3x3_split(c1, split_conv_weight(w2), b2, stride=1, relu=True)
+                head = dict(c1=None, w2_planes=None, b2=None, c2=y)
+            else:
+                head = dict(c1=c1, w2_planes=split_conv_weight(w2), b2=b2)
             if blk.downsample is not None:
                 tail = f[(name, bi, 'tail_ds_kn')]     # [W3; Wd] as [K, N], b3 + bd
                 w3p = _split_cached(tail[0], 'tail_cat', lambda planes: ops.split_weight_bf16x3(
                     tail[0].t().contiguous(), planes))
-                out, c1 = ops.bottleneck_chain(c1, split_conv_weight(w2), b2, w3p, tail[1], a2=x,
-                                               w1n_planes=wnp, b1n=bnx)
+                out, c1 = ops.bottleneck_chain(w3_planes=w3p, b3=tail[1], a2=x, w1n_planes=wnp,
+                                               b1n=bnx, **head)
             else:
                 # blocks after the first overwrite the previous block's output (a temporary)
                 res = out if out is not None else x
-                out, c1 = ops.bottleneck_chain(c1, split_conv_weight(w2), b2,
-                                               _split_weight(w3.flatten(1)), b3, residual=res,
-                                               w1n_planes=wnp, b1n=bnx,
-                                               out=res if out is not None else None)
+                out, c1 = ops.bottleneck_chain(w3_planes=_split_weight(w3.flatten(1)), b3=b3,
+                                               residual=res, w1n_planes=wnp, b1n=bnx,
+                                               out=res if out is not None else None, **head)
         return out, c1
 
     def _bottleneck_gemm(self, blk, x, f, name, bi, inplace_identity=False, c1=None):

@@ -739,21 +739,32 @@ __device__ __forceinline__ void chain_sync() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-template <int KIND2, int TN3>
+// HAS_A = false: the launch starts at conv3 (the 3x3 was a launch of its own: at three blocks per CU
+// the 64-column-tile 3x3 runs faster alone than as the first phase of a two-blocks-per-CU chain);
+// CN = outputs of the next conv1 (0: none; 64 | 128: narrow form)
+template <bool HAS_A, int KIND2, int CN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_chain_kernel(
     const ChainArgs p) {
   const QLn ln0{nullptr, nullptr, 0.f};
-  gemm_q_body<2, 1, 1, false, false>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
-                                     QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30}, QOut{nullptr, 0, 0, 64, 0}, ln0);
-  chain_sync();
+  // the block's row tile (XCD-aware order over the row tiles), the same for every body
+  const int ttot = (p.M + QBM - 1) / QBM;
+  const int per = ttot >> 3, rem = ttot & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tm0 = (xcd * per + (xcd < rem ? xcd : rem) + idx) * QBM;
+  if constexpr (HAS_A) {
+    gemm_q_body<2, 1, 1, false, false>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
+                                       QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30},
+                                       QOut{nullptr, 0, 0, 64, 0}, ln0, nullptr, tm0, 0);
+    chain_sync();
+  }
   gemm_q_body<8, 1, KIND2, false, false, true>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
                                                nullptr, QConv{0, 0, p.k1, 0, 0, 0},
-                                               QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2);
-  if constexpr (TN3 > 0) {
+                                               QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2, tm0, 0);
+  if constexpr (CN > 0) {
     chain_sync();
-    gemm_q_body<(TN3 > 0 ? TN3 : 2), 1, 0, false, false>(
-        p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, TN3 * 32, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
-        QOut{nullptr, 0, 0, TN3 * 32, 0}, ln0);
+    gemm_q_body<(CN > 0 ? CN / 32 : 2), 1, 0, false, false>(
+        p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
+        QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0, 0);
   }
 }
 
@@ -1106,9 +1117,9 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   return PAVE_OK;
 }
 
-template <int KIND2, int TN3>
+template <bool HAS_A, int KIND2, int CN>
 static int launch_chain(const ChainArgs& p, hipStream_t st) {
-  auto kern = bottleneck_chain_kernel<KIND2, TN3>;
+  auto kern = bottleneck_chain_kernel<HAS_A, KIND2, CN>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1127,10 +1138,11 @@ extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes,
                                          const float* a2, int k2, float* out, const void* w1n_planes,
                                          const float* b1n, float* c1n, int cn, int N, int H, int W,
                                          void* stream) {
-  if (!c1 || !w2_planes || !c2 || !w3_planes || !out)
-    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: null pointer");
-  if (N <= 0 || H <= 0 || W <= 0 || (long long)N * H * W >= (1ll << 31) / 256)
-    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: bad sizes (N H W < 2^23 pixels)");
+  if (!c2 || !w3_planes || !out || (c1 != nullptr) != (w2_planes != nullptr))
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: null pointer (c1 and w2_planes: both or neither)");
+  // (the 3x3 body addresses the c1 map through a buffer resource: below 4 GiB)
+  if (N <= 0 || H <= 0 || W <= 0 || (long long)N * H * W * 64 * 4 >= (1ll << 32) - 65536)
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: bad sizes (the c1 map must stay below 4 GiB)");
   if ((a2 != nullptr) != (k2 > 0) || (a2 && (k2 % 32 != 0 || k2 > 960)) || (a2 && residual))
     return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: a2 [M, k2] (k2 %% 32 == 0) replaces the residual");
   if ((w1n_planes != nullptr) != (cn > 0) || (w1n_planes && (!c1n || (cn != 64 && cn != 128))))
@@ -1142,14 +1154,18 @@ extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes,
               static_cast<const uint16_t*>(w1n_planes), b1n, c1n,
               N * H * W, H, W, 64 + k2, 64};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a2) {
-    if (cn == 64) return launch_chain<4, 2>(p, st);
-    if (cn == 128) return launch_chain<4, 4>(p, st);
-    return launch_chain<4, 0>(p, st);
-  }
-  if (cn == 64) return launch_chain<0, 2>(p, st);
-  if (cn == 128) return launch_chain<0, 4>(p, st);
-  return launch_chain<0, 0>(p, st);
+#define PAVE_CHAIN_GO(HA)                                              \
+  if (a2) {                                                            \
+    if (cn == 64) return launch_chain<HA, 4, 64>(p, st);               \
+    if (cn == 128) return launch_chain<HA, 4, 128>(p, st);             \
+    return launch_chain<HA, 4, 0>(p, st);                              \
+  }                                                                    \
+  if (cn == 64) return launch_chain<HA, 0, 64>(p, st);                 \
+  if (cn == 128) return launch_chain<HA, 0, 128>(p, st);               \
+  return launch_chain<HA, 0, 0>(p, st)
+  if (c1) { PAVE_CHAIN_GO(true); }
+  PAVE_CHAIN_GO(false);
+#undef PAVE_CHAIN_GO
 }
 
 // Stem: w_stem = the 11-slab (c, ky, kx' = kx + 1) planes [11][3][64][16]; requires W % 4 == 0 and

@@ -865,21 +865,25 @@ def split_conv3x3_weight(weight, planes=3):
 
 
 def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w1n_planes=None,
-                     b1n=None, out=None):
+                     b1n=None, out=None, c2=None):
     """One launch for a 64-channel ResNet Bottleneck from its 3x3 convolution on, chained with the
     next block's conv1 (pave_bottleneck_chain_f32):  c1 [N, 64, H, W] channels_last ->
     out = relu(conv3(relu(conv3x3(c1) + b2)) (+ downsample(a2)) + b3 + residual) [N, 256, H, W] and
     c1n = relu(conv1_next(out) + b1n) [N, cn, H, W] (None without w1n_planes).  residual
     [N, 256, H, W] channels_last (may be given as `out`: in place) or a2 [N, k2, H, W] channels_last
-    with w3_planes = the planes of the [256, 64 + k2] concatenated weight."""
+    with w3_planes = the planes of the [256, 64 + k2] concatenated weight.
+    c1 = w2_planes = None with c2 [N, 64, H, W] channels_last given: the launch starts at conv3
+    (the 3x3 was run by conv3x3_split)."""
     lib = native.load()
-    _require(c1.is_cuda and c1.dtype == torch.float32 and c1.dim() == 4 and c1.shape[1] == 64
-             and c1.is_contiguous(memory_format=torch.channels_last),
-             'bottleneck_chain: c1 [N, 64, H, W] fp32 channels_last')
-    N, _, H, W = c1.shape
+    tail_only = c1 is None
+    src = c2 if tail_only else c1
+    _require(src is not None and src.is_cuda and src.dtype == torch.float32 and src.dim() == 4
+             and src.shape[1] == 64 and src.is_contiguous(memory_format=torch.channels_last),
+             'bottleneck_chain: c1 (or c2) [N, 64, H, W] fp32 channels_last')
+    _require((w2_planes is None) == tail_only, 'bottleneck_chain: c1 and w2_planes go together')
+    N, _, H, W = src.shape
     M = N * H * W
-    for t, nm in ((w2_planes, 'w2_planes'), (w3_planes, 'w3_planes')):
-        _dev(t, nm, torch.int16)
+    _dev(w3_planes, 'w3_planes', torch.int16)
     k2 = 0
     if a2 is not None:
         _require(residual is None and a2.is_cuda and a2.dtype == torch.float32 and a2.dim() == 4
@@ -887,7 +891,9 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
                  and a2.is_contiguous(memory_format=torch.channels_last),
                  'bottleneck_chain: a2 [N, k2, H, W] channels_last, no residual')
         k2 = a2.shape[1]
-    _require(tuple(w2_planes.shape) == (36, 3, 64, 16), 'bottleneck_chain: w2_planes [36, 3, 64, 16]')
+    if not tail_only:
+        _dev(w2_planes, 'w2_planes', torch.int16)
+        _require(tuple(w2_planes.shape) == (36, 3, 64, 16), 'bottleneck_chain: w2_planes [36, 3, 64, 16]')
     _require(tuple(w3_planes.shape) == ((64 + k2) // 16, 3, 256, 16),
              'bottleneck_chain: w3_planes [(64 + k2)/16, 3, 256, 16]')
     if residual is not None:
@@ -906,18 +912,20 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
             _dev(b, 'bias', torch.float32)
             _require(b.numel() == n, 'bottleneck_chain: bias sizes 64 / 256 / cn')
     if out is None:
-        out = torch.empty((N, H, W, 256), dtype=torch.float32, device=c1.device).permute(0, 3, 1, 2)
+        out = torch.empty((N, H, W, 256), dtype=torch.float32, device=src.device).permute(0, 3, 1, 2)
     else:
         _require(out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (N, 256, H, W)
                  and out.is_contiguous(memory_format=torch.channels_last),
                  'bottleneck_chain: out [N, 256, H, W] channels_last')
-    c2 = torch.empty((M, 64), dtype=torch.float32, device=c1.device)
-    c1n = torch.empty((N, H, W, cn), dtype=torch.float32, device=c1.device) if cn else None
+    if not tail_only:
+        c2 = torch.empty((M, 64), dtype=torch.float32, device=src.device)
+    c1n = torch.empty((N, H, W, cn), dtype=torch.float32, device=src.device) if cn else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    flops = 2 * M * (576 * 64 + (64 + k2) * 256 + 256 * cn)
-    with torch.cuda.device(c1.device), _Timed('bottleneck_chain', flops, (M, 64, 256, cn, f'k2={k2}')):
+    flops = 2 * M * ((0 if tail_only else 576 * 64) + (64 + k2) * 256 + 256 * cn)
+    with torch.cuda.device(src.device), _Timed('bottleneck_chain', flops,
+                                               (M, 64, 256, cn, f'k2={k2}', 'tail' if tail_only else '')):
         st = lib.pave_bottleneck_chain_f32(
-            c1.data_ptr(), w2_planes.data_ptr(), ptr(b2), c2.data_ptr(), w3_planes.data_ptr(), ptr(b3),
+            ptr(c1), ptr(w2_planes), ptr(b2), c2.data_ptr(), w3_planes.data_ptr(), ptr(b3),
             ptr(residual), ptr(a2), k2, out.data_ptr(), ptr(w1n_planes), ptr(b1n), ptr(c1n), cn,
             N, H, W, _stream_ptr())
     native.check(st, 'bottleneck_chain')

@@ -895,7 +895,8 @@ def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stri
 
 
 @pytest.mark.parametrize('form', ['identity_next64', 'identity_inplace_next128', 'downsample_next64',
-                                  'identity_last'])
+                                  'identity_last', 'tail_identity_inplace_next64', 'tail_downsample_next128',
+                                  'tail_identity_last'])
 def test_bottleneck_chain_equals_separate_launches(form):
     """pave_bottleneck_chain_f32 (3x3 -> conv3 + identity | downsample -> next conv1 of one
     128-pixel tile per workgroup, the intermediate rows re-read through L2) must give exactly what
@@ -914,7 +915,7 @@ def test_bottleneck_chain_equals_separate_launches(form):
 
     c1 = cl(torch.relu(rnd(N, 64, H, W)))
     w2p, b2 = ops.split_conv3x3_weight(rnd(64, 64, 3, 3, scale=0.05)), rnd(64, scale=0.1)
-    down = form.startswith('downsample')
+    down = 'downsample' in form
     k2 = 64 if down else 0
     w3p, b3 = ops.split_weight_bf16x3(rnd(256, 64 + k2, scale=0.08)), rnd(256, scale=0.1)
     cn = 0 if form.endswith('last') else (128 if form.endswith('128') else 64)
@@ -934,9 +935,14 @@ def test_bottleneck_chain_equals_separate_launches(form):
 
     inplace = 'inplace' in form
     res = x_in.clone(memory_format=torch.channels_last) if inplace else x_in
-    out, c1n = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=None if down else res,
-                                    a2=x_in if down else None, w1n_planes=w1np, b1n=b1n,
-                                    out=res if inplace else None)
+    if form.startswith('tail'):    # the chain from conv3 on, behind a separately run 3x3
+        out, c1n = ops.bottleneck_chain(None, None, None, w3p, b3, residual=None if down else res,
+                                        a2=x_in if down else None, w1n_planes=w1np, b1n=b1n,
+                                        out=res if inplace else None, c2=c2)
+    else:
+        out, c1n = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=None if down else res,
+                                        a2=x_in if down else None, w1n_planes=w1np, b1n=b1n,
+                                        out=res if inplace else None)
     torch.cuda.synchronize()
     if inplace:
         assert out.data_ptr() == res.data_ptr()
