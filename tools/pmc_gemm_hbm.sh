@@ -18,7 +18,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob('$R/gpurun_out/$OUT/p*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        if any(t in r['Kernel_Name'] for t in ('gemm_bf16x3', 'gemm_q_', 'gemm_w_')):
+        if any(t in r['Kernel_Name'] for t in ('gemm_bf16x3', 'gemm_q_', 'gemm_w')):
             agg[r.get('Grid_Size', '?')][r['Counter_Name']].append(float(r['Counter_Value']))
 for grid, d in agg.items():
     rd = sum(sorted(d['FETCH_SIZE'])[1:-1]) / max(1, len(d['FETCH_SIZE']) - 2) * 1024 * 2 / 1e9 if d.get('FETCH_SIZE') else float('nan')
