@@ -1,6 +1,10 @@
-"""Experiment helper: builds variants of libpave_hip.so that differ only in -D switches of
-pave_gemm_split.hip (pavenet_amd/lib/variants/libpave_hip_<name>.so; the other two translation
-units are taken from the regular build).   python tools/build_variants.py name:-DX=1,-DY=2 ..."""
+"""Experiment helper: builds variants of libpave_hip.so that differ only in -D switches of ONE GEMM
+translation unit (pavenet_amd/lib/variants/libpave_hip_<name>.so; the other translation units are
+taken from the regular build).  Flags containing PAVE_Q_ rebuild pave_gemm_dma.hip (the LDS-DMA
+generation), any other flag pave_gemm_split.hip.  The timing-only ablations quoted in DESIGN.md 4.2
+were temporary `#if defined(PAVE_Q_ABL)` edits of the kernel body built this way and timed with
+tools/gemm_ab.py; they are not kept in the source.
+    python tools/build_variants.py name:-DX=1,-DY=2 ..."""
 import os
 import subprocess
 import sys

@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU idle gaps inside one steady-state step of the default bench.py workload (rocprofv3 kernel trace
+# -> tools/trace_gaps.py).    usage (on the GPU box): tools/profile_gaps.sh   -> gpurun_out/gaps.txt
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_gaps
