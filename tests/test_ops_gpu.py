@@ -1117,6 +1117,48 @@ def test_gemm_wide_tile_form_is_bit_identical(form):
     assert torch.equal(wide, narrow), float((wide - narrow).abs().max())
 
 
+@pytest.mark.parametrize('seed', range(16))
+def test_gemm_forms_random_shapes_bit_identical(seed):
+    """Property test over random shapes and epilogue options: the first-generation kernel (diag
+    variant 9), the LDS-DMA generation with narrow tiles only (8) and with wide / mixed tiles forced
+    wherever they apply (7) and the default dispatch must agree bit for bit -- single partial tiles,
+    exact multiples of the 128-row tile, K = 64, two outputs and the row-periodic residual table
+    included."""
+    from pavenet_amd import native, ops
+    lib = native.load()
+    rs = np.random.RandomState(1000 + seed)
+    g = torch.Generator().manual_seed(2000 + seed)
+    M = int(rs.choice([1, 31, 128, 129, 256, 1000, 2047, 2560]))
+    K = int(rs.choice([64, 128, 192, 320, 1024]))
+    N = int(rs.choice([64, 128, 256, 384, 512, 640, 768]))
+    use_res, use_bias, relu = bool(rs.randint(2)), bool(rs.randint(2)), bool(rs.randint(2))
+    table = use_res and N >= 256 and bool(rs.randint(2))
+    nsplit = 256 if (N >= 512 and rs.randint(2)) else 0
+    a = torch.randn(M, K, generator=g).cuda()
+    wp = ops.split_weight_bf16x3((torch.randn(N, K, generator=g) * 0.05).cuda())
+    b = torch.randn(N, generator=g).cuda() if use_bias else None
+    rows = int(rs.choice([7, 53, 200])) if table else 0
+    r = torch.randn(rows if table else M, N, generator=g).cuda() if use_res else None
+
+    def run():
+        if table or nsplit:
+            o1, o2 = ops.gemm_bf16x3_ex(a, wp, b, r, residual_rows=rows, n_split=nsplit, relu=relu)
+            return o1 if o2 is None else torch.cat([o1, o2], 1)
+        return ops.gemm_bf16x3(a, wp, b, r, relu=relu)
+
+    outs = {}
+    try:
+        for v in (9, 8, 7, 0):
+            lib.pave_diag_gemm_variant(v)
+            outs[v] = run().clone()
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    torch.cuda.synchronize()
+    for v in (8, 7, 0):
+        assert torch.equal(outs[v], outs[9]), (seed, M, K, N, v, float((outs[v] - outs[9]).abs().max()))
+    assert torch.isfinite(outs[0]).all()
+
+
 @pytest.mark.parametrize('M,K,N,rows,nsplit', [(1000, 256, 640, 125, 256), (777, 64, 384, 0, 128),
                                                (300, 128, 256, 7, 0), (513, 256, 512, 0, 256)])
 def test_gemm_bf16x3_ex_row_table_and_two_outputs(M, K, N, rows, nsplit):
