@@ -149,6 +149,21 @@ class ResNet(BaseModule):
         from .bricks import SourceKey, module_tensors
         return SourceKey(module_tensors(self))
 
+    def _stem_folded(self):
+        """The folded stem (weight, bias), validated on its own five tensors: a step's first kernel
+        launch does not wait for the walk over the whole backbone (_build_folded runs after it)."""
+        from .bricks import SourceKey
+        bn = self.bn1
+        key = SourceKey([self.conv1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var])
+        hit = self.__dict__.get('_stem_cache')
+        if hit is None or hit[0] != key:
+            mf = torch.channels_last if self.channels_last else torch.contiguous_format
+            with torch.no_grad():
+                hit = (key, tuple(t.contiguous(memory_format=mf) if t.dim() == 4 else t
+                                  for t in _fold(self.conv1, self.bn1)))
+            self.__dict__['_stem_cache'] = hit
+        return hit[1]
+
     def _build_folded(self):
         key = self._params_key()
         if self._folded is not None and self._folded[0] == key:
@@ -395,10 +410,9 @@ class ResNet(BaseModule):
         if self.input_type == 'mul_frames' and x.dim() == 5:
             x = x.flatten(0, 1)  # [B, T, C, H, W] -> [B*T, C, H, W]  (resnet.py:634-639)
         assert not self.training, 'pavenet_amd.ResNet is an inference (frozen BN) backbone'
-        f = self._build_folded()
         gemm_path = (self.channels_last and x.is_cuda and x.dtype == torch.float32
                      and self.style == 'pytorch')
-        w, b = f['stem']
+        w, b = self._stem_folded()
         y = self._stem_split(x, w) if gemm_path else None             # reads the NCHW batch as is
         if y is None and self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -410,6 +424,7 @@ class ResNet(BaseModule):
             x = ops.bias_relu_maxpool_nhwc(y, b)
         else:
             x = self.maxpool(F.relu_(F.conv2d(x, w, b, 2, 3)))
+        f = self._build_folded()     # (validated while the stem runs)
         outs = []
         pre_c1 = None       # the coming block's conv1 output, when the previous launch chained it
         for i, name in enumerate(self.res_layers):
