@@ -465,7 +465,7 @@ class VideoPoseTransformerMulFrames(Transformer):
         if memory_padding_mask is not None:
             output_memory = output_memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
         output_memory = output_memory.masked_fill(~valid, float(0))
-        output_memory = self.enc_output_norm(self.enc_output(output_memory))
+        output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
         return output_memory, output_proposals
 
     @staticmethod

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 # Tests that pick their own GEMM mode (or run the model in a child process) are not doubled.
 _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_within_half_pixel',
+             'test_forward_is_the_same_from_the_first_call_and_reads_no_stale_memory',
              'test_frame_sharded_two_ranks', 'test_t15_frame_sharded_vs_oracle',
              'test_bench_multi_rank_code_path_on_one_gpu', 'test_split_caches_follow_reloaded_weights',
              'test_derived_operand_caches_follow_reloaded_weights',
@@ -748,6 +749,56 @@ def test_bench_batch_full_size_t7_b4_vs_oracle():
     assert free.shape[0] == ek.shape[0], (free.shape, ek.shape)
     for pose in ek[..., :2]:
         assert float((free[..., :2] - pose).abs().amax(dim=(1, 2)).min()) <= 1e-3
+
+
+def test_forward_is_the_same_from_the_first_call_and_reads_no_stale_memory():
+    """The size-gated fast paths and the derived-operand caches must not change a value: at a batch
+    large enough to take every one of them (T = 7 x 2 clips, 800x1344, headline GEMM mode) the FIRST
+    forward of a fresh model (every cache cold) is bit-identical to the second, and to a third run
+    after the allocator's free memory was filled with NaN (a kernel reading memory it did not write
+    -- split-K workspace, chain scratch, LDS-DMA tails -- would show).  Found in round 3: the cold
+    path of the two-stage proposals ran Linear + LayerNorm as two torch ops, the cached path as the
+    fused kernel; near-tie top-k selections then differed between the first and later forwards."""
+    from pavenet_amd import bricks, tuning
+    from pavenet_amd.models import build_model, videopose_r50_cfg
+    from pavenet_amd.weights import init_random_weights
+    T, B, H, W = 7, 2, 800, 1344
+    m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=20))
+    init_random_weights(m, seed=0)
+    m = m.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(99)
+    img = torch.randn(B, T, 3, H, W, device='cuda', generator=g)
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))
+             for _ in range(B)]
+
+    def fwd():
+        with torch.no_grad():
+            res = m.forward_device(img, metas)
+        return {k: v.clone() for k, v in res.items() if torch.is_tensor(v)}
+
+    def poison():
+        torch.cuda.synchronize()
+        blocks = []
+        for sz in (4 << 30, 2 << 30, 1 << 30, 1 << 30, 512 << 20, 256 << 20, 128 << 20, 64 << 20,
+                   32 << 20, 16 << 20, 8 << 20, 4 << 20, 2 << 20, 1 << 20):
+            blocks.append(torch.full((sz // 4,), float('nan'), dtype=torch.float32, device='cuda'))
+        torch.cuda.synchronize()
+        del blocks
+
+    bricks.set_gemm_mode('bf16x3')
+    tuning.use_tuned_gemms()
+    try:
+        cold = fwd()
+        warm = fwd()
+        poison()
+        again = fwd()
+    finally:
+        tuning.disable()
+        bricks.set_gemm_mode('native')
+    for k in cold:
+        assert torch.equal(cold[k], warm[k]), f'{k}: the first forward differs from the second'
+        assert torch.equal(warm[k], again[k]), f'{k}: result depends on the contents of free memory'
+        assert not torch.isnan(again[k].float()).any(), k
 
 
 def test_neck_eval_with_grad_keeps_the_differentiable_path():
