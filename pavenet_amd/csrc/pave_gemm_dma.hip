@@ -987,17 +987,17 @@ int launch_w(const float* a, const uint16_t* w, const float* bias, const float* 
 
 // Split-K plan of an [M, Kp] x [Np, Kp] product: how many parts the K axis is cut into (1 = none)
 // and the slabs per part.  Worth it when the tiles alone leave most of the 512 block slots of the
-// chip empty and K is long; every part gets an even number >= 32 of slabs.
+// chip empty and K is very long; every part gets an even number >= 64 of slabs.
 void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks_slabs) {
   const long long tiles = ((M + QBM - 1) / QBM) * (Np % 256 == 0 ? Np / 256 : (Np + 127) / 128);
   const int nsl = Kp / 16;
   *ksplit = 1, *ks_slabs = 0;
-  if (tiles >= 200 || nsl < 128 || pave_internal_diag_variant() == 6) return;
-  int parts = (int)(480 / tiles);
-  if (parts > 8) parts = 8;
-  if (parts > nsl / 32) parts = nsl / 32;
-  if (parts < 2) return;
-  int per = ((nsl + parts - 1) / parts + 1) & ~1;
+  // Few tiles and a very long K (K >= 8192: the ChannelMapper's 3x3 on C5).  ALWAYS 8 parts: the
+  // summation order of an output must not depend on the batch size (a clip's values are the same
+  // alone and inside a batch, as long as the batch stays under the tile threshold).
+  if (tiles >= 200 || nsl < 512 || pave_internal_diag_variant() == 6) return;
+  int per = ((nsl + 7) / 8 + 1) & ~1;
+  int parts;
   for (;; per += 2) {   // the last part keeps >= 4 slabs (nsl and per are even: its size is even)
     parts = (nsl + per - 1) / per;
     if (nsl - (parts - 1) * per >= 4) break;
