@@ -303,7 +303,13 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const int head = lb & 7;
   const int tiles = p.nx * p.ny;
   const int tile = (lb >> 3) % tiles, frame = (lb >> 3) / tiles;
-  const int ty = tile / p.nx, tx = tile - ty * p.nx;
+  // tiles in bands of 4 tile rows, column-major inside a band: the ~12 tiles an XCD has in flight
+  // form a 4 x 3 patch, so the halo rows shared with the tiles above / below are still in its L2
+  // (row-major order puts vertical neighbours 21 tiles = 8.7 MB of windows apart)
+  constexpr int kBand = 4;
+  const int band = tile / (kBand * p.nx), in_band = tile - band * (kBand * p.nx);
+  const int band_rows = min(kBand, p.ny - band * kBand);
+  const int tx = in_band / band_rows, ty = band * kBand + (in_band - tx * band_rows);
 
   // ---- which query this pair is: waves 0-3 level 0, wave 4 level 1, wave 5 levels 2, 3
   int qy, qx, qH, qW, qS;
