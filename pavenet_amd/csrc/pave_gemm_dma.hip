@@ -1087,6 +1087,13 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
     if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
     return PAVE_OK;
   }
+  // 65..96 real outputs in 128-row planes (HRNet's 96-channel branch): three column tiles instead of four
+  if (N == 128 && n_real <= 96 && n_real > 64 && !narrow && !out2 && pave_internal_diag_variant() != 8 &&
+      ksplit == 1 && (kind == 1 || kind == 0) && !a_bias) {
+    if (kind == 1 && big3) return launch_q<3, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    if (kind == 1) return launch_q<3, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    return launch_q<3, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+  }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO

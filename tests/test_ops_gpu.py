@@ -1055,7 +1055,8 @@ def test_gemm_generations_are_bit_identical(form):
         assert torch.equal(new, old), float((new - old).abs().max())
 
 
-@pytest.mark.parametrize('form', ['rows', 'rows_res', 'rows_padded', 'rows_k64', 'ex', 'ex640', 'rows_n384', 'strided',
+@pytest.mark.parametrize('form', ['rows', 'rows_res', 'rows_padded', 'rows_k64', 'ex', 'ex640', 'rows_n384', 'rows_n96',
+                                  'conv3x3_n96', 'strided',
                                   'conv3x3', 'conv3x3_res', 'cat', 'grouped'])
 def test_gemm_wide_tile_form_is_bit_identical(form):
     """The wide tile form of the LDS-DMA GEMM (a wave owns 32 rows x 256 columns, W fragments read
@@ -1087,6 +1088,15 @@ def test_gemm_wide_tile_form_is_bit_identical(form):
             M, K, N, rows, ns = 901, 256, (768 if form == 'ex' else 640), 53, 256
             a, wp, tab = rnd(M, K), ops.split_weight_bf16x3(rnd(N, K, scale=0.05)), rnd(rows, N)
             return lambda: torch.cat(ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=rows, n_split=ns), 1)
+        if form == 'rows_n96':      # 96 real columns in 128-row planes: three column tiles (HRNet)
+            a, wp = rnd(700, 192), ops.split_weight_bf16x3(rnd(96, 192, scale=0.05), pad=True)
+            b, r = rnd(96), rnd(700, 96)
+            return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True, n_out=96)
+        if form == 'conv3x3_n96':
+            x = rnd(2, 96, 19, 27).contiguous(memory_format=torch.channels_last)
+            wp, b = ops.split_conv3x3_weight(rnd(96, 96, 3, 3, scale=0.04)), rnd(96)
+            r = rnd(2, 96, 19, 27).contiguous(memory_format=torch.channels_last)
+            return lambda: ops.conv3x3_split(x, wp, b, stride=1, relu=True, residual=r, cout=96).contiguous()
         if form == 'rows_n384':
             a, wp, b, r = rnd(517, 128), ops.split_weight_bf16x3(rnd(384, 128, scale=0.05)), rnd(384), rnd(517, 384)
             return lambda: ops.gemm_bf16x3(a, wp, b, r, relu=True)
