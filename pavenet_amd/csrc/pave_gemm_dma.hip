@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_q_body(
         const unsigned toff = (unsigned)(((ky * g.W + kx) * g.Cin + c0) * 4);
         // (tap >= 9: the zero slab that pads K = 9 Cin to a multiple of 32 -- no mask bit)
         const bool ok = (a_mask[q] >> tap) & 1u;
-        dma16_buf(ok ? a_voff[q] + toff : 0x80000000u, a_rsrc, dst);
+        dma16_buf(ok ? a_voff[q] + toff : 0xffffff00u, a_rsrc, dst);   // (beyond any map < 4 GiB - 64 KiB)
       } else if (KIND == 2) {
         const int k0 = slab * 16;
         const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;   // (scalar) a slab lies inside one tap

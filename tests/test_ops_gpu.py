@@ -898,6 +898,28 @@ def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stri
     assert int(torch.isnan(buf[0]).any(0).sum()) <= 4     # only the windows holding the NaN pixel
 
 
+def test_conv3x3_buffer_addressed_form_between_2_and_4_gib():
+    """A 2.2 GB map: lane byte offsets above 2^31 and the out-of-range sentinel of a padded tap must
+    both stay correct (a sentinel inside the map would read data instead of zeros) -- against the
+    64-bit lane-address form (diag variant 5), bit for bit, borders included."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    lib = native.load()
+    N, H, W, Cin, Cout = 1, 2944, 2944, 64, 64
+    assert 2 ** 31 < N * H * W * Cin * 4 < 2 ** 32 - 65536
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g).permute(0, 3, 1, 2)   # channels_last map
+    wp = split_conv3x3_weight(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g) * 0.05)
+    try:
+        lib.pave_diag_gemm_variant(5)
+        flat = conv3x3_split(x, wp, None, stride=2, relu=False, cout=Cout).clone()
+    finally:
+        lib.pave_diag_gemm_variant(0)
+    buf = conv3x3_split(x, wp, None, stride=2, relu=False, cout=Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, flat)
+
+
 @pytest.mark.parametrize('form', ['identity_next64', 'identity_inplace_next128', 'downsample_next64',
                                   'identity_last', 'tail_identity_inplace_next64', 'tail_downsample_next128',
                                   'tail_identity_last'])
