@@ -205,7 +205,8 @@ __device__ __forceinline__ void gemm_q_body(
     a_rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ab);
     a_rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ab >> 32) & 0xffff);
     // bytes of the whole map (the launcher takes this form below 4 GiB only)
-    a_rsrc.z = __builtin_amdgcn_readfirstlane((M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 4);
+    a_rsrc.z = __builtin_amdgcn_readfirstlane(
+        (int)((unsigned)(M / (g.Ho * g.Wo)) * (unsigned)g.H * (unsigned)g.W * (unsigned)g.Cin * 4u));
     a_rsrc.w = 0x00020000;
   }
   unsigned w_voff[QMAX - QA];

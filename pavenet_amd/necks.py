@@ -75,9 +75,9 @@ class ChannelMapper(BaseModule):
                 conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
             s_ = conv.stride[0]
             if n * ((h - 1) // s_ + 1) * ((w - 1) // s_ + 1) < 16384 and \
-                    (get_gemm_mode() != 'bf16x3' or c < 256):
-                # too few 128-row tiles to fill 256 CUs (the 3-plane kernel has a split-K form for
-                # long K: ops.conv3x3_split): the library's split-K wins
+                    (get_gemm_mode() != 'bf16x3' or 9 * c < 8192):
+                # too few 128-row tiles to fill 256 CUs: the library's split-K wins (the 3-plane
+                # kernel has its own split-K form from K = 8192 on: ops.conv3x3_split)
                 return None
             wsplit = split_conv_weight(conv.weight)
             if wsplit is None:
