@@ -58,6 +58,12 @@ def parse():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--max-per-img', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', choices=('nccl', 'gloo'), default=None,
+                    help='create the process group and take every `world > 1` branch (rank census, result '
+                         'all-gather on device tensors, max-over-ranks all-reduce, barrier, teardown) even '
+                         'with --gpus 1: executes RCCL on a one-GPU box')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the short runs of the other BASELINE configurations (`extra`)')
     ap.add_argument('--no-native-side', action='store_true',
                     help='skip the --gemm native side measurement (profiling runs: one mode per trace)')
     ap.add_argument('--cpu-baseline-clips', type=int, default=3,
@@ -217,6 +223,82 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     return base, parity
 
 
+def secondary_workloads(args, dev, budget_s=75.0):
+    """The other BASELINE configurations on the driver's clock (`extra` of the JSON line): short
+    single-stream runs -- 3 warm-up + 10 timed steps each, results copied to the host per step as in
+    the headline, the split-GEMM class timed by HIP events over the last 3 steps -- of configs[1]
+    (R-50, T = 3, one clip), configs[3] on ONE GPU (HRNet-w48, T = 7, 4 clips) and the configs[4]
+    shape on ONE GPU (R-50, T = 15, one clip; exact split GEMMs and fp16-operand projections).
+    No vendor-kernel side, no oracle; a workload that would start after `budget_s` is skipped and
+    says so."""
+    from pavenet_amd import ops
+    from pavenet_amd.bricks import set_gemm_mode
+    from pavenet_amd.models import build_model, videopose_r50_cfg, with_hrnet_w48
+    from pavenet_amd.weights import init_random_weights
+    todo = [('configs[1]', 'r50', 3, 1, 'bf16x3'), ('configs[3] on one GPU', 'hrnet_w48', 7, 4, 'bf16x3'),
+            ('configs[4] shape on one GPU', 'r50', 15, 1, 'bf16x3'),
+            ('configs[4] shape on one GPU, fp16-operand projections', 'r50', 15, 1, 'fp16')]
+    out, t_begin, model, key = [], time.perf_counter(), None, None
+    steps, warmup, ev_steps = 10, 3, 3
+    for name, backbone, T, B, gemm in todo:
+        label = (f'{name}: PAVE-Net {"R-50" if backbone == "r50" else "HRNet-w48"} T={T}, batch={B} clips, '
+                 f'{args.height}x{args.width}, gemm={gemm}')
+        if time.perf_counter() - t_begin > budget_s:
+            out.append(dict(workload=label, skipped=f'secondary budget of {budget_s:.0f} s used up'))
+            continue
+        if key != (backbone, T):
+            model = None
+            torch.cuda.empty_cache()
+            mcfg = videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img)
+            if backbone == 'hrnet_w48':
+                mcfg = with_hrnet_w48(mcfg)
+            model = init_random_weights(build_model(mcfg), seed=0).to(dev).eval()
+            key = (backbone, T)
+        set_gemm_mode(gemm)
+        metas = [dict(batch_input_shape=(args.height, args.width), img_shape=(args.height, args.width, 3),
+                      scale_factor=(1., 1., 1., 1.)) for _ in range(B)]
+        g = torch.Generator(device=dev).manual_seed(4321)
+        img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
+        host = None
+
+        def step():
+            nonlocal host
+            res = model.forward_device(img, metas)
+            packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1), res['keep'].float()], dim=1)
+            if host is None:
+                host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            host.copy_(packed, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        with torch.no_grad():
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps - ev_steps):
+                step()
+            ops.KERNEL_EVENT_TAGS = SPLIT_GEMM_TAGS
+            ops.KERNEL_EVENTS = []
+            for _ in range(ev_steps):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        tt = sum(s_.elapsed_time(e_) for _, s_, e_, _ in ev) * 1e-3
+        fl = sum(f for _, _, _, f in ev)
+        peak = MFMA_PEAK[gemm]
+        out.append(dict(workload=label, steps=steps, warmup=warmup,
+                        ms_per_step=round(dt / steps * 1e3, 3), clips_per_s=round(B * steps / dt, 3),
+                        split_class_tflops=round(fl / tt / 1e12, 1) if tt > 0 else None,
+                        split_class_ms_per_step=round(tt / ev_steps * 1e3, 3),
+                        split_class_tflop_per_step=round(fl / ev_steps / 1e12, 3),
+                        peak_tflops=round(peak, 1), frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None))
+        del img
+    model = None
+    torch.cuda.empty_cache()
+    set_gemm_mode(args.gemm)
+    return out
+
+
 def main():
     args = ARGS if ARGS is not None else parse()
     rank = int(os.environ.get('RANK', 0))
@@ -239,9 +321,16 @@ def main():
     host_collectives = False
     backend = None
     ranks_seen, devices = [0], [f'cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}']
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        backend = 'gloo' if one_device else 'nccl'   # RCCL refuses two ranks on one device
+        backend = args.force_dist or ('gloo' if one_device else 'nccl')   # RCCL refuses two ranks on one device
+        if 'WORLD_SIZE' not in os.environ:   # --force-dist with no launcher: a one-rank rendezvous
+            import socket
+            sock = socket.socket()
+            sock.bind(('127.0.0.1', 0))
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                              MASTER_PORT=str(sock.getsockname()[1]))
+            sock.close()
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -288,7 +377,7 @@ def main():
         from pavenet_amd.dist import FrameShard
         g = torch.Generator(device=dev).manual_seed(1234)
         img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
-        if world > 1:
+        if dist is not None:
             shard = FrameShard(T, rank, world)
             img = img[:, shard.local].contiguous()
         clip0 = None
@@ -522,6 +611,9 @@ def main():
                                       frac=round(tf / peak, 4),
                                       note='whole step incl. the non-MFMA kernels; peak = dense MFMA '
                                            'peak of the --gemm mode (in the split modes the Cin, Cout % 64 == 0 3x3 convolutions run on the same split kernel)')
+        if world == 1 and dist is None and not args.no_secondary and graphed is None and \
+                args.backbone == 'r50' and (T, B) == (7, 4) and args.gemm == 'bf16x3':
+            line['extra'] = secondary_workloads(args, dev)
         if world == 1 and not args.no_cpu_baseline and clip0 is not None:
             kept = last[0, -N:] > 0.5
             free_kpts = last[0, N * 5:N * 5 + N * K * 3].view(N, K, 3)[kept]

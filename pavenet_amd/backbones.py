@@ -253,6 +253,10 @@ class ResNet(BaseModule):
                 return False
             if blk.downsample is None and c1.in_channels != 256:
                 return False
+        # pave_bottleneck_chain_f32's own size guards: larger batches take the per-block path
+        pixels = x.shape[0] * x.shape[2] * x.shape[3]
+        if pixels >= 2 ** 31 or (self.chain_mode != 'tail' and pixels * 256 >= 2 ** 32 - 65536):
+            return False
         return blocks[0].conv1.in_channels == x.shape[1] and x.shape[1] % 64 == 0
 
     def _stage64_chain(self, name, x, f, next_conv1):

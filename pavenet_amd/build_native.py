@@ -2,6 +2,9 @@
 but travel to the GPU box with the snapshot:
 
 * ``pavenet_amd/lib/libpave_hip.so`` -- the C-ABI library (hipcc, gfx950);
+* ``pavenet_amd/lib/libpave_hip_diag.so`` -- the same sources with ``-DPAVE_DIAG``: adds the
+  kernel-form override and the timing-only ablation entry points (``pave_diag_*``) that tests/ and
+  tools/ use through ``native.diag_build()``; the shipped library has neither;
 * ``pavenet_amd/_ext.*.so`` -- the pybind module with mmcv._ext's ``ms_deform_attn_forward /
   _backward`` signatures on top of that C ABI (g++ against the installed torch headers).
 """
@@ -17,6 +20,7 @@ SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
            os.path.join(_HERE, 'csrc', 'pave_gemm_dma.hip')]
 HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
+OUT_DIAG = os.path.join(_HERE, 'lib', 'libpave_hip_diag.so')
 EXT_SOURCE = os.path.join(_HERE, 'csrc', 'pave_mmcv_ext.cpp')
 EXT_OUT = os.path.join(_HERE, '_ext' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
 
@@ -25,27 +29,33 @@ def _fresh(out, deps):
     return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in deps)
 
 
-def build_native(force=False, verbose=False):
+def build_native(force=False, verbose=False, diag=True):
+    """libpave_hip.so and (diag=True) libpave_hip_diag.so; one hipcc process per translation unit
+    and flavour, all in parallel (the files are independent)."""
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and _fresh(OUT, SOURCES + HEADERS):
-        return OUT
+    flavours = [('', [], OUT)] + ([('_diag', ['-DPAVE_DIAG=1'], OUT_DIAG)] if diag else [])
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    # one hipcc process per translation unit, in parallel (the three files are independent)
-    objs, procs = [], []
-    for src in SOURCES:
-        obj = os.path.join(_HERE, 'lib', os.path.basename(src).replace('.hip', '.o'))
-        objs.append(obj)
-        if not force and _fresh(obj, [src] + HEADERS):
+    procs, links = [], []
+    for suffix, defs, out in flavours:
+        if not force and _fresh(out, SOURCES + HEADERS):
             continue
-        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-c',
-               '-I' + os.path.join(ROOT, 'include'), '-o', obj, src]
-        if verbose:
-            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-        procs.append((cmd, subprocess.Popen(cmd)))
+        objs = []
+        for src in SOURCES:
+            obj = os.path.join(_HERE, 'lib', os.path.basename(src).replace('.hip', suffix + '.o'))
+            objs.append(obj)
+            if not force and _fresh(obj, [src] + HEADERS):
+                continue
+            cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-c'] + defs + \
+                  ['-I' + os.path.join(ROOT, 'include'), '-o', obj, src]
+            if verbose and not suffix:
+                cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+            procs.append((cmd, subprocess.Popen(cmd)))
+        links.append((out, objs))
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    for out, objs in links:
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
     return OUT
 
 

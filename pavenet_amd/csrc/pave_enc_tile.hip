@@ -505,7 +505,8 @@ extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* pr
                             window_shift, stream);
 }
 
-// Timing-only ablations for tools/bench_kernels.py (not part of the C ABI, outputs are wrong):
+#ifdef PAVE_DIAG
+// Timing-only ablations for tools/bench_kernels.py (-DPAVE_DIAG build only, outputs are wrong):
 // ablate 1 = no window staging, 2 = no gather loop, 3 = neither.
 extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, const float* ref,
                                          float* out, int n_frames, int S, const int* levels_hw,
@@ -517,3 +518,4 @@ extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, 
     default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
   }
 }
+#endif  // PAVE_DIAG

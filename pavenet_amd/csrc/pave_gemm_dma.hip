@@ -1040,6 +1040,9 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (K % 32 != 0 || K < 64) return pave_internal_fail(PAVE_E_ARG, "gemm_q: K %% 32 == 0, K >= 64");
+  // the row forms address a tile's A bytes with a 32-bit lane offset: (rows - 1) * row length * 4 + 64
+  if (kind != 1 && K >= (1 << 23))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: K < 2^23 (32-bit lane offsets inside a 128-row tile)");
   if (a_bias && (kind != 0 || K > 8192))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: a_bias with the plain row form, K <= 8192");
   if (kind == 1 && Cin % 16 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 16 == 0");
@@ -1149,8 +1152,10 @@ extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes,
   if (!c2 || !w3_planes || !out || (c1 != nullptr) != (w2_planes != nullptr))
     return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: null pointer (c1 and w2_planes: both or neither)");
   // (the 3x3 body addresses the c1 map through a buffer resource: below 4 GiB)
-  if (N <= 0 || H <= 0 || W <= 0 || (long long)N * H * W * 64 * 4 >= (1ll << 32) - 65536)
-    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: bad sizes (the c1 map must stay below 4 GiB)");
+  if (N <= 0 || H <= 0 || W <= 0 || (long long)N * H * W >= (1ll << 31) ||
+      (c1 && (long long)N * H * W * 64 * 4 >= (1ll << 32) - 65536))
+    return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: bad sizes (N*H*W < 2^31; with the 3x3 inside "
+                                          "the launch the c1 map must stay below 4 GiB)");
   if ((a2 != nullptr) != (k2 > 0) || (a2 && (k2 % 32 != 0 || k2 > 960)) || (a2 && residual))
     return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: a2 [M, k2] (k2 %% 32 == 0) replaces the residual");
   if ((w1n_planes != nullptr) != (cn > 0) || (w1n_planes && (!c1n || (cn != 64 && cn != 128))))

@@ -543,7 +543,12 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   }
 }
 
-int g_diag_variant = 0;  // tools/ only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
+#ifdef PAVE_DIAG
+int g_diag_variant = 0;
+#else
+constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form global
+#endif
+                         // -DPAVE_DIAG build only (pave_diag_gemm_variant): 2 = the 256-row tile forms,
                          // 3 = 128 x 256 / 8-wave tiles wherever N % 256 == 0, 4 = never,
                          // 9 = first-generation kernels for every 3-plane form (A/B against
                          // the LDS-DMA generation of pave_gemm_dma.hip, the default),
@@ -713,9 +718,9 @@ int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_pl
   if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0 || group_n <= 0)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: bad sizes (0 < M < 2^31)");
   if (K % 32 != 0 || K < 64 || N % group_n != 0 || group_n % 64 != 0 ||
-      lda < (long long)(N / group_n) * K || lda % 4 != 0 || lda >= (1ll << 24))
+      lda < (long long)(N / group_n) * K || lda % 4 != 0 || lda >= (1ll << 23))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: K %% 32 == 0, group_n %% 64 == 0, N %% group_n == 0, "
-                                          "lda >= groups * K, lda %% 4 == 0");
+                                          "groups * K <= lda < 2^23 (a tile's 127 rows x lda x 4 B is a 32-bit lane offset), lda %% 4 == 0");
   // column tiles must not straddle a group: 128-wide tiles need group_n %% 128 == 0
   const int np = (N % 128 == 0 && group_n % 128 == 0) ? N : -N;
   return pave_internal_gemm_q(a, nullptr, w_planes, bias, nullptr, 0, out, nullptr, 0, M, K, np, relu, 0,
@@ -739,9 +744,13 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
       LnArgs{gamma, beta, eps});
 }
 
-void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tools/)
+#ifdef PAVE_DIAG
+void pave_diag_gemm_variant(int v) { g_diag_variant = v; }  // not part of the C ABI (tests/, tools/)
+#endif
 }
+#ifdef PAVE_DIAG
 int pave_internal_diag_variant() { return g_diag_variant; }
+#endif
 extern "C" {
 
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,

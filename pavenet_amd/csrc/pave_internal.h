@@ -2,7 +2,6 @@
 #ifndef PAVE_INTERNAL_H_
 #define PAVE_INTERNAL_H_
 int pave_internal_fail(int code, const char* msg); /* records pave_last_error(), returns code */
-#endif
 // pave_gemm_dma.hip: the LDS-DMA generation of the 3-plane split GEMM (rows / 3x3 / strided rows)
 int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
                          const float* residual, long long residual_rows, float* out, float* out2,
@@ -16,6 +15,15 @@ int pave_internal_splitk_reduce(const float* ws, int parts, long long M, int n, 
 int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, float* out, long long M,
                             int K, int N, void* stream);
-int pave_internal_diag_variant(); /* tools/ only: kernel-form override (pave_diag_gemm_variant) */
+/* Kernel-form override for A/B runs and the form-equality tests.  Only the -DPAVE_DIAG build
+   (lib/libpave_hip_diag.so, loaded by tests/ and tools/ through native.diag_build()) has the
+   process-global and its setter pave_diag_gemm_variant(); in the shipped library the form
+   selection is a compile-time constant. */
+#ifdef PAVE_DIAG
+int pave_internal_diag_variant();
+#else
+static inline int pave_internal_diag_variant() { return 0; }
+#endif
 int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bias, float* y, int N,
                             int H, int W, int relu, void* stream);
+#endif /* PAVE_INTERNAL_H_ */

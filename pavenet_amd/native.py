@@ -4,11 +4,13 @@ The library is built in-tree by ``pavenet_amd.build_native`` (hipcc,
 --offload-arch=gfx950).  There is NO fallback: if the shared object is missing
 or a symbol is absent, importing the product ops raises.
 """
+import contextlib
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpave_hip.so')
+DIAG_LIB_PATH = os.path.join(_HERE, 'lib', 'libpave_hip_diag.so')   # -DPAVE_DIAG build (tests/, tools/)
 
 _c_int = ctypes.c_int
 _vp = ctypes.c_void_p
@@ -61,17 +63,13 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
-def load():
-    """Load libpave_hip.so (once) and type its entry points."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if not os.path.exists(path):
         raise NativeLibraryError(
-            f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; '
+            f'{path} not found: run `python -c "import __graft_entry__ as g; '
             f'g.build()"` (hipcc --offload-arch=gfx950). pavenet_amd has no '
             f'CPU or eager fallback for its HIP kernels.')
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -85,8 +83,49 @@ def load():
     have = lib.pave_abi_version()
     if have != ABI_VERSION:   # a stale .so called with the wrong argument list corrupts memory
         raise NativeLibraryError(
-            f'{LIB_PATH} has ABI version {have}, this package expects {ABI_VERSION}: rebuild it '
+            f'{path} has ABI version {have}, this package expects {ABI_VERSION}: rebuild it '
             f'(`python -m pavenet_amd.build_native`)')
+    return lib
+
+
+def load():
+    """Load libpave_hip.so (once) and type its entry points."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+_diag_lib = None
+
+
+@contextlib.contextmanager
+def diag_build(variant=0):
+    """tests/ and tools/ only: inside the block every op of this package runs on the -DPAVE_DIAG
+    build of the same sources with kernel-form override `variant` (pave_gemm_split.hip lists the
+    values); yields that library (it also has pave_diag_enc_tile_ablate).  The shipped library
+    has no such switch, and is back in place when the block ends."""
+    global _lib, _diag_lib
+    if _diag_lib is None:
+        _diag_lib = _open(DIAG_LIB_PATH)
+        _diag_lib.pave_diag_gemm_variant.argtypes = [_c_int]
+        _diag_lib.pave_diag_gemm_variant.restype = None
+    product = load()
+    _diag_lib.pave_diag_gemm_variant(int(variant))
+    _lib = _diag_lib
+    try:
+        yield _diag_lib
+    finally:
+        _diag_lib.pave_diag_gemm_variant(0)
+        _lib = product
+
+
+def use_diag_build(variant=0):
+    """tools/ only: run the rest of this process on the -DPAVE_DIAG build with override `variant`."""
+    global _lib
+    with diag_build(variant) as lib:
+        pass
+    lib.pave_diag_gemm_variant(int(variant))
     _lib = lib
     return lib
 

@@ -14,130 +14,109 @@ import inspect
 
 
 def build_from_cfg(cfg, registry, default_args=None):
+    """``cfg['type']`` (a registered name, possibly scope-qualified, or a class / function) called
+    with the remaining keys of ``cfg``; keys of ``default_args`` fill in what ``cfg`` leaves out.
+    Same contract as the reference's helper (registry.py:12-76): TypeError for a non-dict cfg or a
+    non-Registry registry, KeyError for a missing or unknown type; a failure inside the constructor
+    is re-raised as the same exception type with the class name in front."""
     if not isinstance(cfg, dict):
-        raise TypeError(f'cfg must be a dict, but got {type(cfg)}')
-    if 'type' not in cfg:
-        if default_args is None or 'type' not in default_args:
-            raise KeyError(f'`cfg` or `default_args` must contain the key "type", but got {cfg}\n{default_args}')
+        raise TypeError(f'a config must be a dict, not {type(cfg).__name__}')
     if not isinstance(registry, Registry):
-        raise TypeError(f'registry must be a Registry object, but got {type(registry)}')
-    args = dict(cfg)
-    if default_args is not None:
-        for name, value in default_args.items():
-            args.setdefault(name, value)
-    obj_type = args.pop('type')
-    if isinstance(obj_type, str):
-        obj_cls = registry.get(obj_type)
-        if obj_cls is None:
-            raise KeyError(f'{obj_type} is not in the {registry.name} registry')
-    elif inspect.isclass(obj_type) or inspect.isfunction(obj_type):
-        obj_cls = obj_type
+        raise TypeError(f'expected a Registry to build from, not {type(registry).__name__}')
+    kwargs = {**(default_args or {}), **cfg}
+    if 'type' not in kwargs:
+        raise KeyError(f'neither the config nor its defaults name a "type": {cfg} / {default_args}')
+    target = kwargs.pop('type')
+    if isinstance(target, str):
+        factory = registry.get(target)
+        if factory is None:
+            raise KeyError(f'no "{target}" among the {registry.name} types (scope {registry.scope})')
+    elif inspect.isclass(target) or inspect.isfunction(target):
+        factory = target
     else:
-        raise TypeError(f'type must be a str or valid type, but got {type(obj_type)}')
+        raise TypeError(f'"type" must be a name, a class or a function, not {type(target).__name__}')
     try:
-        return obj_cls(**args)
-    except Exception as e:
-        raise type(e)(f'{obj_cls.__name__}: {e}')
+        return factory(**kwargs)
+    except Exception as err:
+        raise type(err)(f'{factory.__name__}: {err}')
 
 
 class Registry:
+    """name -> class table with a scope; child registries (one per scope) hang off a root."""
 
     def __init__(self, name, build_func=None, parent=None, scope=None):
         self._name = name
-        self._module_dict = {}
-        self._children = {}
-        self._scope = scope if scope is not None else 'mmcv'
-        if build_func is None:
-            self.build_func = parent.build_func if parent is not None else build_from_cfg
-        else:
-            self.build_func = build_func
-        self.parent = None
+        self._scope = 'mmcv' if scope is None else scope
+        self._table = {}
+        self._by_scope = {}     # child registries of this one, keyed by their scope
+        self.parent = parent
+        self.build_func = build_func or (parent.build_func if parent is not None else build_from_cfg)
         if parent is not None:
-            parent._add_children(self)
-            self.parent = parent
+            if self._scope in parent._by_scope:
+                raise AssertionError(f'{parent.name} already has a child registry for scope {self._scope}')
+            parent._by_scope[self._scope] = self
+
+    name = property(lambda self: self._name)
+    scope = property(lambda self: self._scope)
+    module_dict = property(lambda self: self._table)
+    children = property(lambda self: self._by_scope)
 
     def __len__(self):
-        return len(self._module_dict)
+        return len(self._table)
 
     def __contains__(self, key):
         return self.get(key) is not None
 
     def __repr__(self):
-        return f'{self.__class__.__name__}(name={self._name}, scope={self._scope}, ' \
-               f'items={sorted(self._module_dict)})'
+        return f'{type(self).__name__}(name={self._name}, scope={self._scope}, items={sorted(self._table)})'
 
     @staticmethod
     def split_scope_key(key):
-        split_index = key.find('.')
-        if split_index != -1:
-            return key[:split_index], key[split_index + 1:]
-        return None, key
+        """'scope.Name' -> ('scope', 'Name') at the FIRST dot; 'Name' -> (None, 'Name')."""
+        scope, dot, rest = key.partition('.')
+        return (scope, rest) if dot else (None, key)
 
-    @property
-    def name(self):
-        return self._name
-
-    @property
-    def scope(self):
-        return self._scope
-
-    @property
-    def module_dict(self):
-        return self._module_dict
-
-    @property
-    def children(self):
-        return self._children
+    def _root(self):
+        node = self
+        while node.parent is not None:
+            node = node.parent
+        return node
 
     def get(self, key):
-        scope, real_key = self.split_scope_key(key)
-        if scope is None or scope == self._scope:
-            if real_key in self._module_dict:
-                return self._module_dict[real_key]
-        else:
-            if scope in self._children:
-                return self._children[scope].get(real_key)
-            parent = self.parent
-            while parent is not None and parent.parent is not None:
-                parent = parent.parent
-            if parent is not None:
-                return parent.get(key)
-        # superset of the reference: a bare / own-scope miss also tries the parent chain
-        # (the reference returns None here), so bare mmcv names work from a child registry
-        if self.parent is not None and (scope is None or scope == self._scope):
-            return self.parent.get(real_key if scope is None else key)
-        return None
+        """Resolution order of the reference (registry.py:211-234): a name of this registry's own
+        scope is looked up here; a foreign scope goes to the child registry of that scope, else to
+        the root, which retries.  Superset: an own-scope or bare miss also asks the parent, so bare
+        mmcv names resolve from a child registry (the reference returns None there)."""
+        scope, bare = self.split_scope_key(key)
+        mine = scope is None or scope == self._scope
+        if mine:
+            hit = self._table.get(bare)
+            if hit is not None or self.parent is None:
+                return hit
+            return self.parent.get(bare if scope is None else key)
+        child = self._by_scope.get(scope)
+        if child is not None:
+            return child.get(bare)
+        return self._root().get(key) if self.parent is not None else None
 
     def build(self, *args, **kwargs):
         return self.build_func(*args, **kwargs, registry=self)
 
-    def _add_children(self, registry):
-        assert registry.scope not in self.children, \
-            f'scope {registry.scope} exists in {self.name} registry'
-        self.children[registry.scope] = registry
-
-    def _register_module(self, module_class, module_name=None, force=False):
-        if not inspect.isclass(module_class):
-            raise TypeError(f'module must be a class, but got {type(module_class)}')
-        if module_name is None:
-            module_name = module_class.__name__
-        if isinstance(module_name, str):
-            module_name = [module_name]
-        for name in module_name:
-            if not force and name in self._module_dict:
-                raise KeyError(f'{name} is already registered in {self.name}')
-            self._module_dict[name] = module_class
+    def _put(self, cls, names, force):
+        if not inspect.isclass(cls):
+            raise TypeError(f'only classes can be registered, got {type(cls).__name__}')
+        for n in ([cls.__name__] if names is None else [names] if isinstance(names, str) else list(names)):
+            if n in self._table and not force:
+                raise KeyError(f'{self.name} already has a type called {n} (pass force=True to replace it)')
+            self._table[n] = cls
+        return cls
 
     def register_module(self, name=None, force=False, module=None):
+        """Decorator ``@R.register_module()`` / ``@R.register_module(name=...)``, or a direct call
+        with ``module=cls``; ``name`` may be one name or several."""
         if module is not None:
-            self._register_module(module_class=module, module_name=name, force=force)
-            return module
-
-        def _register(cls):
-            self._register_module(module_class=cls, module_name=name, force=force)
-            return cls
-
-        return _register
+            return self._put(module, name, force)
+        return lambda cls: self._put(cls, name, force)
 
 
 # ---- registries, laid out as in the reference ------------------------------

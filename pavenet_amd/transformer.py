@@ -94,8 +94,8 @@ def _frame_branches(branches, lid, x, cat_dim):
     dims = [l[0].weight.shape for l in lins]                      # [(out, in)] per layer
     # (T Linears per launch: worth it from a few thousand frame-rows on; tests force min_rows = 1)
     if (get_gemm_mode() == 'bf16x3' and R * T >= min(_GEMM['min_rows'], 4096) and rows.is_contiguous()
-            and dims[0][1] % 32 == 0 and dims[0][1] >= 64 and (T * dims[0][0]) % 64 == 0
-            and all(d[1] % 32 == 0 and d[1] >= 64 for d in dims[1:])
+            and dims[0][1] % 64 == 0 and (T * dims[0][0]) % 64 == 0
+            and all(d[1] % 64 == 0 for d in dims[1:])      # split_weight_bf16x3 (un-padded): K % 64 == 0
             and all(d[0] % 64 == 0 for d in dims[1:-1]) and dims[-1][0] % 2 == 0):
         # the exact 3-plane split kernels: ONE GEMM for the T first Linears, then one GROUPED
         # launch per following layer (group t = frame t's Linear on its own column block)

@@ -26,6 +26,27 @@ def test_capi_exports_every_declared_symbol():
     assert lib.pave_abi_version() == int(m.group(1)) == native.ABI_VERSION
 
 
+def test_shipped_library_has_no_diagnostic_switches():
+    """The kernel-form override and the timing-only ablations live in the -DPAVE_DIAG build only:
+    the shipped library exports exactly the C ABI of the header, the diag build adds pave_diag_*."""
+    import subprocess
+    from pavenet_amd import native
+    from pavenet_amd.build_native import build_native
+    build_native()
+
+    def exported(path):
+        out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True,
+                             check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if ' T ' in ln}
+    shipped, diag = exported(native.LIB_PATH), exported(native.DIAG_LIB_PATH)
+    assert not [s for s in shipped if 'diag' in s], shipped
+    assert {s for s in shipped if s.startswith('pave_')} == set(native.EXPORTED)
+    assert {'pave_diag_gemm_variant', 'pave_diag_enc_tile_ablate'} <= diag
+    with native.diag_build(0) as dlib:
+        assert native.load() is dlib
+    assert native.load() is not dlib
+
+
 def test_pybind_ext_module_surface():
     """pavenet_amd._ext (csrc/pave_mmcv_ext.cpp) builds against the installed torch headers, loads
     on a CPU-only host and exposes the two entry points of mmcv._ext with the keyword names of

@@ -21,6 +21,7 @@ _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_w
              'test_oks_nms_kernel_vs_oracle', 'test_oks_nms_kernel_survives_nan_and_inf',
              'test_deterministic_mode_is_bit_reproducible_and_matches_default',
              'test_hipgraph_replay_equals_eager', 'test_bench_batch_full_size_t7_b4_vs_oracle',
+             'test_hrnet_w48_full_size_t7_vs_oracle', 'test_t15_full_size_unsharded_vs_oracle',
              'test_neck_eval_with_grad_keeps_the_differentiable_path')
 
 
@@ -207,16 +208,23 @@ def test_joint_mulframes_module(golden_dir, T, convention):
 
 def _assert_same_selection(values, ref_idx, tol, what):
     """The reference's top-k selection `ref_idx` is a valid top-k of OUR `values` up to near-ties:
-    every member the reference picked is within `tol` of our k-th largest value (the library GEMM /
-    conv kernels are not run-to-run deterministic at the 1e-6 level, so exactly tied members may
-    swap; a wrong logit would fail this by orders of magnitude)."""
+    every member the reference picked is within `tol` of our k-th largest value, and every member
+    of OUR top-k that the reference did not pick is within `tol` of it too -- a member may differ
+    only when it sits on the selection boundary (under random weights the 300-of-S proposal
+    logits and the N-of-300 scores have near-ties there); there is no allowance for
+    members that are clearly inside or outside.  A wrong logit fails this by orders of magnitude."""
     values = values.flatten().float().cpu()
     ref_idx = torch.as_tensor(np.asarray(ref_idx)).flatten().long()
-    kth = values.topk(ref_idx.numel())[0][-1]
+    top_v, top_i = values.topk(ref_idx.numel())
+    kth = top_v[-1]
     worst = values[ref_idx].min()
     assert worst >= kth - tol, f'{what}: reference-selected member {float(worst)} vs k-th {float(kth)}'
-    own = set(values.topk(ref_idx.numel())[1].tolist())
-    assert len(own ^ set(ref_idx.tolist())) <= 4, f'{what}: selections differ in more than 2 members'
+    ref_set = set(ref_idx.tolist())
+    for v, i in zip(top_v.tolist(), top_i.tolist()):
+        if i not in ref_set:
+            assert v <= float(kth) + tol, \
+                f'{what}: our member {i} ({v}) is not in the reference selection and not a near-tie ' \
+                f'of the k-th value {float(kth)}'
 
 
 def _build(T, max_per_img, g=None):
@@ -351,9 +359,7 @@ def _run_sharded_worker(args, nproc=2):
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'tests', 'sharded_worker.py')] + [str(a) for a in args]
     torch.cuda.empty_cache()  # the workers share this process's GPU
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    if r.returncode != 0 and 'MISMATCH' not in r.stdout:  # rendezvous hiccup: one retry
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)   # one run, no retry
     assert r.returncode == 0, (r.stdout[-1500:] + '\n---\n' + r.stderr[-6000:])
     return r.stdout
 
@@ -585,6 +591,47 @@ def test_streaming_video_equals_per_window_simple_test():
                                    rtol=1e-4, atol=1e-2)
 
 
+def test_streaming_value_cache_is_tied_to_its_slabs():
+    """Advisor finding (round 3): the per-frame projected-value cache belongs to the slab list that
+    encode() returned.  Incremental encoding (`into=`) extends slabs and cache together and decodes
+    exactly like a one-shot encode; slabs of an EARLIER encode keep decoding correctly after the
+    stream has encoded another video (their own cache, not the stream's latest); a plain list of
+    slabs takes the per-window projection (no frame table) and agrees to rounding."""
+    from pavenet_amd.streaming import FrameSlabs, VideoPoseStream
+    m = _build(3, 12)
+    meta = dict(batch_input_shape=(128, 160), img_shape=(128, 160, 3), scale_factor=(1., 1., 1., 1.))
+    video = _t(seeded_array('stream.video.a', (7, 3, 128, 160))).cuda()
+    other = _t(seeded_array('stream.video.b', (3, 3, 128, 160))).cuda()
+    stream = VideoPoseStream(m, meta, encode_chunk=4, decode_chunk=4)
+    wins = stream.window_indices(7, 3)
+
+    def dec(slabs, w, **kw):
+        res = stream.decode(slabs, w, **kw)
+        return res, [r[2].clone() for r in m.bbox_head.results_to_list(res)]
+    one = stream.encode(video)
+    assert isinstance(one, FrameSlabs) and one.covers([0, 6]) and one.n_cached == 7
+    res1, exp = dec(one, wins[2:5])
+    pin = dict(force_topk_proposals=m.bbox_head.transformer.last_topk_proposals,
+               force_score_topk=res1['score_index'])
+    inc = stream.encode(video[:3])
+    assert inc.values[0][0].shape[0] == 3
+    stream.encode(video[3:], into=inc)          # grows slabs and cache (capacity 3 -> 7)
+    assert len(inc) == 7 and inc.n_cached == 7 and inc.covers([0, 6])
+    for a, b in zip(one.values[0] + one.values[1], inc.values[0] + inc.values[1]):
+        assert torch.equal(a[:7], b[:7])
+    _, got = dec(inc, wins[2:5], **pin)
+    assert all(torch.equal(a, b) for a, b in zip(got, exp))
+    stream.encode(other)                        # another video through the same stream object
+    _, got = dec(one, wins[2:5], **pin)         # the earlier slabs still use THEIR cache
+    assert all(torch.equal(a, b) for a, b in zip(got, exp))
+    _, got = dec(list(one), wins[2:5], **pin)   # plain list: per-window projection, no table
+    for a, b in zip(got, exp):
+        assert a.shape == b.shape
+        _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    with pytest.raises(AssertionError):
+        stream.decode(one, [[5, 6, 7]])         # index past the end of the slab list
+
+
 def test_split_gemm_mode_matches_native():
     """Opt-in bf16x3 split GEMM under the whole model: encoder memory and final keypoints agree
     with the native fp32 path to fp32 rounding (selections pinned: near-tie robust)."""
@@ -694,31 +741,35 @@ def test_full_size_800x1344_vs_reference_golden(golden_dir):
     _close(bboxes.cpu().numpy(), g['det_bboxes'], rtol=1e-4, atol=1e-2)
 
 
-def test_bench_batch_full_size_t7_b4_vs_oracle():
-    """BASELINE configs[2] at FULL size inside the GPU suite: bench.py's own batch (R-50, T = 7,
-    4 clips of 800 x 1344, bench weights, headline GEMM mode 'bf16x3', shipped GEMM selections),
-    clip 0 against ONE run of the CPU oracle (about a minute on the box's host cores):
-    key points within 1e-3 px with the oracle's two top-k selections pinned, equal OKS-NMS keep
-    sets, and the FREE run (nothing pinned) reproducing every pose the oracle kept."""
+def _full_size_vs_oracle(T, B, backbone='r50', seed=1234):
+    """bench.py's batch of a BASELINE configuration at 800 x 1344 (bench weights, headline GEMM mode
+    'bf16x3', shipped GEMM selections): clip 0 against ONE run of the CPU oracle -- key points within
+    1e-3 px with the oracle's two top-k selections pinned, equal OKS-NMS keep sets, and the FREE run
+    (nothing pinned) reproducing every pose the oracle kept."""
     import bench
     from pavenet_amd import bricks, tuning
-    from pavenet_amd.models import build_model, videopose_r50_cfg
+    from pavenet_amd.models import build_model, videopose_r50_cfg, with_hrnet_w48
     from pavenet_amd.weights import init_random_weights
-    T, B, N, K, H, W = 7, 4, 20, 15, 800, 1344
-    m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=N))
+    N, K, H, W = 20, 15, 800, 1344
+    mcfg = videopose_r50_cfg(num_frames=T, max_per_img=N)
+    if backbone == 'hrnet_w48':
+        mcfg = with_hrnet_w48(mcfg)
+    m = build_model(mcfg)
     init_random_weights(m, seed=0)
     m = m.cuda().eval()
 
     class A:
         height, width = H, W
     clip0 = bench.clip0_image(A, T)
-    g = torch.Generator(device='cuda').manual_seed(1234)
+    g = torch.Generator(device='cuda').manual_seed(seed)
     img = torch.randn(B, T, 3, H, W, device='cuda', generator=g)
     img[0].copy_(clip0[0])
     metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))
              for _ in range(B)]
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     cfg = dict(num_frames=T, num_keypoints=K, num_query=300, max_per_img=N)
+    if backbone == 'hrnet_w48':
+        cfg['backbone'] = 'hrnet'
     taps = {}
     old = R.SAMPLER
     R.SAMPLER = 'torch'
@@ -749,6 +800,25 @@ def test_bench_batch_full_size_t7_b4_vs_oracle():
     assert free.shape[0] == ek.shape[0], (free.shape, ek.shape)
     for pose in ek[..., :2]:
         assert float((free[..., :2] - pose).abs().amax(dim=(1, 2)).min()) <= 1e-3
+
+
+def test_bench_batch_full_size_t7_b4_vs_oracle():
+    """BASELINE configs[2] at FULL size inside the GPU suite: bench.py's own batch (R-50, T = 7,
+    4 clips of 800 x 1344), clip 0 against one oracle run (about a minute on the box's host cores)."""
+    _full_size_vs_oracle(7, 4)
+
+
+def test_hrnet_w48_full_size_t7_vs_oracle():
+    """BASELINE configs[3] at FULL size: HRNet-w48 + MulFrames head, T = 7, one 800 x 1344 clip --
+    the size-gated convolution forms of the 48 / 96 / 192 / 384-channel branches (wide tiles,
+    96-column tiles, three blocks per CU, the LDS-window 3x3) that a 128 x 160 input never takes."""
+    _full_size_vs_oracle(7, 1, backbone='hrnet_w48')
+
+
+def test_t15_full_size_unsharded_vs_oracle():
+    """The BASELINE configs[4] shape at FULL size, un-sharded, exact arithmetic: R-50, T = 15, one
+    800 x 1344 clip (15-frame T-frame attention kernels, 15 x 22 323-token memory)."""
+    _full_size_vs_oracle(15, 1)
 
 
 def test_forward_is_the_same_from_the_first_call_and_reads_no_stale_memory():

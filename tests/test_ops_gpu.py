@@ -613,13 +613,9 @@ def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
     assert torch.equal(bad, expn)
     if W % 4 == 0:
         from pavenet_amd import native
-        lib = native.load()
         new = conv7x7s2_nchw_split(x.cuda(), wp, b.cuda(), relu=True).clone()
-        try:
-            lib.pave_diag_gemm_variant(9)
+        with native.diag_build(9):
             old = conv7x7s2_nchw_split(x.cuda(), wp, b.cuda(), relu=True).clone()
-        finally:
-            lib.pave_diag_gemm_variant(0)
         assert torch.equal(new, old)
 
 
@@ -832,12 +828,9 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     assert torch.equal(y, conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout))
     y2 = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=True, residual=rd, cout=Cout)
     np.testing.assert_allclose(y2.cpu().numpy(), torch.relu(exp + r.double()).numpy(), rtol=1e-5, atol=2e-5)
-    try:
-        lib.pave_diag_gemm_variant(6)
-        assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == 0
+    with native.diag_build(6) as dlib:
+        assert dlib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == 0
         one = conv3x3_split(xd, wp, b.cuda(), stride=stride, relu=False, cout=Cout)
-    finally:
-        lib.pave_diag_gemm_variant(0)
     np.testing.assert_allclose(y.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=2e-5)
     # a NaN pixel poisons exactly the outputs whose window holds it, in every part
     xn = x.clone()
@@ -879,18 +872,14 @@ def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stri
     boundaries inside a tile and a NaN pixel included."""
     from pavenet_amd import native
     from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
-    lib = native.load()
     g = torch.Generator().manual_seed(Cin + Cout + H)
     x = torch.randn(N, Cin, H, W, generator=g)
     x[0, 1, 0, 0] = float('nan')
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wp = split_conv3x3_weight((torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda())
     b = torch.randn(Cout, generator=g).cuda()
-    try:
-        lib.pave_diag_gemm_variant(5)
+    with native.diag_build(5):
         flat = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout).clone()
-    finally:
-        lib.pave_diag_gemm_variant(0)
     buf = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout)
     torch.cuda.synchronize()
     assert torch.equal(torch.isnan(buf), torch.isnan(flat))
@@ -904,17 +893,13 @@ def test_conv3x3_buffer_addressed_form_between_2_and_4_gib():
     64-bit lane-address form (diag variant 5), bit for bit, borders included."""
     from pavenet_amd import native
     from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
-    lib = native.load()
     N, H, W, Cin, Cout = 1, 2944, 2944, 64, 64
     assert 2 ** 31 < N * H * W * Cin * 4 < 2 ** 32 - 65536
     g = torch.Generator(device='cuda').manual_seed(5)
     x = torch.randn(N, H, W, Cin, device='cuda', generator=g).permute(0, 3, 1, 2)   # channels_last map
     wp = split_conv3x3_weight(torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g) * 0.05)
-    try:
-        lib.pave_diag_gemm_variant(5)
+    with native.diag_build(5):
         flat = conv3x3_split(x, wp, None, stride=2, relu=False, cout=Cout).clone()
-    finally:
-        lib.pave_diag_gemm_variant(0)
     buf = conv3x3_split(x, wp, None, stride=2, relu=False, cout=Cout)
     torch.cuda.synchronize()
     assert torch.equal(buf, flat)
@@ -1023,7 +1008,6 @@ def test_gemm_generations_are_bit_identical(form):
     (pave_gemm_split.hip): every form must give bit-identical results (LayerNorm epilogue: same
     GEMM, different summation order of the row statistics -> 2e-6), including ragged M."""
     from pavenet_amd import native, ops
-    lib = native.load()
     g = torch.Generator().manual_seed(len(form))
     dev = 'cuda'
 
@@ -1063,13 +1047,9 @@ def test_gemm_generations_are_bit_identical(form):
         return lambda: ops.conv3x3_split(x, wp, b, stride=st, relu=True).contiguous()
 
     fn = run()
-    try:
-        lib.pave_diag_gemm_variant(9)
+    with native.diag_build(9):
         old = fn().clone()
-        lib.pave_diag_gemm_variant(0)
-        new = fn().clone()
-    finally:
-        lib.pave_diag_gemm_variant(0)
+    new = fn().clone()      # the shipped library
     torch.cuda.synchronize()
     if form == 'ln':
         np.testing.assert_allclose(new.cpu().numpy(), old.cpu().numpy(), rtol=0, atol=4e-6)
@@ -1086,7 +1066,6 @@ def test_gemm_wide_tile_form_is_bit_identical(form):
     products in the same order per accumulator -> bit-identical on every row source / epilogue,
     ragged M and the shortest K (4 slabs) included."""
     from pavenet_amd import native, ops
-    lib = native.load()
     g = torch.Generator().manual_seed(100 + len(form))
     dev = 'cuda'
 
@@ -1141,13 +1120,10 @@ def test_gemm_wide_tile_form_is_bit_identical(form):
         return lambda: ops.gemm_bf16x3_grouped(a, wp, b, gn, relu=True)
 
     fn = run()
-    try:
-        lib.pave_diag_gemm_variant(8)
+    with native.diag_build(8):
         narrow = fn().clone()
-        lib.pave_diag_gemm_variant(7)
+    with native.diag_build(7):
         wide = fn().clone()
-    finally:
-        lib.pave_diag_gemm_variant(0)
     torch.cuda.synchronize()
     assert torch.isfinite(wide).all()
     assert torch.equal(wide, narrow), float((wide - narrow).abs().max())
@@ -1161,7 +1137,6 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
     exact multiples of the 128-row tile, K = 64, two outputs and the row-periodic residual table
     included."""
     from pavenet_amd import native, ops
-    lib = native.load()
     rs = np.random.RandomState(1000 + seed)
     g = torch.Generator().manual_seed(2000 + seed)
     M = int(rs.choice([1, 31, 128, 129, 256, 1000, 2047, 2560]))
@@ -1183,12 +1158,10 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
         return ops.gemm_bf16x3(a, wp, b, r, relu=relu)
 
     outs = {}
-    try:
-        for v in (9, 8, 7, 0):
-            lib.pave_diag_gemm_variant(v)
+    for v in (9, 8, 7):
+        with native.diag_build(v):
             outs[v] = run().clone()
-    finally:
-        lib.pave_diag_gemm_variant(0)
+    outs[0] = run().clone()     # the shipped library's own selection
     torch.cuda.synchronize()
     for v in (8, 7, 0):
         assert torch.equal(outs[v], outs[9]), (seed, M, K, N, v, float((outs[v] - outs[9]).abs().max()))
@@ -1266,18 +1239,14 @@ def test_gemm_bf16x3_eight_wave_tile_equals_four_wave_tile(M, K, N):
     b, r, ab = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda(), \
         torch.randn(K, generator=g).cuda()
     wp = split_weight_bf16x3(w)
-    lib = native.load()
-    try:
-        lib.pave_diag_gemm_variant(4)
+    with native.diag_build(4):
         ref = gemm_bf16x3(a, wp, b, r, relu=True, a_bias=ab)
         ref2 = gemm_bf16x3_ex(a, wp, b, r[:7].contiguous(), residual_rows=7, n_split=256) \
             if N > 256 else None
-        lib.pave_diag_gemm_variant(3)
+    with native.diag_build(3):
         got = gemm_bf16x3(a, wp, b, r, relu=True, a_bias=ab)
         got2 = gemm_bf16x3_ex(a, wp, b, r[:7].contiguous(), residual_rows=7, n_split=256) \
             if N > 256 else None
-    finally:
-        lib.pave_diag_gemm_variant(0)
     assert torch.equal(ref, got)
     if ref2 is not None:
         assert torch.equal(ref2[0], got2[0]) and torch.equal(ref2[1], got2[1])

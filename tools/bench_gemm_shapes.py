@@ -71,13 +71,13 @@ def main():
                 f3 = lambda: ops.gemm_bf16x3(a, wp, bias, None, relu=(kind == 'act'))
             ms3 = timed(f3)
             from pavenet_amd import native
-            native.load().pave_diag_gemm_variant(2)
+            native.use_diag_build(2)
             ms3b = timed(f3)
             ms8 = float('nan')
             if N % 256 == 0:
-                native.load().pave_diag_gemm_variant(3)
+                native.use_diag_build(3)
                 ms8 = timed(f3)
-            native.load().pave_diag_gemm_variant(0)
+            native.use_diag_build(0)
             print(f'   {label}: library {ms:.3f} ms ({2.0 * M * K * N / ms / 1e9:.0f} TF/s)   '
                   f'bf16x3 split {ms3:.3f} ms ({2.0 * M * K * N / ms3 / 1e9:.0f} TF/s)   '
                   f'256-row tile, 1 wave/SIMD {ms3b:.3f} ms ({2.0 * M * K * N / ms3b / 1e9:.0f} TF/s)   '

@@ -86,7 +86,7 @@ def main():
     if args.ablate:
         import ctypes
         from pavenet_amd import native
-        lib = native.load()
+        lib = native.use_diag_build()     # the -DPAVE_DIAG build has the ablation entry point
         fn = lib.pave_diag_enc_tile_ablate
         fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + \
             [ctypes.c_int] * 3 + [ctypes.c_void_p]

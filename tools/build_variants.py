@@ -25,11 +25,11 @@ def main():
         flags = [f for f in flags.split(',') if f]
         obj = os.path.join(LIB, 'variants', f'gemm_{name}.o')
         src = 'pave_gemm_split.hip'
-        other = 'pave_gemm_dma.o'
+        other = 'pave_gemm_dma_diag.o'
         if any('PAVE_Q_' in f for f in flags):   # switches of the DMA generation
-            src, other = 'pave_gemm_dma.hip', 'pave_gemm_split.o'
+            src, other = 'pave_gemm_dma.hip', 'pave_gemm_split_diag.o'
         cmd = ['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-c',
-               '-I' + os.path.join(ROOT, 'include'), '-Rpass-analysis=kernel-resource-usage'] + flags + \
+               '-DPAVE_DIAG=1', '-I' + os.path.join(ROOT, 'include'), '-Rpass-analysis=kernel-resource-usage'] + flags + \
               ['-o', obj, os.path.join(ROOT, 'pavenet_amd', 'csrc', src)]
         procs.append((name, (obj, other), subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for name, (obj, other), p in procs:
@@ -49,8 +49,8 @@ def main():
                 print(f'{name:12s} {kn:14s} {" ".join(info)}')
         out = os.path.join(LIB, 'variants', f'libpave_hip_{name}.so')
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out,
-                               obj, os.path.join(LIB, other), os.path.join(LIB, 'pave_kernels.o'),
-                               os.path.join(LIB, 'pave_enc_tile.o')])
+                               obj, os.path.join(LIB, other), os.path.join(LIB, 'pave_kernels_diag.o'),
+                               os.path.join(LIB, 'pave_enc_tile_diag.o')])
         print('built', out)
 
 

@@ -19,7 +19,7 @@ def load(name):
     """`name` = a build under pavenet_amd/lib/variants/, or `main` = the regular library; an
     `@V` suffix calls pave_diag_gemm_variant(V) before every timed call (e.g. main@5)."""
     name = name.split('@')[0]
-    path = os.path.join(ROOT, 'pavenet_amd', 'lib', 'libpave_hip.so') if name == 'main' else \
+    path = os.path.join(ROOT, 'pavenet_amd', 'lib', 'libpave_hip_diag.so') if name == 'main' else \
         os.path.join(ROOT, 'pavenet_amd', 'lib', 'variants', f'libpave_hip_{name}.so')
     lib = ctypes.CDLL(path)
     for fn, sig in native.SIGNATURES.items():
@@ -99,7 +99,8 @@ def main():
         ref = None
         row = []
         for name, lib in zip(names, libs):
-            lib.pave_diag_gemm_variant(int(name.split('@')[1]) if '@' in name else 0)
+            if hasattr(lib, 'pave_diag_gemm_variant'):   # -DPAVE_DIAG builds only
+                lib.pave_diag_gemm_variant(int(name.split('@')[1]) if '@' in name else 0)
             fn = make(lib)
             assert fn() == 0, (name, label, lib.pave_last_error())
             torch.cuda.synchronize()

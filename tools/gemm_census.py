@@ -18,7 +18,7 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     if len(sys.argv) > 2:   # kernel-form override (pave_diag_gemm_variant), e.g. 8 = no wide tiles
         from pavenet_amd import native
-        native.load().pave_diag_gemm_variant(int(sys.argv[2]))
+        native.use_diag_build(int(sys.argv[2]))
     T, B, H, W = 7, 4, 800, 1344
     m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=20))
     init_random_weights(m, seed=0)

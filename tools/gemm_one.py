@@ -14,7 +14,7 @@ variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 a = torch.randn(M, K, device='cuda')
 w = torch.randn(N, K, device='cuda') * 0.05
 wp = ops.split_weight_bf16x3(w)
-native.load().pave_diag_gemm_variant(variant)
+native.use_diag_build(variant) if variant else native.load()
 for _ in range(iters):
     out = ops.gemm_bf16x3(a, wp)
 torch.cuda.synchronize()
