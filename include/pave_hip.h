@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 14
+#define PAVE_ABI_VERSION 15
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -112,6 +112,56 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
                                     int K, int proj_stride, const int32_t* frame_table,
                                     void* stream);
+
+/*
+ * Scaled-dot-product core of the decoders' self-attention (replaces what nn.MultiheadAttention
+ * runs between its in- and out-projection, third_party/mmcv/mmcv/cnn/bricks/transformer.py:
+ * 406-551 as the reference's decoder layers call it: no masks, no dropout, 32 channels per head).
+ *   qkv [n_seq * L, ld]: row = (sequence, position); q at column 0, k at column H*32, v at 2*H*32
+ *   out [n_seq * L, H*32] = softmax(q k^T / sqrt(32)) v per (sequence, head)
+ * One head's K and V ([L, 32] each) are staged in LDS: L <= 568.
+ */
+int pave_mha_core_f32(const float* qkv, float* out, int n_seq, int L, int H, int ld, void* stream);
+
+/*
+ * Row-wise top-k in one launch: element (r, i) of x at x[r ld + i cs], i < n; k <= 1024,
+ * n <= 32768 -> index [rows, k] int64 sorted by (value descending, index ascending), values
+ * [rows, k] (may be NULL).  NaN ranks above +inf (torch.topk's order).  Replaces torch.topk for the
+ * proposal selection (opera/models/utils/transformer.py:21383-21385) and the score selection
+ * (opera/models/dense_heads/videopose_head_mul_frames.py:1416).
+ */
+int pave_topk_rows_f32(const float* x, float* values, long long* index, int rows, int n, int ld, int cs,
+                       int k, void* stream);
+
+/*
+ * The N selected queries of every frame in one gather (videopose_head_mul_frames.py:1419-1427, 610):
+ * poses [B, T*Q, C] (frame t at rows [t Q, (t+1) Q)), index [B, N] int64 (clamped to [0, Q))
+ * -> out [T, B*N, C] frame-major.
+ */
+int pave_gather_frame_poses_f32(const float* poses, const long long* index, float* out, int B, int T,
+                                int Q, int N, int C, void* stream);
+
+/*
+ * Post-processing of the refined poses in one launch (videopose_head_mul_frames.py:1440-1490,
+ * get_p :1531-1535): pixels = clamp(kpt * (w, h), 0, (w, h)) [/ scale factor], bounding box =
+ * min / max over the K key points, p = 0.7 (1 - exp(-0.2 / sigma_x)) (1 - exp(-0.2 / sigma_y)),
+ * kpt <- kpt p^5 / (p^5 + 1e-10), key-point score = pose score * p.
+ *   kpts, sigmas [B, N, K, 2]; scores [B, N]; wh, sf [B, 2] (sf only read when rescale != 0)
+ *   -> det_kpts [B, N, K, 3] (x, y, score), det_bboxes [B, N, 5] (x1, y1, x2, y2, score);  K <= 64
+ */
+int pave_pose_finalize_f32(const float* kpts, const float* sigmas, const float* scores, const float* wh,
+                           const float* sf, float* det_kpts, float* det_bboxes, int B, int N, int K,
+                           int rescale, void* stream);
+
+/*
+ * Reference-point update of the decoders read straight from the grouped per-frame MLP output
+ * (opera/models/utils/transformer.py:6728-6735, mmdet/models/utils/transformer.py:861-866):
+ *   y [R, T*op]: row r, frame t's o outputs at columns [t op, t op + o);  ref, out [R*T, o] with row
+ *   (r / G) T G + t G + r % G  (G = queries per clip: frame-major inside a clip; G = R: frame-major
+ *   over all rows);  out = sigmoid(y + inverse_sigmoid(ref)), eps as mmdet's inverse_sigmoid.
+ */
+int pave_ref_update_frames_f32(const float* y, const float* ref, float* out, int R, int T, int op, int o,
+                               int G, float eps, void* stream);
 
 /*
  * Greedy OKS-NMS, one launch for n_clips clips (replaces oks_nms / oks_iou,

@@ -115,7 +115,7 @@ def _fusable(*tensors):
 # it saves) and superseded by folding the positional term into the merged projection GEMM
 # (deform_attn._forward_merged), so it is off (set the attribute for an A/B run).
 FUSE_QUERY_POS = False   # A/B switch (tools/ab_switch.py sets the attribute; never read from the environment)
-_GEMM = {'mode': 'bf16x3', 'min_rows': 8192, 'ln_fused': True}
+_GEMM = {'mode': 'bf16x3', 'min_rows': 8192, 'ln_fused': True, 'small': True}
 
 
 _PLANES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'fp16': 16}   # 16 = ops.PLANES_FP16
@@ -250,6 +250,49 @@ def split_gemm_ok(x2, weight):
             and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
 
 
+def small_split_ok(x2, weight):
+    """Shapes below split_gemm_ok's row threshold or off its column grid that still take the
+    3-plane kernel (zero-padded planes): inference only, exact split mode only."""
+    return (_GEMM['mode'] == 'bf16x3' and _GEMM['small'] and x2.is_cuda and x2.dtype == torch.float32
+            and x2.dim() == 2 and x2.is_contiguous() and x2.shape[0] >= 1
+            and weight.dtype == torch.float32 and weight.dim() == 2
+            and weight.shape[1] % 32 == 0 and weight.shape[1] >= 64
+            and not torch.is_grad_enabled())
+
+
+def mlp_rows(module, x):
+    """A branch of the heads on [..., K] rows: nn.Linear, heads.Linear_with_norm(norm=False) or an
+    nn.Sequential of those and nn.ReLU, every Linear through linear_rows (ReLU in its epilogue)
+    -- on the device in the exact split mode these are launches of this package's GEMM; anything
+    else (other layer types, training) is the module's own forward."""
+    if not (x.is_cuda and x.dtype == torch.float32 and _GEMM['mode'] == 'bf16x3'
+            and not torch.is_grad_enabled()):
+        return module(x)
+    layers = list(module) if isinstance(module, nn.Sequential) else [module]
+    plan = []
+    for i, m in enumerate(layers):
+        if isinstance(m, nn.ReLU):
+            if not plan or plan[-1][2]:
+                return module(x)
+            plan[-1][2] = True
+            continue
+        lin = m if isinstance(m, nn.Linear) else getattr(m, 'linear', None)
+        if not isinstance(lin, nn.Linear) or (lin is not m and getattr(m, 'norm', True)):
+            return module(x)
+        use_bias = lin.bias is not None and (lin is m or bool(getattr(m, 'bias', True)))
+        plan.append([lin.weight, lin.bias if use_bias else None, False])
+    rows = x.reshape(-1, x.shape[-1])
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    for i, (w, b, relu) in enumerate(plan):
+        rows = linear_rows(rows, w, b, relu=relu)
+        if i + 1 < len(plan) and not rows.is_contiguous():
+            rows = rows.contiguous()
+    # (an output width off the 4-column grid comes back as a column slice of a padded matrix: kept
+    # as a strided view, the consumers are elementwise)
+    return rows.unflatten(0, tuple(x.shape[:-1]))
+
+
 def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residual=False,
                 a_bias=None):
     """act(A' @ weight^T + bias + residual) on rows [M, K]: the split GEMM when enabled and
@@ -260,17 +303,22 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
         out = residual if (residual is not None and inplace_residual) else None
         return ops.gemm_bf16x3(x2, _split_weight(weight), bias, residual, relu=relu, out=out,
                                a_bias=a_bias, fp16=_GEMM['mode'] == 'fp16')
-    if (_GEMM['mode'] == 'bf16x3' and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2
-            and x2.is_contiguous() and a_bias is None and not torch.is_grad_enabled()
-            and weight.shape[1] % 32 == 0 and weight.shape[1] >= 64 and weight.shape[0] % 4 == 0
-            and x2.shape[0] >= min(_GEMM['min_rows'], 1024) and weight.shape[0] >= 4096):
-        # wide projections of the decoders (a few hundred query rows x ~10^4 offset / logit
-        # columns, OT:1722-1734): the 3-plane kernel with planes zero-padded to N % 64 == 0
+    if small_split_ok(x2, weight) and a_bias is None:
+        # every other Linear of the path -- the decoders' and heads' few-hundred-row projections,
+        # FFNs and branch MLPs, any output width: the same 3-plane kernel with planes zero-padded
+        # to N % 64 == 0 (and the output to N % 4 == 0), so that no library GEMM is left in the step
         from . import ops
+        N = weight.shape[0]
+        N4 = (N + 3) // 4 * 4
         wp = _split_cached(weight, 'gemm_pad', lambda planes: ops.split_weight_bf16x3(
             weight.detach().contiguous(), planes, pad=True))
-        out = residual if (residual is not None and inplace_residual) else None
-        return ops.gemm_bf16x3(x2, wp, bias, residual, relu=relu, out=out, n_out=weight.shape[0])
+        if N4 == N:
+            out = residual if (residual is not None and inplace_residual) else None
+            return ops.gemm_bf16x3(x2, wp, bias, residual, relu=relu, out=out, n_out=N)
+        if residual is None:    # 1, 2, 30 outputs (class logit, refine offsets, sigmas)
+            b4 = None if bias is None else _split_cached(
+                bias, 'bias_pad4', lambda planes: F.pad(bias.detach(), (0, N4 - N)).contiguous())
+            return ops.gemm_bf16x3(x2, wp, b4, None, relu=relu, n_out=N4)[:, :N]
     if a_bias is not None:
         x2 = torch.relu(x2 + a_bias)
     if residual is not None:
@@ -299,7 +347,8 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
         if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and post_norm is not None
                 and pos_rows is None and C_out == 256 and tuple(post_norm.normalized_shape) == (256,)
                 and post_norm.weight is not None and post_norm.bias is not None
-                and split_gemm_ok(x2, linear.weight)):
+                and linear.weight.shape[1] % 64 == 0
+                and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
             # Linear + bias + residual + LayerNorm as ONE launch (the block tile owns whole rows)
             t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, idt2,
                                    post_norm.weight, post_norm.bias, post_norm.eps,
@@ -334,7 +383,8 @@ def linear_norm(x, linear, norm):
     if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and linear.out_features == 256
             and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (256,)
             and norm.weight is not None and norm.bias is not None and x2.is_contiguous()
-            and not torch.is_grad_enabled() and split_gemm_ok(x2, linear.weight)):
+            and not torch.is_grad_enabled() and linear.weight.shape[1] % 64 == 0
+            and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
         from . import ops
         t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, None, norm.weight,
                                norm.bias, norm.eps)
@@ -501,6 +551,43 @@ class MultiheadAttention(BaseModule):
 
     supports_post_norm = True
 
+    def _self_attention_split(self, x, pos, identity, post_norm):
+        """The decoders' self-attention on this package's own kernels, three launches: ONE split
+        GEMM for q | k | v -- (x + pos) W^T = x W^T + pos W^T, and the positional term of the
+        decoders is a parameter-derived constant per query row ([L, E], the same for every
+        sequence of the batch), so it rides the GEMM epilogue as a row-periodic table
+        [pos W_qk^T + b_qk | b_v] cached per weights --, the scaled-dot-product core
+        (pave_mha_core_f32: K and V of a head in LDS, quad-owned queries, online softmax), and
+        out_proj + identity + LayerNorm as one launch of the LayerNorm-epilogue GEMM.
+        Returns None when the shapes are not the ones this path takes."""
+        from . import ops
+        a = self.attn
+        L, N, E = x.shape
+        H = self.num_heads
+        if E != 256 or E // H != 32 or pos is None or post_norm is None or L > 568:
+            return None
+        pb = pos.transpose(0, 1)                      # [N, L, E]
+        if not (pb.stride(0) == 0 or N == 1) or pb.stride(2) != 1:
+            return None                               # a per-sequence positional term
+        pos_rows = pb[0]                              # [L, E] view of the embedding parameter
+        base = pos_rows._base if pos_rows._base is not None else pos_rows
+        w, b = a.in_proj_weight, a.in_proj_bias
+        key = SourceKey((base, w, b), extra=(tuple(pos_rows.shape), tuple(pos_rows.stride()),
+                                             pos_rows.storage_offset()))
+        hit = self.__dict__.get('_pave_qkv')
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                t = pos_rows.double() @ w[:2 * E].double().t() + b[:2 * E].double()
+                tab = torch.cat([t.float(), b[2 * E:].float().expand(L, E)], 1).contiguous()
+            hit = self.__dict__['_pave_qkv'] = (key, tab)
+        xb = batch_first(x).reshape(N * L, E)
+        qkv, _ = ops.gemm_bf16x3_ex(xb, _split_weight(w), None, hit[1], residual_rows=L)
+        o = ops.mha_core(qkv, N, L, H)
+        t = ops.gemm_bf16x3_ln(o, _split_weight(a.out_proj.weight), a.out_proj.bias,
+                               batch_first(identity).reshape(N * L, E), post_norm.weight,
+                               post_norm.bias, post_norm.eps)
+        return seq_first_view(t.view(N, L, E))
+
     def _self_attention_fast(self, x, pos, identity, post_norm):
         """Self-attention of the decoders on the device (query = key = x + pos, value = x, no
         masks), seq-first [L, N, E]: one add, the q|k and v projections as two GEMMs, fused SDPA,
@@ -544,6 +631,11 @@ class MultiheadAttention(BaseModule):
                 and a.bias_k is None and not a.add_zero_attn
                 and (post_norm is None or (isinstance(post_norm, nn.LayerNorm)
                                            and post_norm.elementwise_affine))):
+            if _GEMM['mode'] == 'bf16x3':
+                out = self._self_attention_split(query, query_pos,
+                                                 query if identity is None else identity, post_norm)
+                if out is not None:
+                    return out
             return self._self_attention_fast(query, query_pos,
                                              query if identity is None else identity, post_norm)
         out = self._forward_reference(query, key, value, identity, query_pos, key_pos, attn_mask,

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
            os.path.join(_HERE, 'csrc', 'pave_gemm_split.hip'),
            os.path.join(_HERE, 'csrc', 'pave_enc_tile.hip'),
-           os.path.join(_HERE, 'csrc', 'pave_gemm_dma.hip')]
+           os.path.join(_HERE, 'csrc', 'pave_gemm_dma.hip'),
+           os.path.join(_HERE, 'csrc', 'pave_decoder.hip')]
 HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
 OUT_DIAG = os.path.join(_HERE, 'lib', 'libpave_hip_diag.so')

@@ -1,0 +1,560 @@
+// pave_decoder.hip -- the small kernels of the decoders' self-attention (gfx950, wave64).
+//
+// Replaces the scaled-dot-product core of nn.MultiheadAttention as the reference uses it in both
+// decoders (third_party/mmcv/mmcv/cnn/bricks/transformer.py:406-551: q = k = x + pos, v = x,
+// 8 heads of 32 channels, no masks, no dropout at inference): 300 pose queries per clip in the
+// pose decoder, 15 joint queries per pose in the joint decoder.  The q | k | v projection and
+// out_proj + identity + LayerNorm are launches of the split GEMM (pave_gemm_dma.hip); this file
+// is what sits between them.
+//
+// Work layout: one workgroup per (query chunk, head, sequence).  The head's K and V rows
+// ([L, 32] fp32 each) are copied once into LDS with rows padded to 36 dwords, so that the four
+// lanes of a quad -- which walk four DIFFERENT keys j, j + 1, j + 2, j + 3 at the same channel
+// chunk -- read four different bank groups (36 j mod 64 = 0, 36, 8, 44), and the 16 quads of a
+// wave, which read the SAME key, broadcast.  A query is owned by LQ = 4 or 16 consecutive lanes:
+// lane r takes the keys j = r (mod LQ) with an online softmax over groups of four of its keys (one
+// rescale of the 32 accumulators per group), and the LQ partial (max, sum, row) states are
+// merged with a shuffle butterfly at the end (16 keys at pitch 36: 16 different bank groups too).  Everything is fp32 FMA: the whole stage is
+// ~25 MFLOP per (clip, head) and latency-bound, the matrix cores have nothing to add here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pave_hip.h"
+#include "pave_internal.h"
+
+namespace {
+
+constexpr int kD = 32;        // channels per head
+constexpr int kPad = 36;      // LDS row pitch in dwords (see header)
+constexpr int kGroup = 4;     // keys per online-softmax group and lane
+
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                               Q * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) {   // quad_perm:[1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1,
+                                                               0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {   // quad_perm:[2,3,0,1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e,
+                                                               0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += quad_xor1(v);
+  v += quad_xor2(v);
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, quad_xor1(v));
+  v = fmaxf(v, quad_xor2(v));
+  return v;
+}
+
+struct MhaParams {
+  const float* qkv;   // [n_seq * L, ld]: q at column 0, k at column E, v at column 2 E (E = H * 32)
+  float* out;         // [n_seq * L, E]
+  int L, H, ld;
+  float scale;        // 1 / sqrt(32)
+};
+
+// NW waves per workgroup; a query is owned by LQ consecutive lanes (64 / LQ queries per wave):
+// LQ = 4 for short sequences (the joint decoder's 15 queries), LQ = 16 for the pose decoder's 300
+// (19 keys per lane instead of 75: the stage is latency-bound, so the serial chain per lane counts)
+template <int NW, int LQ>
+__global__ __launch_bounds__(NW * 64) void mha_core_kernel(const MhaParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // K rows, then V rows
+  constexpr int QW = 64 / LQ;                                   // queries per wave
+  const int L = p.L, E = p.H * kD;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  float* ks = lds;
+  float* vs = lds + (size_t)L * kPad;
+  const float* base = p.qkv + (size_t)seq * L * p.ld + head * kD;
+  // ---- stage K_h and V_h: 8 lanes x 16 B per row; the loads of a batch are all in flight before
+  // the first LDS store (one L2 round trip per batch, not per chunk)
+  constexpr int SU = 5;
+  for (int i0 = threadIdx.x; i0 < L * 8; i0 += SU * NW * 64) {
+    float4 kreg[SU], vreg[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + u * NW * 64;
+      if (i < L * 8) {
+        const float* src = base + (size_t)(i >> 3) * p.ld + (i & 7) * 4;
+        kreg[u] = *reinterpret_cast<const float4*>(src + E);
+        vreg[u] = *reinterpret_cast<const float4*>(src + 2 * E);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + u * NW * 64;
+      if (i < L * 8) {
+        *reinterpret_cast<float4*>(ks + (i >> 3) * kPad + (i & 7) * 4) = kreg[u];
+        *reinterpret_cast<float4*>(vs + (i >> 3) * kPad + (i & 7) * 4) = vreg[u];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & (LQ - 1);
+  const int qi = blockIdx.x * (NW * QW) + wave * QW + lane / LQ;
+  const bool valid = qi < L;
+  float q[kD];
+  {
+    const float* qrow = base + (size_t)(valid ? qi : 0) * p.ld;
+#pragma unroll
+    for (int c = 0; c < kD; c += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(qrow + c);
+      q[c] = t.x * p.scale, q[c + 1] = t.y * p.scale, q[c + 2] = t.z * p.scale, q[c + 3] = t.w * p.scale;
+    }
+  }
+  __syncthreads();
+
+  float m = -INFINITY, l = 0.f;
+  float o[kD];
+#pragma unroll
+  for (int c = 0; c < kD; ++c) o[c] = 0.f;
+  // lane r walks the keys j = r + LQ t; a group = kGroup consecutive t
+  for (int j0 = r; j0 < L; j0 += LQ * kGroup) {
+    float s[kGroup];
+    int jj[kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      const int j = j0 + LQ * g;
+      jj[g] = j < L ? j : L - 1;          // clamped row, score forced to -inf below
+      const float* kr = ks + jj[g] * kPad;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < kD; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(kr + c);
+        acc = fmaf(q[c], t.x, acc);
+        acc = fmaf(q[c + 1], t.y, acc);
+        acc = fmaf(q[c + 2], t.z, acc);
+        acc = fmaf(q[c + 3], t.w, acc);
+      }
+      s[g] = j < L ? acc : -INFINITY;
+    }
+    float mn = m;
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) mn = fmaxf(mn, s[g]);
+    // (s[0] is always a real key, so mn is finite from the first group on)
+    const float alpha = __expf(m - mn);   // exp(-inf) = 0 on the first group
+    l *= alpha;
+#pragma unroll
+    for (int c = 0; c < kD; ++c) o[c] *= alpha;
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      const float pg = __expf(s[g] - mn);
+      l += pg;
+      const float* vr = vs + jj[g] * kPad;
+#pragma unroll
+      for (int c = 0; c < kD; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(vr + c);
+        o[c] = fmaf(pg, t.x, o[c]);
+        o[c + 1] = fmaf(pg, t.y, o[c + 1]);
+        o[c + 2] = fmaf(pg, t.z, o[c + 2]);
+        o[c + 3] = fmaf(pg, t.w, o[c + 3]);
+      }
+    }
+    m = mn;
+  }
+  // ---- merge the LQ partial states of a query (a lane without keys: m = -inf, l = 0, weight 0):
+  // butterfly over the lane bits; the channel range a lane keeps halves at every step, so lane r
+  // ends with the 32 / LQ channels from (32 / LQ) r on
+  float M = m;
+#pragma unroll
+  for (int st = LQ / 2; st >= 1; st >>= 1) M = fmaxf(M, __shfl_xor(M, st, 64));
+  const float w = (m == -INFINITY) ? 0.f : __expf(m - M);
+  float lsum = l * w;
+#pragma unroll
+  for (int st = LQ / 2; st >= 1; st >>= 1) lsum += __shfl_xor(lsum, st, 64);
+  const float inv = 1.f / lsum;
+#pragma unroll
+  for (int c = 0; c < kD; ++c) o[c] *= w;
+  {
+    int n = kD;
+#pragma unroll
+    for (int st = LQ / 2; st >= 1; st >>= 1) {
+      n >>= 1;
+      const bool hi = (r & st) != 0;
+#pragma unroll
+      for (int i = 0; i < kD / 2; ++i) {
+        if (i < n) {
+          const float keep = hi ? o[n + i] : o[i], send = hi ? o[i] : o[n + i];
+          o[i] = keep + __shfl_xor(send, st, 64);
+        }
+      }
+    }
+  }
+  constexpr int CW = kD / LQ;   // channels per lane: 8 (LQ 4) | 2 (LQ 16)
+  if (valid) {
+    float* orow = p.out + ((size_t)seq * L + qi) * E + head * kD + r * CW;
+    if (CW == 8) {
+      *reinterpret_cast<float4*>(orow) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      *reinterpret_cast<float4*>(orow + 4) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+    } else {
+      *reinterpret_cast<float2*>(orow) = make_float2(o[0] * inv, o[1] * inv);
+    }
+  }
+}
+
+template <int NW, int LQ>
+int launch_mha(const MhaParams& p, int n_seq, hipStream_t st) {
+  const size_t smem = (size_t)2 * p.L * kPad * sizeof(float);
+  auto kern = mha_core_kernel<NW, LQ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "mha_core: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  constexpr int QB = NW * (64 / LQ);   // queries per workgroup
+  const dim3 grid((unsigned)((p.L + QB - 1) / QB), (unsigned)p.H, (unsigned)n_seq);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+}  // namespace
+
+extern "C" int pave_mha_core_f32(const float* qkv, float* out, int n_seq, int L, int H, int ld,
+                                 void* stream) {
+  if (!qkv || !out) return pave_internal_fail(PAVE_E_ARG, "mha_core: null pointer");
+  if (n_seq <= 0 || L <= 0 || H <= 0 || n_seq > 65535 || H > 65535)
+    return pave_internal_fail(PAVE_E_ARG, "mha_core: sizes must be positive (n_seq, H <= 65535)");
+  if (ld < 3 * H * kD || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(qkv) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15))
+    return pave_internal_fail(PAVE_E_ARG, "mha_core: ld >= 3 * H * 32, ld %% 4 == 0, 16-byte aligned pointers");
+  if ((size_t)2 * L * kPad * sizeof(float) > 160 * 1024)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "mha_core: K and V of one head must fit in LDS (L <= 568)");
+  MhaParams p{qkv, out, L, H, ld, 0.17677669529663687f /* 1 / sqrt(32) */};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (L <= 16) return launch_mha<1, 4>(p, n_seq, st);
+  if (L <= 64) return launch_mha<4, 16>(p, n_seq, st);
+  return launch_mha<8, 16>(p, n_seq, st);
+}
+
+// ---------------------------------------------------------------------------
+// Row-wise top-k (k <= 1024 of n <= 32768 per row), one launch: the 300-of-S proposal selection
+// (opera/models/utils/transformer.py:21383-21385) and the N-of-300 score selection
+// (opera/models/dense_heads/videopose_head_mul_frames.py:1416) -- torch.topk's multi-block radix
+// path is ~22 launches for the former.  One 1024-thread workgroup per row: the row is copied to
+// LDS once (coalesced), the k-th largest value is found by a 4 x 8-bit radix select over
+// order-preserving keys, the k winners are compacted in index order (ties at the k-th value: the
+// lowest indices, whatever the launch geometry) and sorted by (value descending, index
+// ascending) with a bitonic network in LDS.  NaN ranks above +inf, as in torch.topk.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kTopkThreads = 1024;
+constexpr int kTopkMaxN = 32768;
+constexpr int kTopkMaxK = 1024;
+
+__device__ __forceinline__ unsigned order_key(float x) {
+  const unsigned b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct TopkParams {
+  const float* x;   // element (r, i) at x[r ld + i cs]
+  float* values;    // [rows, k] or null
+  long long* index; // [rows, k]
+  int n, k, ld, cs;
+};
+
+__global__ __launch_bounds__(kTopkThreads) void topk_rows_kernel(const TopkParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  unsigned* keys = reinterpret_cast<unsigned*>(tsm);                          // [n]
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(keys + ((p.n + 1) & ~1));  // [sort size]
+  __shared__ unsigned hist[256];
+  __shared__ unsigned wtot[4];
+  __shared__ unsigned sel_prefix, sel_need;
+  __shared__ unsigned long long wsum[kTopkThreads / 64];
+  const int tid = threadIdx.x, n = p.n, k = p.k;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float* row = p.x + (size_t)blockIdx.x * p.ld;
+  for (int i = tid; i < n; i += kTopkThreads) keys[i] = order_key(row[(size_t)i * p.cs]);
+  if (tid == 0) sel_prefix = 0u, sel_need = (unsigned)k;
+  __syncthreads();
+  // ---- radix select, most significant byte first: after the pass over byte b, `prefix` holds the
+  // top (4 - b) bytes of the k-th largest key and `need` how many keys with exactly that prefix
+  // are still to be taken
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = sel_prefix, need = sel_need;
+    const unsigned hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    // (logits share their sign / exponent byte: the first pass would pile every lane's atomic on two
+    // or three bins.  A wave first counts its four most frequent digits with ballots -- one atomic
+    // each -- and only the lanes left over add individually)
+    for (int ib = wave * 64; ib < n; ib += kTopkThreads) {
+      const int i = ib + lane;
+      const unsigned kk = i < n ? keys[i] : 0u;
+      const bool match = i < n && (kk & hi_mask) == prefix;
+      const unsigned bin = (kk >> shift) & 255u;
+      unsigned long long rem = __ballot(match);
+      for (int it = 0; it < 4 && rem != 0ull; ++it) {
+        const int first = __ffsll((long long)rem) - 1;
+        const unsigned b = (unsigned)__shfl((int)bin, first, 64);
+        const unsigned long long m = __ballot(match && bin == b) & rem;
+        if (lane == first) atomicAdd(&hist[b], (unsigned)__popcll(m));
+        rem &= ~m;
+      }
+      if ((rem >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    // thread t < 256 owns bin 255 - t (descending); inclusive scan of the counts over t: the bin
+    // where the running count first reaches `need` is the next byte of the k-th key
+    unsigned c = 0, incl = 0;
+    if (tid < 256) {
+      c = hist[255 - tid];
+      incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wtot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      for (int w = 0; w < wave; ++w) incl += wtot[w];
+      if (incl >= need && incl - c < need) {     // exactly one thread
+        sel_prefix = prefix | ((unsigned)(255 - tid) << shift);
+        sel_need = need - (incl - c);
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned kth = sel_prefix, need_eq = sel_need;   // need_eq >= 1 keys equal to kth are taken
+  // ---- ordered compaction: thread t owns the contiguous index range [t c, (t + 1) c)
+  const int chunk = (n + kTopkThreads - 1) / kTopkThreads;
+  const int i0 = tid * chunk, i1 = min(n, i0 + chunk);
+  unsigned n_gt = 0, n_eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const unsigned kk = keys[i];
+    n_gt += kk > kth;
+    n_eq += kk == kth;
+  }
+  // block-wide exclusive scans of (n_gt, n_eq), packed into one 64-bit sum per thread
+  unsigned long long v = ((unsigned long long)n_gt << 32) | n_eq, incl = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  int ssz = 32;                                          // sort size: power of two >= k
+  while (ssz < k) ssz <<= 1;
+  for (int i = tid; i < ssz; i += kTopkThreads) cand[i] = 0ull;   // padding sorts last
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+  for (int w = 0; w < kTopkThreads / 64; ++w) {
+    const unsigned long long t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  const unsigned long long excl = base + incl - v;
+  const unsigned total_gt = (unsigned)(tot >> 32);        // == k - need_eq
+  unsigned o_gt = (unsigned)(excl >> 32), o_eq = (unsigned)excl;
+  for (int i = i0; i < i1; ++i) {
+    const unsigned kk = keys[i];
+    const unsigned long long item = ((unsigned long long)kk << 32) | (0xffffffffu - (unsigned)i);
+    if (kk > kth) cand[o_gt++] = item;
+    else if (kk == kth) {
+      if (o_eq < need_eq) cand[total_gt + o_eq] = item;
+      ++o_eq;
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort of the ssz slots, descending (composite: key, then lower index first)
+  for (int size = 2; size <= ssz; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int j = tid ^ stride;
+      if (tid < ssz && j > tid) {
+        const unsigned long long a = cand[tid], b = cand[j];
+        const bool desc = (tid & size) == 0;
+        if (desc ? a < b : a > b) cand[tid] = b, cand[j] = a;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < k) {
+    const unsigned long long item = cand[tid];
+    const unsigned idx = 0xffffffffu - (unsigned)item;
+    p.index[(size_t)blockIdx.x * k + tid] = (long long)idx;
+    if (p.values) p.values[(size_t)blockIdx.x * k + tid] = row[(size_t)idx * p.cs];
+  }
+}
+
+}  // namespace
+
+extern "C" int pave_topk_rows_f32(const float* x, float* values, long long* index, int rows, int n,
+                                  int ld, int cs, int k, void* stream) {
+  if (!x || !index) return pave_internal_fail(PAVE_E_ARG, "topk_rows: null pointer");
+  if (rows <= 0 || n <= 0 || k <= 0 || k > n || cs <= 0 || (rows > 1 && (long long)ld < (long long)(n - 1) * cs + 1))
+    return pave_internal_fail(PAVE_E_ARG, "topk_rows: rows, n, cs > 0, 0 < k <= n, ld >= (n - 1) cs + 1");
+  if (n > kTopkMaxN || k > kTopkMaxK)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "topk_rows: n <= 32768 and k <= 1024");
+  const size_t smem = (size_t)((n + 1) & ~1) * 4 + (size_t)kTopkMaxK * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "topk_rows: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  TopkParams p{x, values, index, n, k, ld, cs};
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)rows), dim3(kTopkThreads), smem,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Selected poses of all frames in one gather (videopose_head_mul_frames.py:1419-1427, 610: the
+// reference gathers the N selected queries from the centre-frame key points and from every
+// auxiliary frame's, then concatenates them frame-major):
+//   poses [B, T * Q, C] (frame t at rows [t Q, (t + 1) Q)), index [B, N] -> out [T, B * N, C]
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void gather_frame_poses_kernel(const float* __restrict__ poses,
+                                                                 const long long* __restrict__ index,
+                                                                 float* __restrict__ out, int B, int T,
+                                                                 int Q, int N, int C) {
+  const long long total = (long long)T * B * N * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int bn = (int)(r % ((long long)B * N)), t = (int)(r / ((long long)B * N));
+    const int b = bn / N;
+    long long q = index[bn];
+    q = q < 0 ? 0 : (q >= Q ? Q - 1 : q);   // (a bad index never becomes an out-of-range read)
+    out[i] = poses[((long long)b * T * Q + (long long)t * Q + q) * C + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Post-processing of the refined poses, one launch (videopose_head_mul_frames.py:1440-1490 +
+// get_p, :1531-1535): key points to pixels (x img_w, y img_h), clamp to the image, optional
+// division by the scale factor, bounding box = min / max over the key points, RLE confidence
+// p = 0.7 (1 - exp(-0.2 / sigma_x)) (1 - exp(-0.2 / sigma_y)), kpt <- kpt p^5 / (p^5 + 1e-10),
+// key-point score = pose score x p.  Same operations in the same order as the tensor
+// expressions they replace (expf / powf / IEEE division as ATen's kernels use them).
+//   kpts, sigmas [B, N, K, 2]; scores [B, N]; wh, sf [B, 2]
+//   -> det_kpts [B, N, K, 3], det_bboxes [B, N, 5]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pose_finalize_kernel(const float* __restrict__ kpts,
+                                                           const float* __restrict__ sigmas,
+                                                           const float* __restrict__ scores,
+                                                           const float* __restrict__ wh,
+                                                           const float* __restrict__ sf, float* det_kpts,
+                                                           float* det_bboxes, int N, int K, int rescale) {
+  const int pose = blockIdx.x, b = pose / N, j = threadIdx.x;
+  const bool act = j < K;
+  const float w = wh[b * 2], h = wh[b * 2 + 1];
+  float x = 0.f, y = 0.f, sx = 1.f, sy = 1.f;
+  if (act) {
+    const float2 kp = *reinterpret_cast<const float2*>(kpts + ((size_t)pose * K + j) * 2);
+    const float2 sg = *reinterpret_cast<const float2*>(sigmas + ((size_t)pose * K + j) * 2);
+    x = fminf(fmaxf(kp.x * w, 0.f), w);
+    y = fminf(fmaxf(kp.y * h, 0.f), h);
+    if (rescale) x = x / sf[b * 2], y = y / sf[b * 2 + 1];
+    sx = sg.x, sy = sg.y;
+  }
+  float x1 = act ? x : INFINITY, y1 = act ? y : INFINITY, x2 = act ? x : -INFINITY,
+        y2 = act ? y : -INFINITY;
+  for (int o = 32; o > 0; o >>= 1) {
+    x1 = fminf(x1, __shfl_xor(x1, o, 64));
+    y1 = fminf(y1, __shfl_xor(y1, o, 64));
+    x2 = fmaxf(x2, __shfl_xor(x2, o, 64));
+    y2 = fmaxf(y2, __shfl_xor(y2, o, 64));
+  }
+  const float score = scores[pose];
+  if (act) {
+    const float px = 1.f - expf(-(0.2f / sx)), py = 1.f - expf(-(0.2f / sy));
+    const float p = (px * py) * 0.7f;
+    const float p5 = powf(p, 5.f);
+    float* o = det_kpts + ((size_t)pose * K + j) * 3;
+    o[0] = (x * p5) / (p5 + 1e-10f);
+    o[1] = (y * p5) / (p5 + 1e-10f);
+    o[2] = score * p;
+  }
+  if (j == 0) {
+    float* bb = det_bboxes + (size_t)pose * 5;
+    bb[0] = x1, bb[1] = y1, bb[2] = x2, bb[3] = y2, bb[4] = score;
+  }
+}
+}  // namespace
+
+extern "C" int pave_gather_frame_poses_f32(const float* poses, const long long* index, float* out, int B,
+                                           int T, int Q, int N, int C, void* stream) {
+  if (!poses || !index || !out) return pave_internal_fail(PAVE_E_ARG, "gather_frame_poses: null pointer");
+  if (B <= 0 || T <= 0 || Q <= 0 || N <= 0 || C <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "gather_frame_poses: sizes must be positive");
+  const long long total = (long long)T * B * N * C;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(gather_frame_poses_kernel, dim3(blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), poses, index, out, B, T, Q, N, C);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+extern "C" int pave_pose_finalize_f32(const float* kpts, const float* sigmas, const float* scores,
+                                      const float* wh, const float* sf, float* det_kpts,
+                                      float* det_bboxes, int B, int N, int K, int rescale, void* stream) {
+  if (!kpts || !sigmas || !scores || !wh || !det_kpts || !det_bboxes || (rescale && !sf))
+    return pave_internal_fail(PAVE_E_ARG, "pose_finalize: null pointer");
+  if (B <= 0 || N <= 0 || K <= 0 || K > 64)
+    return pave_internal_fail(PAVE_E_ARG, "pose_finalize: B, N > 0 and 0 < K <= 64");
+  hipLaunchKernelGGL(pose_finalize_kernel, dim3((unsigned)(B * N)), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), kpts, sigmas, scores, wh, sf, det_kpts,
+                     det_bboxes, N, K, rescale);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Reference-point update straight from the grouped per-frame MLP output (one launch instead of a
+// layout copy + the update):  y [R, T * op] (row r, frame t's `o` outputs at columns [t op, t op + o))
+//   out[(r / G) T G + t G + r % G][c] = sigmoid(y[r][t op + c] + inverse_sigmoid(ref[same]))
+// G = queries per clip (pose decoder: rows frame-major inside a clip, OT:6728-6735) or G = R (joint
+// decoder: frame-major over all rows, MT:861-866).  Same fp32 operation order as pave_ref_update_f32.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ref_update_frames_kernel(const float* __restrict__ y,
+                                                                const float* __restrict__ ref,
+                                                                float* __restrict__ out, int R, int T,
+                                                                int op, int o, int G, float eps) {
+  const long long n = (long long)R * T * o;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % o);
+    const long long rt = i / o;
+    const int t = (int)(rt % T), r = (int)(rt / T);
+    const long long orow = (long long)(r / G) * T * G + (long long)t * G + r % G;
+    const float x = fminf(fmaxf(ref[orow * o + c], 0.f), 1.f);
+    const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+    const float v = y[(long long)r * T * op + (long long)t * op + c] + logf(x1 / x2);
+    out[orow * o + c] = 1.f / (1.f + expf(-v));
+  }
+}
+}  // namespace
+
+extern "C" int pave_ref_update_frames_f32(const float* y, const float* ref, float* out, int R, int T,
+                                          int op, int o, int G, float eps, void* stream) {
+  if (!y || !ref || !out) return pave_internal_fail(PAVE_E_ARG, "ref_update_frames: null pointer");
+  if (R <= 0 || T <= 0 || o <= 0 || op < o || G <= 0 || R % G != 0)
+    return pave_internal_fail(PAVE_E_ARG, "ref_update_frames: R, T, o > 0, op >= o, R %% G == 0");
+  const long long n = (long long)R * T * o;
+  const unsigned nb = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(ref_update_frames_kernel, dim3(nb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), y, ref, out, R, T, op, o, G, eps);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}

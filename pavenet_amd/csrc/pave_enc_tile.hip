@@ -366,10 +366,14 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const float rW = __int_as_float(tabB.y), rH = __int_as_float(tabB.z);
 
   // ---- softmax over the 16 logits of (unit, head): 4 per lane, quad reduction
-  const float mx = quad_max(fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w)));
-  const float e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx), e2 = __expf(lg.z - mx),
-              e3 = __expf(lg.w - mx);
-  float inv_sum = __builtin_amdgcn_rcpf(quad_sum((e0 + e1) + (e2 + e3)));  // 1 ulp
+  float e0, e1, e2, e3, inv_sum;
+  if (ABL & 4) {   // timing only: weights taken as given (what a producer-side softmax would leave)
+    e0 = lg.x, e1 = lg.y, e2 = lg.z, e3 = lg.w, inv_sum = 1.f;
+  } else {
+    const float mx = quad_max(fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w)));
+    e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx), e2 = __expf(lg.z - mx), e3 = __expf(lg.w - mx);
+    inv_sum = __builtin_amdgcn_rcpf(quad_sum((e0 + e1) + (e2 + e3)));  // 1 ulp
+  }
   if (!valid) inv_sum = 0.f;  // idle slots carry weight 0 through the DPP steps
 
   // ---- corner descriptors of my 4 points
@@ -380,8 +384,13 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
     const float ee[4] = {e0, e1, e2, e3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float lx = rf.x + div_by(ofx[i], fW, rW), ly = rf.y + div_by(ofy[i], fH, rH);  // MO:381-384
-      const float px = lx * fW - 0.5f, py = ly * fH - 0.5f;  // cuda_kernel.cuh:233-234
+      float px, py;
+      if (ABL & 4) {   // timing only: positions taken as given in level pixels
+        px = fmaf(rf.x, fW, ofx[i]) - 0.5f, py = fmaf(rf.y, fH, ofy[i]) - 0.5f;
+      } else {
+        const float lx = rf.x + div_by(ofx[i], fW, rW), ly = rf.y + div_by(ofy[i], fH, rH);  // MO:381-384
+        px = lx * fW - 0.5f, py = ly * fH - 0.5f;  // cuda_kernel.cuh:233-234
+      }
       flags |= make_point(d[i], px, py, ee[i] * inv_sum, H, W, st, ox, oy, ww, wbase, G::kZ, par)
                << (3 * i);
     }
@@ -507,7 +516,8 @@ extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* pr
 
 #ifdef PAVE_DIAG
 // Timing-only ablations for tools/bench_kernels.py (-DPAVE_DIAG build only, outputs are wrong):
-// ablate 1 = no window staging, 2 = no gather loop, 3 = neither.
+// ablate 1 = no window staging, 2 = no gather loop, 3 = neither, 4 = no softmax / location arithmetic
+// (what moving them into the projection GEMM's epilogue would leave), 6 = 4 + 2.
 extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, const float* ref,
                                          float* out, int n_frames, int S, const int* levels_hw,
                                          int proj_stride, int variant, int ablate, void* stream) {
@@ -515,6 +525,8 @@ extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, 
     case 1: return enc_tile_launch<1>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     case 2: return enc_tile_launch<2>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     case 3: return enc_tile_launch<3>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
+    case 4: return enc_tile_launch<4>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
+    case 6: return enc_tile_launch<6>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
   }
 }

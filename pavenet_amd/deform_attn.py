@@ -654,7 +654,11 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         proj = linear_rows(q.reshape(N * num_query, self.embed_dims), w, b)
         ref = reference_points.reshape(T, N * num_query, L, 2)
         if _fused_ok(self, q, v) and L == 4 and P == 4:
-            unit_clip = clip_index.to(torch.int32).repeat_interleave(num_query)
+            hit = self.__dict__.get('_pave_unit_clip')   # (the head passes one cached index tensor)
+            if hit is None or hit[0] is not clip_index or hit[1] != num_query:
+                hit = (clip_index, num_query, clip_index.to(torch.int32).repeat_interleave(num_query))
+                self.__dict__['_pave_unit_clip'] = hit
+            unit_clip = hit[2]
             out = ops.deform_attn_grid_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
                 proj, ref if ref.is_contiguous() else ref.contiguous(), T=T, n_clips=n_clips,

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .bricks import (BaseModule, Linear, bias_init_with_prob, build_activation_layer,
-                     constant_init)
+                     constant_init, mlp_rows)
 from .deform_attn import frame_prefixes
 from .transformer import _frame_branches, _ref_update
 from .registry import HEADS, LOSSES, MMDET_MODELS, build_positional_encoding, build_transformer
@@ -265,7 +265,7 @@ class VideoPoseHeadMulFrames(BaseModule):
                 has_padding=has_padding, **tr_kwargs)
         hs = hs.permute(0, 2, 1, 3)
         outputs_classes, outputs_kpts, output_sigmas = [], [], []
-        aux_poses = None
+        aux_poses = all_frame_poses = None
         n_lvl = hs.shape[0]
         # The class / key-point / sigma branches of the earlier decoder levels only feed training
         # losses (HEAD:1304-1330 reads [-1]); in eval mode they are skipped unless asked for.
@@ -278,36 +278,45 @@ class VideoPoseHeadMulFrames(BaseModule):
                 # transformer._frame_branches), then ONE reference update over [B, T*Q, 2K]
                 brs = [getattr(self, ('next_' if (T == 5 and t == 4) else fp) + 'kpt_branches')
                        for t, fp in enumerate(self.frame_prefixes)]   # HEAD:503 quirk kept
-                poses = _ref_update(_frame_branches(brs, lvl, hs[lvl], 1), reference)
+                poses = _frame_branches(brs, lvl, hs[lvl], 1, update_ref=reference)
+                all_frame_poses = poses
                 aux_poses = [None if t == c else poses[:, t * Q:(t + 1) * Q] for t in range(T)]
                 outputs_kpt = poses[:, c * Q:(c + 1) * Q]
             else:
                 # (tmp + inverse_sigmoid(reference)).sigmoid(): one launch on the device
-                outputs_kpt = _ref_update(self.kpt_branches[lvl](hs[lvl]),
+                outputs_kpt = _ref_update(mlp_rows(self.kpt_branches[lvl], hs[lvl]),
                                           reference[:, c * Q:(c + 1) * Q])
-            outputs_class = self.cls_branches[lvl](hs[lvl])
-            output_sigma = self.dec_fc_sigma_branches[lvl](hs[lvl]).sigmoid()
+            outputs_class = mlp_rows(self.cls_branches[lvl], hs[lvl])
+            output_sigma = mlp_rows(self.dec_fc_sigma_branches[lvl], hs[lvl]).sigmoid()
             outputs_classes.append(outputs_class)
             outputs_kpts.append(outputs_kpt)
             output_sigmas.append(output_sigma)
-        return dict(all_cls_scores=torch.stack(outputs_classes),
-                    all_kpt_preds=torch.stack(outputs_kpts),
-                    all_sigma_preds=torch.stack(output_sigmas),
-                    enc_cls_scores=enc_outputs_class, enc_kpt_preds=enc_outputs_kpt.sigmoid(),
-                    enc_sigma_preds=enc_outputs_sigma.sigmoid(), memory=memory,
+        one = len(outputs_classes) == 1        # a one-level stack is a view, not a copy
+        stack = (lambda ts: ts[0].unsqueeze(0)) if one else torch.stack
+        # (the encoder-side predictions only feed training losses: left un-activated at inference)
+        lazy = only_last and not self.training
+        return dict(all_cls_scores=stack(outputs_classes),
+                    all_kpt_preds=stack(outputs_kpts),
+                    all_sigma_preds=stack(output_sigmas),
+                    enc_cls_scores=enc_outputs_class,
+                    enc_kpt_preds=None if lazy else enc_outputs_kpt.sigmoid(),
+                    enc_sigma_preds=None if lazy else enc_outputs_sigma.sigmoid(), memory=memory,
                     mlvl_masks=mlvl_masks, has_padding=has_padding, aux_poses=aux_poses,
+                    all_frame_poses=all_frame_poses, last_level_only=lazy,
                     frame_shard=shard, refine_value_cache=refine_value_cache,
                     hs=hs, init_reference=init_reference, inter_references=inter_references)
 
     # HEAD:569-674 (inference branch) ----------------------------------------
     def forward_refine(self, memory, mlvl_masks, frame_poses, img_inds, has_padding=True,
-                       frame_shard=None, value_cache=None):
+                       frame_shard=None, value_cache=None, last_level_only=None):
         """frame_poses: list of T tensors [Ntot, 2K] (centre = selected kpt preds).
         Returns (kpts [Ntot, K, 2] normalised, score [Ntot, K, 1], sigma [Ntot, K, 2]) of the last
         refine layer plus all intermediates."""
         T = self.num_frames
         c = T // 2
-        pos_kpt_preds = torch.cat(frame_poses, dim=0)  # frame-major, HEAD:610
+        # frame-major, HEAD:610 (a [T, Ntot, 2K] tensor: already concatenated by the gather)
+        pos_kpt_preds = frame_poses.flatten(0, 1) if torch.is_tensor(frame_poses) else \
+            torch.cat(frame_poses, dim=0)
         S = memory.size(0)
         Tl = T if frame_shard is None else frame_shard.n_local
         mem4 = memory.reshape(S, -1, Tl, memory.size(-1))  # [S, B, T(_loc), C] view
@@ -320,15 +329,20 @@ class VideoPoseHeadMulFrames(BaseModule):
             frame_shard=frame_shard, **extra)
         hs = hs.permute(0, 2, 1, 3)
         outs_kpt, outs_sigma, outs_score = [], [], []
-        for lvl in range(hs.shape[0]):
+        # (only the last refine level is read outside training, HEAD:1430-1438: one-level stacks)
+        n_lvl = hs.shape[0]
+        only_last = self.eval_last_level_only if last_level_only is None else bool(last_level_only)
+        levels = [n_lvl - 1] if (only_last and not self.training) else range(n_lvl)
+        for lvl in levels:
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             n = reference.shape[0] // T
-            tmp_kpt = self.refine_kpt_branches[lvl](hs[lvl])
-            tmp_sigma = self.refine_fc_sigma_branches[lvl](hs[lvl]).sigmoid()
+            tmp_kpt = mlp_rows(self.refine_kpt_branches[lvl], hs[lvl])
+            tmp_sigma = mlp_rows(self.refine_fc_sigma_branches[lvl], hs[lvl]).sigmoid()
             outs_score.append(torch.mean(1 - tmp_sigma, dim=2, keepdim=True))
             outs_kpt.append(_ref_update(tmp_kpt, reference[c * n:(c + 1) * n]))
             outs_sigma.append(tmp_sigma)
-        return torch.stack(outs_kpt), torch.stack(outs_score), torch.stack(outs_sigma), hs
+        stack = (lambda ts: ts[0].unsqueeze(0)) if len(outs_kpt) == 1 else torch.stack
+        return stack(outs_kpt), stack(outs_score), stack(outs_sigma), hs
 
     @staticmethod
     def get_p(output_regression_sigma, p_x=0.2):
@@ -336,6 +350,12 @@ class VideoPoseHeadMulFrames(BaseModule):
         p = 1 - torch.exp(-(p_x / output_regression_sigma))
         p = p[:, :, 0] * p[:, :, 1]
         return p[:, :, None] * 0.7
+
+    def _cached(self, key, make):
+        """Shape-derived constant tensors (no dependence on the inputs), built once per key."""
+        if key not in self._consts:
+            self._consts[key] = make()
+        return self._consts[key]
 
     def _meta_scales(self, img_metas, device):
         """[B,1,1,2] (w, h) and scale-factor tensors of the clips, cached on the device (a
@@ -375,7 +395,11 @@ class VideoPoseHeadMulFrames(BaseModule):
         N = self.test_cfg.get('max_per_img', self.num_query)
         assert self.loss_cls.use_sigmoid
         cls_score = cls_scores.sigmoid().view(B, -1)
-        scores, indexs = cls_score.topk(N, dim=1)
+        fused = cls_score.is_cuda and cls_score.dtype == torch.float32 and not torch.is_grad_enabled()
+        if fused and cls_score.shape[1] <= 32768 and N <= 1024:
+            scores, indexs = ops.topk_rows(cls_score, N)          # one launch
+        else:
+            scores, indexs = cls_score.topk(N, dim=1)
         if force_score_topk is not None:
             indexs = force_score_topk
             scores = torch.gather(cls_score, 1, indexs)
@@ -386,18 +410,29 @@ class VideoPoseHeadMulFrames(BaseModule):
             from . import dist as pdist
             indexs = pdist.broadcast_from(indexs.contiguous(), 0, shard.group)
             scores = torch.gather(cls_score, 1, indexs)
-        det_labels = indexs % self.num_classes
-        bbox_index = indexs // self.num_classes                     # [B, N]
-        gidx = bbox_index.unsqueeze(-1).expand(-1, -1, 2 * K)
-        frame_poses = []
-        for t in range(T):
-            src = kpt_preds if t == c else outs['aux_poses'][t]
-            frame_poses.append(torch.gather(src, 1, gidx).reshape(B * N, 2 * K))
-        img_inds = torch.arange(B, device=cls_scores.device).repeat_interleave(N)
+        if self.num_classes == 1:
+            bbox_index = indexs                                      # [B, N]
+            det_labels = self._cached(('labels0', B, N, str(indexs.device)),
+                                      lambda: torch.zeros((B, N), dtype=indexs.dtype, device=indexs.device))
+        else:
+            det_labels = indexs % self.num_classes
+            bbox_index = indexs // self.num_classes
+        all_poses = outs.get('all_frame_poses')     # [B, T*Q, 2K]: every frame's poses, frame-major
+        if fused and all_poses is not None and all_poses.is_contiguous():
+            # the N selected queries of all T frames in one gather, already frame-major
+            frame_poses = ops.gather_frame_poses(all_poses, bbox_index.contiguous(), T)
+        else:
+            gidx = bbox_index.unsqueeze(-1).expand(-1, -1, 2 * K)
+            frame_poses = []
+            for t in range(T):
+                src = kpt_preds if t == c else outs['aux_poses'][t]
+                frame_poses.append(torch.gather(src, 1, gidx).reshape(B * N, 2 * K))
+        img_inds = self._cached(('img_inds', B, N, str(cls_scores.device)),
+                                lambda: torch.arange(B, device=cls_scores.device).repeat_interleave(N))
         r_kpts, r_scores, r_sigmas, r_hs = self.forward_refine(
             outs['memory'], outs['mlvl_masks'], frame_poses, img_inds,
             has_padding=outs['has_padding'], frame_shard=outs.get('frame_shard'),
-            value_cache=outs.get('refine_value_cache'))
+            value_cache=outs.get('refine_value_cache'), last_level_only=outs.get('last_level_only'))
         det_kpts = r_kpts[-1].view(B, N, K, 2)
         det_sigmas = r_sigmas[-1].view(B, N, K, 2)
         if taps is not None:
@@ -405,6 +440,14 @@ class VideoPoseHeadMulFrames(BaseModule):
                         refine_sigma=det_sigmas)
         dev = det_kpts.device
         wh, sf = self._meta_scales(img_metas, dev)
+        if fused and K <= 64 and det_kpts.is_contiguous() and det_sigmas.is_contiguous():
+            # pixels / clamp / rescale / box / RLE confidence / key-point scores: one launch
+            scores = scores.contiguous()
+            det_kpts, det_bboxes = ops.pose_finalize(det_kpts, det_sigmas, scores, wh.view(B, 2),
+                                                     sf.view(B, 2) if rescale else None)
+            keep, order = ops.oks_nms(det_kpts, scores, self._sigmas(dev), self.oks_thresh)
+            return dict(bboxes=det_bboxes, labels=det_labels, kpts=det_kpts, keep=keep, order=order,
+                        scores=scores, score_index=indexs)
         det_kpts = det_kpts * wh
         det_kpts = torch.minimum(det_kpts.clamp(min=0), wh)
         if rescale:

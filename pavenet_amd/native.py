@@ -50,13 +50,18 @@ SIGNATURES = {
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
     'pave_bottleneck_chain_f32': [_vp] * 8 + [_c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp],
     'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _vp],
+    'pave_mha_core_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
+    'pave_topk_rows_f32': [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
+    'pave_gather_frame_poses_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [_vp],
+    'pave_pose_finalize_f32': [_vp] * 7 + [_c_int] * 4 + [_vp],
+    'pave_ref_update_frames_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [ctypes.c_float, _vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
 # every symbol include/pave_hip.h declares
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 14  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 15  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

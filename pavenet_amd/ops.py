@@ -751,6 +751,26 @@ def ref_update(tmp, ref, eps=1e-5):
     return out
 
 
+def ref_update_frames(y, ref, T, o, group, eps=1e-5):
+    """sigmoid(y_t + inverse_sigmoid(ref)) read straight from the grouped per-frame MLP output
+    y [R, T * op] (frame t's `o` outputs at columns [t op, t op + o)); ref [..., o] with R * T rows
+    ordered (r // group, t, r % group) -> same shape as ref.  One launch, no layout copy."""
+    lib = native.load()
+    _dev(y, 'y', torch.float32)
+    _dev(ref, 'ref', torch.float32)
+    R = y.shape[0]
+    op = y.shape[1] // int(T)
+    _require(y.dim() == 2 and op * T == y.shape[1] and op >= o and ref.shape[-1] == o
+             and ref.numel() == R * T * o and R % int(group) == 0,
+             'ref_update_frames: y [R, T*op], ref [R*T rows, o], R % group == 0')
+    out = torch.empty_like(ref)
+    with torch.cuda.device(y.device), _Timed('ref_update'):
+        st = lib.pave_ref_update_frames_f32(y.data_ptr(), ref.data_ptr(), out.data_ptr(), R, int(T),
+                                            op, int(o), int(group), float(eps), _stream_ptr())
+    native.check(st, 'ref_update_frames')
+    return out
+
+
 def groupnorm_nhwc_into(x_rows, gamma, beta, num_groups, eps, dst):
     """GroupNorm of an NHWC map given as rows x_rows [N, HW, C] (dense), written into dst
     [N, HW, C] whose batch stride may be larger than HW * C (a slice of a [N, S, C] token buffer).
@@ -852,6 +872,86 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
                                          _stream_ptr())
     native.check(st, 'gemm_bf16x3_ex')
     return out, out2
+
+
+def mha_core(qkv, n_seq, seq_len, num_heads):
+    """Scaled-dot-product core of the decoders' self-attention: qkv [n_seq * seq_len, >= 3 * E]
+    (q | k | v columns, E = num_heads * 32; row = (sequence, position)) -> [n_seq * seq_len, E] =
+    softmax(q k^T / sqrt(32)) v per (sequence, head).  pave_mha_core_f32 (csrc/pave_decoder.hip)."""
+    lib = native.load()
+    _dev(qkv, 'qkv', torch.float32)
+    E = int(num_heads) * 32
+    _require(qkv.dim() == 2 and qkv.shape[0] == n_seq * seq_len and qkv.shape[1] >= 3 * E,
+             'mha_core: qkv [n_seq * seq_len, >= 3 * num_heads * 32]')
+    out = torch.empty((qkv.shape[0], E), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        st = lib.pave_mha_core_f32(qkv.data_ptr(), out.data_ptr(), int(n_seq), int(seq_len),
+                                   int(num_heads), qkv.stride(0), _stream_ptr())
+    native.check(st, 'mha_core')
+    return out
+
+
+def topk_rows(x, k):
+    """torch.topk(x, k, dim=1) for a 2-D fp32 device tensor as ONE launch (pave_topk_rows_f32):
+    -> (values [rows, k], indices [rows, k] int64), sorted by value descending, ties by the
+    lower index.  x may be any strided 2-D view (no copy)."""
+    lib = native.load()
+    _require(isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+             and x.shape[0] > 0 and x.stride(1) > 0 and (x.shape[0] == 1 or x.stride(0) > 0),
+             'topk_rows: x [rows, n] fp32 on the device, positive strides')
+    rows, n = x.shape
+    k = int(k)
+    _require(0 < k <= n and n <= 32768 and k <= 1024, 'topk_rows: 0 < k <= n <= 32768, k <= 1024')
+    values = torch.empty((rows, k), dtype=torch.float32, device=x.device)
+    index = torch.empty((rows, k), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.pave_topk_rows_f32(x.data_ptr(), values.data_ptr(), index.data_ptr(), rows, n,
+                                    x.stride(0), x.stride(1), k, _stream_ptr())
+    native.check(st, 'topk_rows')
+    return values, index
+
+
+def gather_frame_poses(poses, index, T):
+    """poses [B, T*Q, C] (frame-major rows), index [B, N] int64 -> [T, B*N, C]: the selected
+    queries of every frame, frame-major (pave_gather_frame_poses_f32)."""
+    lib = native.load()
+    _dev(poses, 'poses', torch.float32)
+    _dev(index, 'index', torch.int64)
+    _require(poses.dim() == 3 and poses.shape[1] % T == 0 and index.dim() == 2
+             and index.shape[0] == poses.shape[0], 'gather_frame_poses: poses [B, T*Q, C], index [B, N]')
+    B, TQ, C = poses.shape
+    N = index.shape[1]
+    out = torch.empty((T, B * N, C), dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        st = lib.pave_gather_frame_poses_f32(poses.data_ptr(), index.data_ptr(), out.data_ptr(), B,
+                                             int(T), TQ // T, N, C, _stream_ptr())
+    native.check(st, 'gather_frame_poses')
+    return out
+
+
+def pose_finalize(kpts, sigmas, scores, wh, sf=None):
+    """Post-processing of the refined poses (HEAD:1440-1490 + get_p) in one launch:
+    kpts, sigmas [B, N, K, 2], scores [B, N], wh [B, 2] (image w, h), sf [B, 2] or None (rescale)
+    -> (det_kpts [B, N, K, 3], det_bboxes [B, N, 5])."""
+    lib = native.load()
+    for t, nm in ((kpts, 'kpts'), (sigmas, 'sigmas'), (scores, 'scores'), (wh, 'wh')):
+        _dev(t, nm, torch.float32)
+    _require(kpts.dim() == 4 and kpts.shape[-1] == 2 and kpts.shape == sigmas.shape
+             and tuple(scores.shape) == tuple(kpts.shape[:2]) and wh.numel() == 2 * kpts.shape[0],
+             'pose_finalize: kpts / sigmas [B, N, K, 2], scores [B, N], wh [B, 2]')
+    B, N, K, _ = kpts.shape
+    if sf is not None:
+        _dev(sf, 'sf', torch.float32)
+        _require(sf.numel() == 2 * B, 'pose_finalize: sf [B, 2]')
+    det_kpts = torch.empty((B, N, K, 3), dtype=torch.float32, device=kpts.device)
+    det_bboxes = torch.empty((B, N, 5), dtype=torch.float32, device=kpts.device)
+    with torch.cuda.device(kpts.device):
+        st = lib.pave_pose_finalize_f32(kpts.data_ptr(), sigmas.data_ptr(), scores.data_ptr(),
+                                        wh.data_ptr(), sf.data_ptr() if sf is not None else None,
+                                        det_kpts.data_ptr(), det_bboxes.data_ptr(), B, N, K,
+                                        int(sf is not None), _stream_ptr())
+    native.check(st, 'pose_finalize')
+    return det_kpts, det_bboxes
 
 
 def split_conv3x3_weight(weight, planes=3):

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .bricks import (Linear, batch_first, bias_init_with_prob, constant_init, inverse_sigmoid,
-                     seq_first_view, xavier_init)
+                     mlp_rows, seq_first_view, xavier_init)
 from .detectors import VideoPoseV1
 from .heads import (RealNVP, VideoPoseHeadMulFrames, _clones, _kpt_branch, _refine_kpt_branch,
                     _sigma_branch, _TrainingOnlyLoss)
@@ -106,7 +106,7 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
         if self.as_two_stage:
             output_memory, output_proposals = self.gen_encoder_output_proposals(
                 memory, attn_mask, geom)
-            enc_outputs_class = cls_branches[self.decoder.num_layers](output_memory)
+            enc_outputs_class = mlp_rows(cls_branches[self.decoder.num_layers], output_memory)
             topk = self.two_stage_num_proposals
             topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
             forced = kwargs.pop('force_topk_proposals', None)
@@ -117,7 +117,7 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
             rows = torch.gather(output_memory, 1,
                                 topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
             props = torch.gather(output_proposals, 1, topk_proposals.unsqueeze(-1).repeat(1, 1, 2))
-            topk_kpts_unact = kpt_branches[self.decoder.num_layers](rows)  # top-k rows only
+            topk_kpts_unact = mlp_rows(kpt_branches[self.decoder.num_layers], rows)  # top-k rows only
             topk_kpts_unact[..., 0::2] += props[..., 0:1]
             topk_kpts_unact[..., 1::2] += props[..., 1:2]
             enc_outputs_kpt_unact = topk_kpts_unact
@@ -135,7 +135,7 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
             enc_outputs_class = enc_outputs_kpt_unact = None
         inter_states, inter_references = self.decoder(
             query=seq_first_view(query.contiguous()), key=None, value=seq_first_view(memory),
-            query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
+            query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,
             reference_points=reference_points, spatial_shapes=spatial_shapes,
             level_start_index=level_start_index, valid_ratios=valid_ratios,
             kpt_branches=kpt_branches)
@@ -162,7 +162,7 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
                                                          reference_points_pose.size(1) // 2, 2)
         inter_states, inter_references = self.refine_decoder(
             query=seq_first_view(query.contiguous()), key=None, value=memory,
-            query_pos=seq_first_view(query_pos.contiguous()),
+            query_pos=seq_first_view(query_pos),
             key_padding_mask=mask_flatten if has_padding else None,
             reference_points=reference_points, spatial_shapes=geom.spatial_shapes,
             level_start_index=geom.level_start_index, valid_ratios=valid_ratios[img_inds],
@@ -260,8 +260,8 @@ class PETRHead(BaseModule):
         for lvl in range(hs.shape[0]):
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             reference = inverse_sigmoid(reference)
-            outputs_classes.append(self.cls_branches[lvl](hs[lvl]))
-            outputs_kpts.append((self.kpt_branches[lvl](hs[lvl]) + reference).sigmoid())
+            outputs_classes.append(mlp_rows(self.cls_branches[lvl], hs[lvl]))
+            outputs_kpts.append((mlp_rows(self.kpt_branches[lvl], hs[lvl]) + reference).sigmoid())
         return dict(all_cls_scores=torch.stack(outputs_classes),
                     all_kpt_preds=torch.stack(outputs_kpts), enc_cls_scores=enc_outputs_class,
                     enc_kpt_preds=enc_outputs_kpt.sigmoid(), memory=memory,
@@ -277,9 +277,9 @@ class PETRHead(BaseModule):
         for lvl in range(hs.shape[0]):
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             reference = inverse_sigmoid(reference)
-            outs_kpt.append((self.refine_kpt_branches[lvl](hs[lvl]) + reference).sigmoid())
+            outs_kpt.append((mlp_rows(self.refine_kpt_branches[lvl], hs[lvl]) + reference).sigmoid())
             if self.with_sigma:
-                outs_sigma.append(self.refine_fc_sigma_branches[lvl](hs[lvl]).sigmoid())
+                outs_sigma.append(mlp_rows(self.refine_fc_sigma_branches[lvl], hs[lvl]).sigmoid())
         return torch.stack(outs_kpt), (torch.stack(outs_sigma) if outs_sigma else None), hs
 
     def get_bboxes(self, outs, img_metas, rescale=False, force_score_topk=None, taps=None):

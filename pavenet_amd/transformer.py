@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .bricks import (BaseModule, SourceKey, TransformerLayerSequence, batch_first, inverse_sigmoid,
-                     linear_norm,
+                     linear_norm, mlp_rows,
                      seq_first_view, xavier_init)
 from .deform_attn import (MulFramesMultiScaleDeformableAttention,
                           MulFramesMultiScaleDeformablePoseAttention,
@@ -56,7 +56,7 @@ def _ref_update(tmp, ref):
     return (tmp + inverse_sigmoid(ref)).sigmoid()
 
 
-def _frame_branches(branches, lid, x, cat_dim):
+def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
     """torch.cat([b[lid](x) for b in branches], dim=cat_dim) for T per-frame MLPs of identical
     structure (Linear / ReLU chains, OT:6728-6732, MT:861-864).  On the device the T first Linears
     run as ONE GEMM over the row-concatenated weights and the following per-frame Linears as
@@ -72,7 +72,8 @@ def _frame_branches(branches, lid, x, cat_dim):
                                       and m[i].bias is not None))
                   for m in mods for i in range(len(m0))))
     if not ok:
-        return torch.cat([m(x) for m in mods], dim=cat_dim)
+        y = torch.cat([m(x) for m in mods], dim=cat_dim)
+        return y if update_ref is None else _ref_update(y, update_ref)
     lins = [[m[i] for m in mods] for i in range(0, len(m0), 2)]      # [layer][frame]
     srcs = [p for layer in lins for l in layer for p in (l.weight, l.bias)]
     key = SourceKey(srcs)
@@ -124,12 +125,19 @@ def _frame_branches(branches, lid, x, cat_dim):
             o = dims[li][0]
             y = ops.gemm_bf16x3_grouped(y, planes[li], biases[li], (o + 63) // 64 * 64, relu=not last)
         o = dims[-1][0]
+        if update_ref is not None and update_ref.is_contiguous() and update_ref.dtype == torch.float32 \
+                and update_ref.shape[-1] == o and update_ref.numel() == R * T * o:
+            # update_ref given: return sigmoid(cat_t(branch_t(x)) + inverse_sigmoid(update_ref)), read
+            # straight from the grouped output (no layout copy, one launch)
+            return ops.ref_update_frames(y, update_ref, T, o, lead[1] if cat_dim == 1 else R)
         y = y.view(R, T, -1)[:, :, :o].permute(1, 0, 2)            # [T, R, out]
         y = y.reshape((T,) + tuple(lead) + (o,))
         if cat_dim == 0:
-            return y.reshape((T * lead[0],) + tuple(lead[1:]) + (o,))
-        assert cat_dim == 1
-        return y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], o)
+            y = y.reshape((T * lead[0],) + tuple(lead[1:]) + (o,))
+        else:
+            assert cat_dim == 1
+            y = y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], o)
+        return y if update_ref is None else _ref_update(y, update_ref)
     y = torch._addmm_activation(b1, rows, w1)                    # relu(x W1^T + b1), all frames
     y = y.view(R, T, -1).transpose(0, 1)                          # [T, R, h]
     for li, (w, b) in enumerate(rest):
@@ -138,9 +146,11 @@ def _frame_branches(branches, lid, x, cat_dim):
             y = torch.relu_(y)
     y = y.view((T,) + tuple(lead) + (y.shape[-1],))               # [T, d0, d1, out]
     if cat_dim == 0:
-        return y.reshape((T * lead[0],) + tuple(lead[1:]) + (y.shape[-1],))
-    assert cat_dim == 1
-    return y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], y.shape[-1])
+        y = y.reshape((T * lead[0],) + tuple(lead[1:]) + (y.shape[-1],))
+    else:
+        assert cat_dim == 1
+        y = y.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], y.shape[-1])
+    return y if update_ref is None else _ref_update(y, update_ref)
 
 
 # ---------------------------------------------------------------------------
@@ -157,10 +167,16 @@ class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
         T = getattr(self.layers[0].attentions[-1], 'num_frames', 1)
         branches = _collect_frame_branches(T, kwargs, 'kpt_branches')
         projected = kwargs.pop('values_projected', None)  # optional: one per layer
+        # un-padded clips: every valid ratio is exactly 1.0 and x * 1.0 == x, so the scaled
+        # reference is a broadcast view instead of two elementwise launches per layer
+        unit_ratios = kwargs.pop('unit_valid_ratios', False)
         output = query
         intermediate, intermediate_reference_points = [], []
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == K * 2:
+            if reference_points.shape[-1] == K * 2 and unit_ratios:
+                reference_points_input = reference_points[:, :, None].expand(
+                    -1, -1, valid_ratios.shape[1], -1)
+            elif reference_points.shape[-1] == K * 2:
                 reference_points_input = reference_points[:, :, None] * \
                     valid_ratios.repeat(1, 1, K)[:, None]
             else:
@@ -171,11 +187,10 @@ class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if branches is not None:
-                tmps = _frame_branches(branches, lid, output, 1)  # OT:6728-6732
-                if reference_points.shape[-1] == K * 2:
-                    reference_points = _ref_update(tmps, reference_points)
-                else:
+                if reference_points.shape[-1] != K * 2:
                     raise NotImplementedError
+                reference_points = _frame_branches(branches, lid, output, 1,       # OT:6728-6735
+                                                   update_ref=reference_points)
             output = output.permute(1, 0, 2)
             if self.return_intermediate:
                 intermediate.append(output)
@@ -206,10 +221,14 @@ class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
         T = getattr(self.layers[0].attentions[-1], 'num_frames', 1)
         branches = _collect_frame_branches(T, kwargs, 'reg_branches')
         projected = kwargs.pop('values_projected', None)
+        unit_ratios = kwargs.pop('unit_valid_ratios', False)   # (see the pose decoder)
         output = query
         intermediate, intermediate_reference_points = [], []
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
+            if unit_ratios and reference_points.shape[-1] == 2:
+                reference_points_input = reference_points[:, :, None].expand(
+                    -1, -1, valid_ratios.shape[1], -1)
+            elif reference_points.shape[-1] == 4:
                 reference_points_input = reference_points[:, :, None] * \
                     torch.cat([valid_ratios, valid_ratios], -1)[:, None]
             else:
@@ -220,9 +239,9 @@ class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if branches is not None:
-                tmps = _frame_branches(branches, lid, output, 0)  # MT:861-864
                 assert reference_points.shape[-1] == 2
-                reference_points = _ref_update(tmps, reference_points)
+                reference_points = _frame_branches(branches, lid, output, 0,       # MT:861-866
+                                                   update_ref=reference_points)
             output = output.permute(1, 0, 2)
             if self.return_intermediate:
                 intermediate.append(output)
@@ -265,7 +284,7 @@ class DeformableDetrTransformerDecoder(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if reg_branches is not None:
-                tmp = reg_branches[lid](output)
+                tmp = mlp_rows(reg_branches[lid], output)
                 if reference_points.shape[-1] == 4:
                     new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
                 else:
@@ -306,7 +325,7 @@ class PetrTransformerDecoder(TransformerLayerSequence):
             output = layer(output, *args, reference_points=reference_points_input, **kwargs)
             output = output.permute(1, 0, 2)
             if kpt_branches is not None:
-                tmp = kpt_branches[lid](output)
+                tmp = mlp_rows(kpt_branches[lid], output)
                 if reference_points.shape[-1] == K * 2:
                     reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid().detach()
                 else:
@@ -606,9 +625,15 @@ class VideoPoseTransformerMulFrames(Transformer):
         if self.as_two_stage:
             output_memory, output_proposals = self.gen_encoder_output_proposals(
                 now_frame_memory, now_frame_mask_flatten if has_padding else None, geom)
-            enc_outputs_class = cls_branches[self.decoder.num_layers](output_memory)
+            enc_outputs_class = mlp_rows(cls_branches[self.decoder.num_layers], output_memory)
             topk = self.two_stage_num_proposals
-            topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
+            logits = enc_outputs_class[..., 0]
+            if (logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] <= 32768
+                    and topk <= 1024 and not torch.is_grad_enabled()):
+                from . import ops
+                topk_proposals = ops.topk_rows(logits, topk)[1]     # one launch (torch.topk: ~22)
+            else:
+                topk_proposals = torch.topk(logits, topk, dim=1)[1]
             forced = kwargs.pop('force_topk_proposals', None)
             if forced is not None:  # parity harness: follow the reference's selection
                 topk_proposals = forced
@@ -622,11 +647,11 @@ class VideoPoseTransformerMulFrames(Transformer):
                                topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
             top_props = torch.gather(output_proposals, 1,
                                      topk_proposals.unsqueeze(-1).repeat(1, 1, 2))
-            topk_kpts_unact = kpt_branches[self.decoder.num_layers](tgt)
+            topk_kpts_unact = mlp_rows(kpt_branches[self.decoder.num_layers], tgt)
             topk_kpts_unact[..., 0::2] += top_props[..., 0:1]
             topk_kpts_unact[..., 1::2] += top_props[..., 1:2]
             enc_outputs_kpt_unact = topk_kpts_unact
-            enc_outputs_sigma_unact = sigma_branches[self.decoder.num_layers](tgt)
+            enc_outputs_sigma_unact = mlp_rows(sigma_branches[self.decoder.num_layers], tgt)
             if frame_shard is not None:
                 from . import dist as pdist
                 for t_ in (tgt, topk_kpts_unact, enc_outputs_sigma_unact):
@@ -649,6 +674,8 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_kpt_branches'] = branches
         if frame_shard is not None:
             dec_kwargs['frame_shard'] = frame_shard
+        if not has_padding and isinstance(self.decoder, VideoPoseTransformerDecoderMulFrames):
+            dec_kwargs['unit_valid_ratios'] = True
         cached = kwargs.pop('values_projected', None)   # streaming: per-frame caches + frame table
         if cached is not None:
             dec_kwargs['values_projected'] = cached
@@ -660,7 +687,7 @@ class VideoPoseTransformerMulFrames(Transformer):
                 [l.attentions[-1] for l in self.decoder.layers], memory, attn_mask)
         inter_states, inter_references = self.decoder(
             query=seq_first_view(query.contiguous()), key=None, value=seq_first_view(memory),
-            query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
+            query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,
             reference_points=reference_points, spatial_shapes=spatial_shapes,
             level_start_index=level_start_index, valid_ratios=now_frame_valid_ratios,
             **dec_kwargs)
@@ -711,6 +738,8 @@ class VideoPoseTransformerMulFrames(Transformer):
             dec_kwargs['frame_reg_branches'] = branches
         if frame_shard is not None:
             dec_kwargs['frame_shard'] = frame_shard
+        if not has_padding and isinstance(self.refine_decoder, DeformableDetrTransformerDecoderMulFrames):
+            dec_kwargs['unit_valid_ratios'] = True
         mem_bt = memory.permute(1, 2, 0, 3)                                   # [B, T, S, C]
         attn_mask = mask_bt if has_padding else None
         cached = kwargs.pop('values_projected', None)   # streaming: per-frame caches + frame table
@@ -724,7 +753,7 @@ class VideoPoseTransformerMulFrames(Transformer):
                 [l.attentions[-1] for l in self.refine_decoder.layers], mem_bt, attn_mask)
         inter_states, inter_references = self.refine_decoder(
             query=seq_first_view(query.contiguous()), key=None, value=memory,
-            query_pos=seq_first_view(query_pos.contiguous()), key_padding_mask=attn_mask,
+            query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,
             reference_points=reference_points, spatial_shapes=spatial_shapes,
             level_start_index=level_start_index, valid_ratios=vr.flatten(0, 1),
             memory_clip_index=img_inds, **dec_kwargs)

@@ -617,17 +617,20 @@ def test_streaming_value_cache_is_tied_to_its_slabs():
     assert inc.values[0][0].shape[0] == 3
     stream.encode(video[3:], into=inc)          # grows slabs and cache (capacity 3 -> 7)
     assert len(inc) == 7 and inc.n_cached == 7 and inc.covers([0, 6])
+    def same(got, exp, atol):
+        for a, b in zip(got, exp):
+            assert a.shape == b.shape
+            _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=atol)
+    # (the two encodes run the backbone at other batch sizes: vendor kernels round differently)
     for a, b in zip(one.values[0] + one.values[1], inc.values[0] + inc.values[1]):
-        assert torch.equal(a[:7], b[:7])
+        _close(a[:7].cpu().numpy(), b[:7].cpu().numpy(), rtol=2e-3, atol=2e-3)
     _, got = dec(inc, wins[2:5], **pin)
-    assert all(torch.equal(a, b) for a, b in zip(got, exp))
+    same(got, exp, 1e-2)
     stream.encode(other)                        # another video through the same stream object
-    _, got = dec(one, wins[2:5], **pin)         # the earlier slabs still use THEIR cache
-    assert all(torch.equal(a, b) for a, b in zip(got, exp))
+    _, got = dec(one, wins[2:5], **pin)         # the earlier slabs still use THEIR cache:
+    assert all(torch.equal(a, b) for a, b in zip(got, exp))     # the very same computation
     _, got = dec(list(one), wins[2:5], **pin)   # plain list: per-window projection, no table
-    for a, b in zip(got, exp):
-        assert a.shape == b.shape
-        _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    same(got, exp, 1e-3)
     with pytest.raises(AssertionError):
         stream.decode(one, [[5, 6, 7]])         # index past the end of the slab list
 
@@ -1052,7 +1055,7 @@ def test_streaming_windows_vs_oracle(padded):
     wins = stream.window_indices(4, 3)
     assert wins[0] == [0, 0, 1] and wins[2] == [1, 2, 3]
     slabs = stream.encode(video.cuda())
-    assert (stream._vcache is None) == padded
+    assert (slabs.values is None) == padded
     cfg = dict(num_frames=3, num_keypoints=15, num_query=300, max_per_img=N)
     for c in (0, 2):
         taps = {}

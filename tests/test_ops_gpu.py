@@ -1,4 +1,5 @@
 """HIP kernels (through the C ABI) vs golden vectors and the oracle.  Needs an MI355X."""
+import copy
 import math
 import os
 
@@ -1341,3 +1342,188 @@ def test_kernels_survive_non_finite_inputs():
                                num_keypoints=K)
     torch.cuda.synchronize()
     assert o.shape == (2 * Q, 256)
+
+
+@pytest.mark.parametrize('n_seq,L', [(4, 300), (80, 15), (2, 33), (3, 1), (1, 97), (2, 568)])
+def test_mha_core_vs_fp64(n_seq, L):
+    """pave_mha_core_f32 (the scaled-dot-product core of the decoders' self-attention,
+    bricks/transformer.py:406-551 -> nn.MultiheadAttention) against softmax(q k^T / sqrt(d)) v in
+    fp64; logits of a few units so that the softmax is neither flat nor one-hot."""
+    from pavenet_amd.ops import mha_core
+    H, d = 8, 32
+    E = H * d
+    g = torch.Generator().manual_seed(n_seq * 1000 + L)
+    qkv = torch.randn(n_seq * L, 3 * E + 64, generator=g)[:, :3 * E + 64]   # ld > 3 E: a padded row
+    qkv[:, :E] *= 1.5
+    got = mha_core(qkv.cuda(), n_seq, L, H).cpu()
+    x = qkv[:, :3 * E].double().view(n_seq, L, 3, H, d)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1)
+    exp = (p @ v).transpose(1, 2).reshape(n_seq * L, E)
+    assert tuple(got.shape) == (n_seq * L, E)
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=2e-5, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        mha_core(qkv.cuda(), n_seq, L + 1, H)
+    if L == 568:
+        big = torch.zeros(569, 3 * E, device='cuda')
+        with pytest.raises(RuntimeError):
+            mha_core(big, 1, 569, H)      # K and V of a head no longer fit in LDS
+
+
+@pytest.mark.parametrize('L,N', [(300, 4), (15, 40)])
+def test_self_attention_split_path_vs_reference_module(L, N):
+    """bricks.MultiheadAttention in the headline GEMM mode (q|k|v split GEMM with the positional
+    table in its epilogue, pave_mha_core_f32, out_proj + identity + LayerNorm GEMM: three launches
+    of this package's kernels) against nn.MultiheadAttention + LayerNorm run in fp64."""
+    from pavenet_amd import bricks
+    torch.manual_seed(L)
+    m = bricks.MultiheadAttention(256, 8).cuda().eval()
+    norm = torch.nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        m.attn.in_proj_bias.normal_(0, 0.1)
+        m.attn.out_proj.bias.normal_(0, 0.1)
+        norm.weight.normal_(1, 0.1)
+        norm.bias.normal_(0, 0.1)
+    emb = torch.randn(L, 512, device='cuda')
+    pos = emb[:, :256].unsqueeze(0).expand(N, -1, -1).transpose(0, 1)    # [L, N, E], stride 0 over N
+    x = torch.randn(N, L, 256, device='cuda').transpose(0, 1)           # seq-first view
+    old = bricks.get_gemm_mode()
+    try:
+        bricks.set_gemm_mode('bf16x3')
+        with torch.no_grad():
+            got = m(x, query_pos=pos, post_norm=norm)
+            assert '_pave_qkv' in m.__dict__, 'the split path did not run'
+            again = m(x, query_pos=pos, post_norm=norm)
+        assert torch.equal(got, again)
+    finally:
+        bricks.set_gemm_mode(old)
+    md, nd = copy.deepcopy(m).double(), copy.deepcopy(norm).double()
+    with torch.no_grad():
+        exp = nd(md._forward_reference(x.double(), query_pos=pos.double()))
+    np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('rows,n,k', [(4, 22323, 300), (4, 300, 20), (1, 7, 7), (3, 1000, 1), (2, 32768, 1024),
+                                      (5, 1025, 17)])
+def test_topk_rows_vs_torch(rows, n, k):
+    """pave_topk_rows_f32 (the proposal / score top-k, OT:21383-21385, HEAD:1416) against torch.topk:
+    same values in the same (descending) order, indices that address those values; exact ties are
+    returned lowest index first; strided views are read in place."""
+    from pavenet_amd.ops import topk_rows
+    g = torch.Generator().manual_seed(rows * 7 + n)
+    x = torch.randn(rows, n, generator=g)
+    if n >= 1000:
+        x[:, ::97] = x[:, 5:6]          # exact ties (also across the k-th value for some rows)
+        x[0, 3] = float('inf')
+        x[0, 4] = float('-inf')
+    xd = x.cuda()
+    v, i = topk_rows(xd, k)
+    ev = torch.topk(x, k, dim=1)[0]
+    assert torch.equal(v.cpu(), ev)
+    assert torch.equal(torch.gather(x, 1, i.cpu()), ev)
+    for r in range(rows):                                   # a selection: no index twice
+        assert len(set(i[r].tolist())) == k
+    # ties: equal values come out with ascending indices
+    vi = torch.stack([v.cpu(), -i.cpu().float()], -1)
+    for r in range(rows):
+        for a in range(k - 1):
+            assert (vi[r, a, 0] > vi[r, a + 1, 0]) or (vi[r, a, 0] == vi[r, a + 1, 0] and i[r, a] < i[r, a + 1])
+    # a strided view: one column of a [rows, n, 4] tensor (the class logit of the proposal branch)
+    wide = torch.randn(rows, n, 4, generator=g).cuda()
+    v2, i2 = topk_rows(wide[..., 1], k)
+    assert torch.equal(v2.cpu(), torch.topk(wide[..., 1].cpu(), k, dim=1)[0])
+    assert torch.equal(torch.gather(wide[..., 1], 1, i2), v2)
+    x[0, 0] = float('nan')                                   # NaN ranks first, as in torch.topk
+    v3, i3 = topk_rows(x.cuda(), k)
+    assert int(i3[0, 0]) == 0 and torch.isnan(v3[0, 0])
+    with pytest.raises(RuntimeError):
+        topk_rows(xd, n + 1)
+
+
+def test_gather_frame_poses_and_pose_finalize_vs_torch():
+    """The selection gather (HEAD:1419-1427, 610) and the fused post-processing (HEAD:1440-1490,
+    get_p) against the tensor expressions they replace."""
+    from pavenet_amd.ops import gather_frame_poses, pose_finalize
+    g = torch.Generator().manual_seed(3)
+    B, T, Q, N, K = 3, 5, 300, 20, 15
+    poses = torch.rand(B, T * Q, 2 * K, generator=g).cuda()
+    idx = torch.stack([torch.randperm(Q, generator=g)[:N] for _ in range(B)]).cuda()
+    got = gather_frame_poses(poses, idx, T)
+    gidx = idx.unsqueeze(-1).expand(-1, -1, 2 * K)
+    exp = torch.cat([torch.gather(poses[:, t * Q:(t + 1) * Q], 1, gidx).reshape(B * N, 2 * K)
+                     for t in range(T)], 0)
+    assert torch.equal(got.flatten(0, 1), exp)
+    kp = (torch.rand(B, N, K, 2, generator=g) * 1.2 - 0.1).cuda()      # some outside [0, 1]
+    sg = (torch.rand(B, N, K, 2, generator=g) * 0.5 + 0.02).cuda()
+    sc = torch.rand(B, N, generator=g).cuda()
+    wh = torch.tensor([[1344., 800.], [1200., 780.], [640., 480.]]).cuda()
+    sf = torch.tensor([[1.5, 1.25], [0.8, 0.9], [1., 1.]]).cuda()
+    for rescale in (False, True):
+        dk, db = pose_finalize(kp, sg, sc, wh, sf if rescale else None)
+        whb, sfb = wh.view(B, 1, 1, 2), sf.view(B, 1, 1, 2)
+        k = kp * whb
+        k = torch.minimum(k.clamp(min=0), whb)
+        if rescale:
+            k = k / sfb
+        x1, y1 = k[..., 0].min(2, keepdim=True)[0], k[..., 1].min(2, keepdim=True)[0]
+        x2, y2 = k[..., 0].max(2, keepdim=True)[0], k[..., 1].max(2, keepdim=True)[0]
+        eb = torch.cat([x1, y1, x2, y2, sc.unsqueeze(-1)], 2)
+        p = 1 - torch.exp(-(0.2 / sg))
+        p = (p[..., 0] * p[..., 1])[..., None] * 0.7
+        p5 = p ** 5
+        ek = torch.cat(((k * p5) / (p5 + 1e-10), sc[:, :, None, None] * p), 3)
+        assert torch.equal(db, eb)
+        np.testing.assert_allclose(dk.cpu().numpy(), ek.cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('cat_dim', [0, 1])
+def test_ref_update_frames_equals_copy_plus_ref_update(cat_dim):
+    from pavenet_amd.ops import ref_update, ref_update_frames
+    g = torch.Generator().manual_seed(11 + cat_dim)
+    T, o, op = 5, 30 if cat_dim else 2, 64
+    lead = (4, 300) if cat_dim else (40, 15)
+    R = lead[0] * lead[1]
+    y = torch.randn(R, T * op, generator=g).cuda()
+    yt = y.view(R, T, op)[:, :, :o].permute(1, 0, 2).reshape((T,) + lead + (o,))
+    if cat_dim == 0:
+        cat = yt.reshape((T * lead[0], lead[1], o))
+    else:
+        cat = yt.permute(1, 0, 2, 3).reshape(lead[0], T * lead[1], o)
+    ref = torch.rand(cat.shape, generator=g).cuda()
+    exp = ref_update(cat.contiguous(), ref)
+    got = ref_update_frames(y, ref, T, o, lead[1] if cat_dim else R)
+    assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', [(2, 64, 64, 23, 37), (1, 48, 48, 40, 50), (2, 64, 128, 9, 16),
+                                            (1, 64, 96, 17, 33), (3, 48, 48, 8, 16), (1, 64, 64, 200, 336)])
+def test_conv3x3_lds_window_form_equals_implicit_gemm_form(N, Cin, Cout, H, W):
+    """The 3x3 form with the tile's input window resident in LDS (stride 1, Cin 48 | 64: ResNet
+    layer1, HRNet's 48-channel branch; resnet.py:263-300, hrnet.py:183-260) against the
+    implicit-GEMM form (diag variant 10) -- same products in the same order: bit for bit, partial
+    tiles, image borders, bias + identity + ReLU and a NaN pixel included -- and against fp64."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    rd = r.cuda().contiguous(memory_format=torch.channels_last)
+    wp = split_conv3x3_weight(w.cuda())
+    for kw in (dict(relu=False), dict(relu=True, residual=rd)):
+        win = conv3x3_split(xd, wp, b.cuda(), stride=1, cout=Cout, **kw).clone()
+        with native.diag_build(10):
+            old = conv3x3_split(xd, wp, b.cuda(), stride=1, cout=Cout, **kw).clone()
+        assert torch.equal(win, old), float((win - old).abs().max())
+    exp = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1) + r.double())
+    np.testing.assert_allclose(win.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    xn = x.clone()
+    xn[0, 1, H // 2, W // 2] = float('nan')
+    xnd = xn.cuda().contiguous(memory_format=torch.channels_last)
+    win = conv3x3_split(xnd, wp, b.cuda(), stride=1, cout=Cout, relu=False)
+    with native.diag_build(10):
+        old = conv3x3_split(xnd, wp, b.cuda(), stride=1, cout=Cout, relu=False)
+    assert torch.equal(torch.isnan(win), torch.isnan(old))
+    assert int(torch.isnan(win[0]).any(0).sum()) == 9        # exactly the 3 x 3 outputs around it

@@ -92,11 +92,11 @@ def main():
             [ctypes.c_int] * 3 + [ctypes.c_void_p]
         hw = (ctypes.c_int * 8)(*[v for hw_ in LEVELS for v in hw_])
         out = torch.empty(U, 256, device=dev)
-        for ab in (0, 1, 2, 3):
+        for ab in (0, 1, 2, 3, 4, 6):
             us = timeit(lambda: fn(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                    F, S, ctypes.cast(hw, ctypes.c_void_p), 384, 0, ab,
                                    torch.cuda.current_stream().cuda_stream))
-            print(f'enc_tile v0 ablate={ab} (1: no staging, 2: no gather): {us:9.1f} us')
+            print(f'enc_tile v0 ablate={ab} (1: no staging, 2: no gather, 4: no softmax / locations): {us:9.1f} us')
     if args.enc_only:
         return
     # the un-fused reference-shaped op on the same work

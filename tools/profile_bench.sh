@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -- pytho
 T=$(find /tmp/prof_$NAME -name '*kernel_trace.csv' | head -1)
 S=$(find /tmp/prof_$NAME -name '*kernel_stats.csv' | head -1)
 python3 $R/tools/trace_stats.py $T 5 > $R/gpurun_out/${NAME}_steady.txt
-python3 $R/tools/trace_sequence.py $T 40 > $R/gpurun_out/${NAME}_sequence.txt
+python3 $R/tools/trace_sequence.py $T ${SEQ_MIN_US:-40} > $R/gpurun_out/${NAME}_sequence.txt
 head -60 $S > $R/gpurun_out/${NAME}_stats.csv
 tail -1 $R/gpurun_out/${NAME}_run.log | cut -c1-400
