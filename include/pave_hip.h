@@ -114,6 +114,22 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     void* stream);
 
 /*
+ * The encoder layer's merged projection (value_proj | sampling_offsets | attention_weights as ONE
+ * N = 640 GEMM, third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:357-384) with the sampler's
+ * per-(query, head) arithmetic done in the GEMM epilogue:
+ *   a [M, K] fp32;  w_planes = the 3-plane split of the [640, K] row-concatenated weight;
+ *   table [table_rows, 640]: row m adds table[m % table_rows] (bias + positional term);
+ *   ref [M, 4, 2] reference points (normalised x, y per level);  levels_hw [4][2] (h, w), HOST memory
+ *   -> value [M, 256];  samp [M, 384] = level PIXEL coordinates [8 heads][4 levels][4 points][x, y]
+ *      ((ref + off / (w, h)) * (w, h) - 0.5), then softmaxed attention weights [8][16]
+ * i.e. `proj` of pave_enc_deform_attn_tile_f32 in its prepared form (variant | 4): same bits as
+ * feeding that kernel the raw projections (one definition of the arithmetic, csrc/pave_enc_math.h).
+ */
+int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
+                                 long long table_rows, const float* ref, const int* levels_hw,
+                                 float* value, float* samp, long long M, int K, void* stream);
+
+/*
  * Scaled-dot-product core of the decoders' self-attention (replaces what nn.MultiheadAttention
  * runs between its in- and out-projection, third_party/mmcv/mmcv/cnn/bricks/transformer.py:
  * 406-551 as the reference's decoder layers call it: no masks, no dropout, 32 channels per head).

@@ -31,6 +31,7 @@
 
 #include "pave_hip.h"
 #include "pave_internal.h"
+#include "pave_enc_math.h"
 
 namespace {
 
@@ -71,20 +72,9 @@ template <int Q>
 __device__ __forceinline__ float qbf(float x) {
   return __builtin_bit_cast(float, qbi<Q>(__builtin_bit_cast(int, x)));
 }
-__device__ __forceinline__ float quad_max(float v) {
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                   0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true)));  // quad_perm:[1,0,3,2]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                   0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true)));  // quad_perm:[2,3,0,1]
-  return v;
-}
-__device__ __forceinline__ float quad_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1,
-                                                             0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e,
-                                                             0xf, 0xf, true));
-  return v;
-}
+using pave_enc::quad_max;
+using pave_enc::quad_sum;
+using pave_enc::div_by;
 
 template <int W0, int W1, int W2, int W3>
 struct WinGeom {
@@ -130,13 +120,6 @@ struct PointDesc {
   int a[4];    // LDS byte address of the 128-byte row (a zero row if the point is not in LDS)
   int tok00;   // token of the footprint's upper-left pixel (second pass)
 };
-
-__device__ __forceinline__ float div_by(float x, float d, float rd) {
-  // x / d with rd = 1 / d: one residual correction of the product (correctly rounded up to rare
-  // half-way cases), 3 instructions instead of the ~10 of an IEEE division
-  const float q = x * rd;
-  return fmaf(fmaf(-q, d, x), rd, q);
-}
 
 // returns the point's 3 flag bits: 1 = footprint not (entirely) inside the window -> second
 // pass, 2 = upper row visited right-to-left, 4 = lower row visited right-to-left
@@ -285,7 +268,8 @@ __device__ __forceinline__ void far_quad_loop(float4& accA, float4& accB, const 
 // ABL: timing-only ablations for tools/ (1: no window staging, 2: no gather loop); 0 in the product
 constexpr int FAR_PER_ROUND = 1;   // far points of a pair fetched per round of the second pass (2: spills at 96 VGPRs, 2-3x slower)
 
-template <int W0, int W1, int W2, int W3, int MB0, int MB1, int MB2, int MB3, int WPE, int ABL = 0>
+template <int W0, int W1, int W2, int W3, int MB0, int MB1, int MB2, int MB3, int WPE, int ABL = 0,
+          bool PREP = false>
 __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) {
   using G = WinGeom<W0, W1, W2, W3>;
   constexpr int kWaves = 6;
@@ -335,7 +319,8 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const float4 of01 = *reinterpret_cast<const float4*>(row);
   const float4 of23 = *reinterpret_cast<const float4*>(row + 4);
   const float4 lg = *reinterpret_cast<const float4*>(row + (kHeads - head) * 32 + head * 16 - k * 4);
-  const float2 rf = *reinterpret_cast<const float2*>(p.ref + (size_t)unit * 8 + k * 2);
+  const float2 rf = PREP ? make_float2(0.f, 0.f)
+                         : *reinterpret_cast<const float2*>(p.ref + (size_t)unit * 8 + k * 2);
   const int4* tab = reinterpret_cast<const int4*>(
       (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileParams, tab)) + k * 2;
   const int4 tabA = tab[0], tabB = tab[1];
@@ -366,13 +351,14 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   const float rW = __int_as_float(tabB.y), rH = __int_as_float(tabB.z);
 
   // ---- softmax over the 16 logits of (unit, head): 4 per lane, quad reduction
-  float e0, e1, e2, e3, inv_sum;
-  if (ABL & 4) {   // timing only: weights taken as given (what a producer-side softmax would leave)
-    e0 = lg.x, e1 = lg.y, e2 = lg.z, e3 = lg.w, inv_sum = 1.f;
+  // (PREP: the producer -- the merged projection GEMM's epilogue -- has run the softmax and the
+  // location arithmetic with the very same code, pave_enc_math.h: `proj` holds the attention
+  // weights and the level pixel coordinates)
+  float ee[4], inv_sum;
+  if (PREP) {
+    ee[0] = lg.x, ee[1] = lg.y, ee[2] = lg.z, ee[3] = lg.w, inv_sum = 1.f;
   } else {
-    const float mx = quad_max(fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w)));
-    e0 = __expf(lg.x - mx), e1 = __expf(lg.y - mx), e2 = __expf(lg.z - mx), e3 = __expf(lg.w - mx);
-    inv_sum = __builtin_amdgcn_rcpf(quad_sum((e0 + e1) + (e2 + e3)));  // 1 ulp
+    pave_enc::softmax16(lg.x, lg.y, lg.z, lg.w, ee, inv_sum);
   }
   if (!valid) inv_sum = 0.f;  // idle slots carry weight 0 through the DPP steps
 
@@ -381,18 +367,13 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
   int flags = 0;
   {
     const float ofx[4] = {of01.x, of01.z, of23.x, of23.z}, ofy[4] = {of01.y, of01.w, of23.y, of23.w};
-    const float ee[4] = {e0, e1, e2, e3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float px, py;
-      if (ABL & 4) {   // timing only: positions taken as given in level pixels
-        px = fmaf(rf.x, fW, ofx[i]) - 0.5f, py = fmaf(rf.y, fH, ofy[i]) - 0.5f;
-      } else {
-        const float lx = rf.x + div_by(ofx[i], fW, rW), ly = rf.y + div_by(ofy[i], fH, rH);  // MO:381-384
-        px = lx * fW - 0.5f, py = ly * fH - 0.5f;  // cuda_kernel.cuh:233-234
-      }
-      flags |= make_point(d[i], px, py, ee[i] * inv_sum, H, W, st, ox, oy, ww, wbase, G::kZ, par)
-               << (3 * i);
+      // MO:381-384, cuda_kernel.cuh:233-234
+      const float px = PREP ? ofx[i] : pave_enc::pixel_coord(rf.x, ofx[i], fW, rW);
+      const float py = PREP ? ofy[i] : pave_enc::pixel_coord(rf.y, ofy[i], fH, rH);
+      const float aw = PREP ? (valid ? ee[i] : 0.f) : ee[i] * inv_sum;
+      flags |= make_point(d[i], px, py, aw, H, W, st, ox, oy, ww, wbase, G::kZ, par) << (3 * i);
     }
   }
   if (!valid) flags &= ~0x249;  // no second pass for idle slots
@@ -442,7 +423,11 @@ template <int ABL>
 static int enc_tile_launch(const float* value, const float* proj, const float* ref, float* out,
                            int n_frames, int S, const int* levels_hw, int proj_stride, int variant,
                            const int* window_shift, void* stream) {
-  if (!value || !proj || !ref || !out || !levels_hw)
+  // variant bit 2 (value 4): `proj` is PREPARED (pave_gemm_bf16x3_encproj_f32): attention weights and
+  // level pixel coordinates instead of logits and offsets; ref is not read
+  const bool prepared = (variant & 4) != 0;
+  variant &= 3;
+  if (!value || !proj || (!ref && !prepared) || !out || !levels_hw)
     return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: null pointer");
   if (n_frames <= 0 || S <= 0) return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: sizes must be positive");
   if (proj_stride < kHeads * 16 * 3)
@@ -499,8 +484,13 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
     hipLaunchKernelGGL((enc_tile_kernel<16, 12, 10, 9, 4, 4, 4, 4, 1, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   } else {             // -4 .. +3 px windows (52 KB), 3 workgroups per CU
     fill(WinGeom<14, 10, 8, 7>{}, 14, 10, 8, 7);
-    hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
+    if (prepared)
+      hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL, true>), dim3((unsigned)nb), dim3(384), 0, st, p);
+    else
+      hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   }
+  if (prepared && variant != 0)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "enc_deform_attn_tile: prepared input with the default windows only");
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -516,8 +506,7 @@ extern "C" int pave_enc_deform_attn_tile_f32(const float* value, const float* pr
 
 #ifdef PAVE_DIAG
 // Timing-only ablations for tools/bench_kernels.py (-DPAVE_DIAG build only, outputs are wrong):
-// ablate 1 = no window staging, 2 = no gather loop, 3 = neither, 4 = no softmax / location arithmetic
-// (what moving them into the projection GEMM's epilogue would leave), 6 = 4 + 2.
+// ablate 1 = no window staging, 2 = no gather loop, 3 = neither.
 extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, const float* ref,
                                          float* out, int n_frames, int S, const int* levels_hw,
                                          int proj_stride, int variant, int ablate, void* stream) {
@@ -525,8 +514,6 @@ extern "C" int pave_diag_enc_tile_ablate(const float* value, const float* proj, 
     case 1: return enc_tile_launch<1>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     case 2: return enc_tile_launch<2>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     case 3: return enc_tile_launch<3>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
-    case 4: return enc_tile_launch<4>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
-    case 6: return enc_tile_launch<6>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
     default: return enc_tile_launch<0>(value, proj, ref, out, n_frames, S, levels_hw, proj_stride, variant, nullptr, stream);
   }
 }

@@ -39,6 +39,7 @@
 
 #include "pave_hip.h"
 #include "pave_internal.h"
+#include "pave_enc_math.h"
 
 namespace {
 
@@ -66,6 +67,11 @@ struct QLn {     // LayerNorm over the output row (LNORM forms, N == block width
   const float* gamma;
   const float* beta;
   float eps;
+};
+
+struct QEpi {    // encoder projection epilogues (EPI 1 / 2): what the sampler would otherwise compute
+  const float* ref;              // [M, 4, 2] reference points of the rows (normalised x, y per level)
+  float fW[4], fH[4], rW[4], rH[4];   // level sizes and their reciprocals (as the sampler's launcher)
 };
 
 __device__ __forceinline__ unsigned hi16(float x) { return __float_as_uint(x) & 0xffff0000u; }
@@ -145,12 +151,17 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 // the slab is in registers, its stage takes the DMA of slab s + 2 (one slab = 48 MFMAs per wave of
 // latency cover), and the fourth quarter's MFMAs run over the reads and the split of slab s + 1.
 // Per accumulator the products keep the order of the narrow form: results are bit-identical.
-template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false>
+// EPI (epilogue transform of the stored values, plain row forms only; pave_enc_math.h):
+//   1 = the columns are sampling offsets [head][level][point][x, y] of the encoder's deformable
+//       attention: stored as level pixel coordinates (ref + off / size) * size - 0.5;
+//   2 = the columns are attention logits [head][16]: stored as their softmax over each 16
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const QLn ln,
-    const float* __restrict__ A2 = nullptr, const int tile_m0 = -1, const int tile_n0 = 0) {
+    const float* __restrict__ A2 = nullptr, const int tile_m0 = -1, const int tile_n0 = 0,
+    const QEpi* epi = nullptr) {
   // (tile_m0 >= 0: the caller names the tile -- kernels that run several bodies per block)
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
@@ -544,6 +555,18 @@ __device__ __forceinline__ void gemm_q_body(
     const int ldo = os.out2 == nullptr ? os.n_real : (seg2 ? N - os.nsplit : os.nsplit);
     const int csh = seg2 ? os.nsplit : 0;
     if constexpr (!LNORM) {
+      float2 erf[NPS];          // EPI 1: reference point (x, y) of the lane's level per pass
+      float eW = 0.f, eH = 0.f, erW = 0.f, erH = 0.f;
+      if constexpr (EPI == 1) {
+        const int lvl = ec4 >> 1;   // 32 offset columns per head = 4 levels x 4 points x (x, y)
+        eW = epi->fW[lvl], eH = epi->fH[lvl], erW = epi->rW[lvl], erH = epi->rH[lvl];
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
+          erf[ps] = gm < M ? *reinterpret_cast<const float2*>(epi->ref + gm * 8 + lvl * 2)
+                           : make_float2(0.f, 0.f);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
@@ -568,6 +591,17 @@ __device__ __forceinline__ void gemm_q_body(
           }
           if (relu) {
             v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+          }
+          if constexpr (EPI == 1) {   // two points (x, y) of one level
+            v.x = pave_enc::pixel_coord(erf[ps].x, v.x, eW, erW);
+            v.y = pave_enc::pixel_coord(erf[ps].y, v.y, eH, erH);
+            v.z = pave_enc::pixel_coord(erf[ps].x, v.z, eW, erW);
+            v.w = pave_enc::pixel_coord(erf[ps].y, v.w, eH, erH);
+          }
+          if constexpr (EPI == 2) {   // the quad holds the 16 logits of (row, head)
+            float e[4], inv;
+            pave_enc::softmax16(v.x, v.y, v.z, v.w, e, inv);
+            v.x = e[0] * inv, v.y = e[1] * inv, v.z = e[2] * inv, v.w = e[3] * inv;
           }
           if (gm < M && colok) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
         }
@@ -711,6 +745,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gemm_q_body<4, 1, 0, false, false>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
                                        nullptr, row * QBM, nw * 256);
 }
+// The encoder layer's merged projection (N = 640 = value 256 | sampling offsets 256 | attention
+// logits 128, multi_scale_deform_attn.py:357-384) with the sampler's per-(query, head) arithmetic in
+// the epilogue: tile 0 (value) is stored as it is, tile 1 as level pixel coordinates, the narrow
+// tail as softmaxed attention weights -- with the code the sampling kernel itself uses
+// (pave_enc_math.h), so pave_enc_deform_attn_tile_f32 in its `prepared` mode returns the same bits.
+// These waves are ~25 % VALU-active; the sampler is VALU-bound.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wn_enc_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* residual, float* out,
+    const int M, const int K, const QOut os, const QEpi epi) {
+  constexpr int N = 640, ntl = 3;
+  const int ttot = ((M + QBM - 1) / QBM) * ntl;
+  const int per = ttot >> 3, rem = ttot & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  const int row = lb / ntl, c = lb - row * ntl;
+  const QLn ln0{nullptr, nullptr, 0.f};
+  const QConv g{0, 0, 0, 0, 0, 0, 0u};
+  if (c == 0)
+    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os, ln0,
+                                             nullptr, row * QBM, 0);
+  else if (c == 1)
+    gemm_q_body<8, 1, 0, false, false, true, 1>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
+                                                ln0, nullptr, row * QBM, 256, &epi);
+  else
+    gemm_q_body<4, 1, 0, false, false, false, 2>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
+                                                 ln0, nullptr, row * QBM, 512, &epi);
+}
 // ---------------------------------------------------------------------------
 // ResNet Bottleneck (64-channel stage) from its 3x3 convolution on, chained with the NEXT block's
 // conv1 -- three GEMMs of ONE 128-pixel row tile back to back in one workgroup:
@@ -779,6 +840,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
+  // (A first-tile stagger of every other CU -- half a tile of s_sleep, so that main loops and the
+  // HBM-heavy LayerNorm epilogues of different CUs interleave instead of running in lockstep -- was
+  // measured: 647 -> 729 us at K = 256, equal at K = 1024.  Not kept.)
   gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
                                     QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
@@ -961,258 +1025,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   reinterpret_cast<float4*>(out)[i] = v;
 }
 
-// ---------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolution with the tile's INPUT WINDOW resident in LDS (Cin <= 64).
-// The implicit-GEMM forms above re-load every input pixel nine times (once per tap) through the
-// L1 / texture path into the A ring; an ablation priced that at up to 18 % of the 64-channel 3x3
-// launches.  Here a block's 128 output pixels are a 2-D patch (TH rows x TW columns, TH TW = 128,
-// wave w = rows [w 32 / TW, (w + 1) 32 / TW)), the (TH + 2) x (TW + 2) x Cin window around it is
-// copied ONCE by LDS-DMA (buffer-addressed: pixels outside the image are out-of-range lanes and
-// arrive as zeros = the padding) and every wave builds the A operand of slab (tap, 16 channels)
-// from there; only the W planes still stream through a 3-stage ring.  Window pixel pitch =
-// Cin * 4 + 16 bytes (an ODD number of 16-byte chunks): the 16 lanes a ds_read_b128 serves
-// together read 16 consecutive pixels at the same channel offset and land on 16 different bank
-// groups.  K order (tap-major, then channel, zero slab up to K % 32 == 0), products and their order
-// per accumulator are those of the implicit-GEMM form: results are bit-identical.
-// ---------------------------------------------------------------------------
-template <int TN, int CIN, int TW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, TN == 2 ? 3 : 2))) void conv3x3_win_kernel(
-    const float* __restrict__ x, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
-    const float* residual, float* out, const int NI, const int H, const int W, const int N,
-    const int n_real, const int relu) {
-  constexpr int TH = QBM / TW, WR = TH + 2, WC = TW + 2;
-  constexpr int P = CIN / 4 + 1;                 // 16-byte chunks per window pixel (one pad chunk)
-  constexpr int PITCH = P * 16;
-  constexpr int NCH = WR * WC * P;
-  constexpr int NWIN = (NCH + 63) / 64;          // window DMA instructions
-  constexpr int WIN_BYTES = NWIN * 1024;
-  constexpr int BN = TN * 32;
-  constexpr int W_STAGE = 3 * BN * 32;
-  constexpr int NWI = W_STAGE / 1024;            // W DMA instructions per slab: 6 | 12
-  constexpr int QW = (NWI + 3) / 4, QMIN = NWI / 4;
-  constexpr int KSL = CIN / 16;                  // slabs per tap
-  constexpr int NSLAB = ((9 * KSL + 1) / 2) * 2; // K = 9 Cin rounded up to a multiple of 32
-  static_assert(P % 2 == 1 && CIN % 16 == 0 && QBM % TW == 0 && 32 % TW == 0 || TW == 32, "tile");
-  static_assert(4 * 32 * QCST * 4 <= WIN_BYTES, "the epilogue chunks reuse the window region");
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, kh = lane >> 5;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-  // ---- the block's tile: column tile fastest, then the patches of an image row by row; blocks
-  // dealt to one XCD are neighbours (their halos meet in its L2)
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntn = N / BN;
-  const int ttot = NI * tiles_y * tiles_x * ntn;
-  const int per = ttot >> 3, rem = ttot & 7;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
-  const int cn = lb % ntn; lb /= ntn;
-  const int tx = lb % tiles_x; lb /= tiles_x;
-  const int ty = lb % tiles_y;
-  const int img = lb / tiles_y;
-  const int n0 = cn * BN, oy0 = ty * TH, ox0 = tx * TW;
-
-  // ---- window -> LDS
-  {
-    i32x4 rsrc;
-    const unsigned long long xb = reinterpret_cast<unsigned long long>(x);
-    rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
-    rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
-    rsrc.z = __builtin_amdgcn_readfirstlane((int)((unsigned)NI * (unsigned)H * (unsigned)W * (unsigned)(CIN * 4)));
-    rsrc.w = 0x00020000;
-#pragma unroll
-    for (int q = 0; q < (NWIN + 3) / 4; ++q) {
-      const int i = wave + 4 * q;
-      if (i < NWIN) {   // (wave-uniform)
-        const int ci = i * 64 + lane;
-        const int pix = ci / P, ch = ci - pix * P;
-        const int wy = pix / WC, wx = pix - wy * WC;
-        const int iy = oy0 - 1 + wy, ix = ox0 - 1 + wx;
-        const bool ok = ci < NCH && ch < P - 1 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const unsigned off = (unsigned)(((img * H + iy) * W + ix) * CIN + ch * 4) * 4u;
-        dma16_buf(ok ? off : 0xffffff00u, rsrc, lds0 + i * 1024);
-      }
-    }
-  }
-  // ---- W ring
-  const long long w_slab = (long long)3 * N * 32;
-  const unsigned char* const w_base = reinterpret_cast<const unsigned char*>(Wp);
-  unsigned w_voff[QW];
-#pragma unroll
-  for (int q = 0; q < QW; ++q) {
-    const int j = wave + 4 * q;
-    const int p = j / (NWI / 3), row = (j % (NWI / 3)) * 32 + (lane >> 1);
-    const int h = (lane & 1) ^ ((row >> 3) & 1);
-    w_voff[q] = (unsigned)((((long long)p * N + n0 + row) * 32 + h * 16));
-  }
-  auto issue = [&](const int slab, const int stage) {
-#pragma unroll
-    for (int q = 0; q < QW; ++q) {
-      const int j = wave + 4 * q;
-      if (NWI % 4 == 0 || j < NWI)
-        dma16(w_voff[q], w_base + slab * w_slab, lds0 + WIN_BYTES + stage * W_STAGE + j * 1024);
-    }
-  };
-  // ---- operand addresses: lane (lr, kh) = output pixel lr of the wave, k half kh
-  const int py = wave * (32 / TW) + lr / TW, px = lr % TW;
-  const int a_rd = (py * WC + px) * PITCH + kh * 32;
-  const int w_rd = WIN_BYTES + lr * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);
-  f32x16 acc[TN];
-  f32x4 raw[2];
-  u32x4 apl[2][3];
-  u32x4 wf[2][3][TN];
-  auto read_frags = [&](const int slab, const int stage, const int set) {
-    // (scalar) slab -> tap, channel group; tap >= 9: the zero slab that pads K
-    const int tap = slab / KSL, c0 = slab - tap * KSL;
-    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-    if (tap < 9) {
-      const unsigned char* a = smem + a_rd + (ky * WC + kx) * PITCH + c0 * 64;
-      raw[0] = *reinterpret_cast<const f32x4*>(a);
-      raw[1] = *reinterpret_cast<const f32x4*>(a + 16);
-    } else {
-      raw[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      raw[1] = raw[0];
-    }
-    const unsigned char* st = smem + stage * W_STAGE;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        wf[set][p][j] = *reinterpret_cast<const u32x4*>(st + w_rd + (p * BN + j * 32) * 32);
-  };
-  auto mma = [&](const int set, const int o) {
-#pragma unroll
-    for (int pa = 0; pa <= o; ++pa)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, apl[set][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
-            acc[j], 0, 0, 0);
-  };
-
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  PAVE_QWAIT(2 * QMIN);                    // the window and slab 0 have landed everywhere
-  read_frags(0, 0, 0);
-  split8(raw[0], raw[1], apl[0]);
-#define PAVE_CSTEP(I, FULL)                                                    \
-  if (FULL || s + I < NSLAB - 1) {                                             \
-    constexpr int cur = (I) & 1, nxt = cur ^ 1;                                \
-    const int sl = s + I;                                                      \
-    if (FULL || sl + 2 < NSLAB) PAVE_QWAIT(QMIN); else PAVE_QWAIT(0);          \
-    if (FULL || sl + 3 < NSLAB) issue(sl + 3, (I) % 3);                        \
-    read_frags(sl + 1, ((I) + 1) % 3, nxt);                                    \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    mma(cur, 2);                                                               \
-    split8(raw[0], raw[1], apl[nxt]);                                          \
-    mma(cur, 1);                                                               \
-    mma(cur, 0);                                                               \
-  }
-  int s = 0;
-  for (; s + 9 <= NSLAB; s += 6) {
-    PAVE_CSTEP(0, true)
-    PAVE_CSTEP(1, true)
-    PAVE_CSTEP(2, true)
-    PAVE_CSTEP(3, true)
-    PAVE_CSTEP(4, true)
-    PAVE_CSTEP(5, true)
-  }
-  for (; s < NSLAB - 1; s += 6) {
-    PAVE_CSTEP(0, false)
-    PAVE_CSTEP(1, false)
-    PAVE_CSTEP(2, false)
-    PAVE_CSTEP(3, false)
-    PAVE_CSTEP(4, false)
-    PAVE_CSTEP(5, false)
-  }
-#undef PAVE_CSTEP
-  // ---- last slab (operands in set 1: NSLAB is even); every wave is done with the window, whose
-  // bytes the epilogue chunks reuse; the identity rows are fetched under the last MFMAs
-  PAVE_QWAIT(0);
-  constexpr int NPS = 4;
-  const int erow = lane >> 3, ec4 = lane & 7;
-  long long grow[NPS];                   // output (and identity) pixel of the lane per pass, -1: none
-#pragma unroll
-  for (int ps = 0; ps < NPS; ++ps) {
-    const int l = ps * 8 + erow;
-    const int oy = oy0 + wave * (32 / TW) + l / TW, ox = ox0 + l % TW;
-    grow[ps] = (oy < H && ox < W) ? ((long long)img * H + oy) * W + ox : -1;
-  }
-  float4 resv[TN][NPS];
-  if (residual) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ncol = n0 + j * 32 + ec4 * 4;
-#pragma unroll
-      for (int ps = 0; ps < NPS; ++ps)
-        resv[j][ps] = (grow[ps] >= 0 && ncol < n_real)
-                          ? *reinterpret_cast<const float4*>(residual + grow[ps] * n_real + ncol)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  mma(1, 2);
-  mma(1, 1);
-  mma(1, 0);
-  float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * QCST;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int ncol = n0 + j * 32 + ec4 * 4;
-    const bool colok = ncol < n_real;
-    const float4 b4 = (bias && colok) ? *reinterpret_cast<const float4*>(bias + ncol)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      const int lrow = ps * 8 + erow;
-      float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
-      v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
-      if (residual) {
-        const float4 rv = resv[j][ps];
-        v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
-      }
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-      }
-      if (grow[ps] >= 0 && colok) *reinterpret_cast<float4*>(out + grow[ps] * n_real + ncol) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-template <int TN, int CIN, int TW>
-int launch_conv_win(const float* x, const uint16_t* w, const float* bias, const float* residual, float* out,
-                    int NI, int H, int W, int N, int n_real, int relu, hipStream_t st) {
-  constexpr int P = CIN / 4 + 1, TH = QBM / TW;
-  constexpr int NWIN = ((TH + 2) * (TW + 2) * P + 63) / 64;
-  constexpr int smem = NWIN * 1024 + QNS * 3 * (TN * 32) * 32;
-  const long long gx = (long long)NI * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (N / (TN * 32));
-  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "conv3x3_win: grid too large");
-  auto kern = conv3x3_win_kernel<TN, CIN, TW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return pave_internal_fail(PAVE_E_LAUNCH, "conv3x3_win: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, st, x, w, bias, residual, out, NI, H, W, N,
-                     n_real, relu);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  return PAVE_OK;
-}
-
 constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
 
 template <int KIND>
@@ -1304,19 +1116,6 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   // (diag variant 5: the 64-bit lane-address form everywhere, for A/B)
   const bool big3 = kind == 1 && ((M / ((long long)Ho * Wo)) * H * W * Cin * 4 >= (1ll << 32) - 65536 ||
                                   pave_internal_diag_variant() == 5);
-  // stride 1, Cin 48 | 64: the form with the tile's input window resident in LDS (diag variant 10:
-  // the implicit-GEMM form instead, for the bit-identity test and A/B runs)
-  if (kind == 1 && !big3 && stride == 1 && Ho == H && Wo == W && (Cin == 48 || Cin == 64) && !out2 &&
-      !a_bias && ksplit == 1 && os.res_rows == 0 && K == ((9 * Cin + 31) / 32) * 32 && !narrow &&
-      pave_internal_diag_variant() != 10 && pave_internal_diag_variant() != 9 && (N == 64 || N == 128)) {
-    const int NI = (int)(M / ((long long)H * W));
-    // 8 x 16 patches tile a 200 x 336 map exactly; maps narrower than 16 columns are not worth it
-    if (W >= 16 && H >= 8) {
-      if (Cin == 64 && N == 64) return launch_conv_win<2, 64, 16>(a, w, bias, residual, out, NI, H, W, N, n_real, relu, st);
-      if (Cin == 48 && N == 64) return launch_conv_win<2, 48, 16>(a, w, bias, residual, out, NI, H, W, N, n_real, relu, st);
-      if (Cin == 64 && N == 128) return launch_conv_win<4, 64, 16>(a, w, bias, residual, out, NI, H, W, N, n_real, relu, st);
-    }
-  }
 #define PAVE_QGO(TN_)                                                                               \
   if (kind == 0) {                                                                                  \
     if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
@@ -1367,6 +1166,37 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO
   return pave_internal_fail(PAVE_E_ARG, "gemm_q: N %% 64 == 0 required");
+}
+
+// merged encoder projection with the sampler's softmax / location arithmetic in the epilogue
+int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float* table, long long table_rows,
+                               const float* ref, const int* levels_hw, float* value, float* samp,
+                               long long M, int K, void* stream) {
+  if (K % 32 != 0 || K < 64 || K >= (1 << 23)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: K %% 32 == 0, 64 <= K < 2^23");
+  QEpi epi{};
+  epi.ref = ref;
+  for (int l = 0; l < 4; ++l) {
+    if (levels_hw[2 * l] <= 0 || levels_hw[2 * l + 1] <= 0)
+      return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: bad level size");
+    epi.fH[l] = (float)levels_hw[2 * l], epi.fW[l] = (float)levels_hw[2 * l + 1];
+    epi.rH[l] = 1.f / (float)levels_hw[2 * l], epi.rW[l] = 1.f / (float)levels_hw[2 * l + 1];
+  }
+  const QOut os{samp, 256, table_rows >= M ? 0 : (int)table_rows, 640, 0};
+  const long long gx = ((M + QBM - 1) / QBM) * 3;
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_enc_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_encproj: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_wn_enc_kernel, dim3((unsigned)gx), dim3(256), W_SMEM,
+                     reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes), table,
+                     value, (int)M, K, os, epi);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
 }
 
 int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,

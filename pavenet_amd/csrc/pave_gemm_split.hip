@@ -554,7 +554,6 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // the LDS-DMA generation of pave_gemm_dma.hip, the default),
                          // 5 = 3x3 form with 64-bit lane addresses (not buffer-addressed),
                          // 6 = no split-K plan,
-                         // 10 = 3x3 without the LDS-window form (the implicit-GEMM form),
                          // 8 = LDS-DMA generation without its wide tile form, 7 = wide
                          // tile form wherever it applies (default: from 512 tiles up)
 
@@ -622,6 +621,16 @@ int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes
 static int gemm_split_entry(const float* a, const float* a_bias, const void* w_planes,
                             const float* bias, const float* residual, float* out, long long M,
                             int K, int N, int relu, int nplanes, void* stream, OutSplit os);
+
+int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
+                                 long long table_rows, const float* ref, const int* levels_hw, float* value,
+                                 float* samp, long long M, int K, void* stream) {
+  if (!a || !w_planes || !table || !ref || !levels_hw || !value || !samp)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: null pointer");
+  if (M <= 0 || M >= (1ll << 31) || table_rows <= 0 || table_rows >= (1ll << 31))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: bad sizes (0 < M, table_rows < 2^31)");
+  return pave_internal_gemm_encproj(a, w_planes, table, table_rows, ref, levels_hw, value, samp, M, K, stream);
+}
 
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
                          const float* bias, const float* residual, float* out, long long M, int K,

@@ -142,6 +142,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         self.dropout = nn.Identity()  # inference path
         self.batch_first = batch_first
         self.im2col_step = im2col_step
+        self.prepare_in_gemm = True   # A/B switch: softmax / locations in the merged GEMM's epilogue
         self.embed_dims = embed_dims
         self.num_levels = num_levels
         self.num_heads = num_heads
@@ -219,12 +220,21 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             table[:, :nv] = self.value_proj.bias
             torch.addmm(b_cat, pos_row, w_cat.t(), out=table[:, nv:])
             self._table_key, self._table = tkey, table
-        v, proj = ops.gemm_bf16x3_ex(q.reshape(bs * S, C), _split_weight(w_all), None, table,
-                                     residual_rows=S, n_split=nv,
-                                     fp16=get_gemm_mode() == 'fp16')
         ref = reference_points.reshape(1, bs * S, self.num_levels, 2)
         if not ref.is_contiguous():
             ref = ref.contiguous()
+        if get_gemm_mode() == 'bf16x3' and self.prepare_in_gemm and nv == 256 and w_all.shape[0] == 640:
+            # the sampler's softmax / location arithmetic runs in this GEMM's epilogue (its waves are
+            # ~25 % VALU-active, the sampler is VALU-bound): same code, same bits (pave_enc_math.h)
+            v, samp = ops.gemm_bf16x3_encproj(q.reshape(bs * S, C), _split_weight(w_all), table, ref,
+                                              tile_levels)
+            out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), samp, None,
+                                           levels_hw=tile_levels, window_shift=self._tile_shift(),
+                                           prepared=True)
+            return out.view(bs, S, self.embed_dims)
+        v, proj = ops.gemm_bf16x3_ex(q.reshape(bs * S, C), _split_weight(w_all), None, table,
+                                     residual_rows=S, n_split=nv,
+                                     fp16=get_gemm_mode() == 'fp16')
         out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), proj, ref,
                                        levels_hw=tile_levels, window_shift=self._tile_shift())
         return out.view(bs, S, self.embed_dims)

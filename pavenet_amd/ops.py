@@ -405,25 +405,61 @@ def enc_tile_window_shift(offset_bias):
     return tuple(int(v) for v in m.flatten().tolist())
 
 
-def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift=None):
+def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw):
+    """The encoder layer's merged N = 640 projection with the sampler's softmax / location
+    arithmetic in the GEMM epilogue (pave_gemm_bf16x3_encproj_f32): a [M, K], w_planes = 3-plane
+    split of the [640, K] weight, table [rows, 640] (row m adds table[m % rows]), ref [M, 4, 2]
+    -> (value [M, 256], samp [M, 384]): samp = level pixel coordinates + attention weights, the
+    `prepared=True` input of deform_attn_enc_tile."""
+    lib = native.load()
+    for t, nm in ((a, 'a'), (table, 'table'), (ref, 'ref')):
+        _dev(t, nm, torch.float32)
+    _dev(w_planes, 'w_planes', torch.int16)
+    M, K = a.shape
+    _require(w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[2] == 640
+             and w_planes.shape[0] * 16 == K, 'gemm_bf16x3_encproj: w_planes [K/16, 3, 640, 16]')
+    _require(table.dim() == 2 and table.shape[1] == 640 and ref.numel() == M * 8,
+             'gemm_bf16x3_encproj: table [rows, 640], ref [M, 4, 2]')
+    _require(len(levels_hw) == 4, 'gemm_bf16x3_encproj: four (h, w) levels')
+    import ctypes
+    hw_arr = (ctypes.c_int * 8)(*[int(v) for hw in levels_hw for v in hw])
+    value = torch.empty((M, 256), dtype=torch.float32, device=a.device)
+    samp = torch.empty((M, 384), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * 640, (M, K, 640, 'encproj')):
+        st = lib.pave_gemm_bf16x3_encproj_f32(a.data_ptr(), w_planes.data_ptr(), table.data_ptr(),
+                                              table.shape[0], ref.data_ptr(),
+                                              ctypes.cast(hw_arr, ctypes.c_void_p), value.data_ptr(),
+                                              samp.data_ptr(), M, K, _stream_ptr())
+    native.check(st, 'gemm_bf16x3_encproj')
+    return value, samp
+
+
+def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift=None, prepared=False):
     """Encoder deformable attention ([R2], T = 1) with LDS-staged value windows per image tile.
     value [F, S, 8, 32]; proj [F*S, >= 384]; ref [.., F*S, 4, 2] -> out [F*S, 256].
     Same results as ``deform_attn_grid_fused(..., T=1)``.  Differentiable (fused_autograd.py).
     window_shift: optional 64 host ints [8 heads][4 levels][(dx, dy)] (`enc_tile_window_shift`):
-    moves each head's LDS window onto its mean sampling offset -- speed only, same results."""
-    if torch.is_grad_enabled() and (value.requires_grad or proj.requires_grad or ref.requires_grad):
+    moves each head's LDS window onto its mean sampling offset -- speed only, same results.
+    prepared=True: `proj` comes from gemm_bf16x3_encproj (level pixel coordinates + attention
+    weights instead of offsets + logits; ref is not read and may be None) -- same bits."""
+    if not prepared and torch.is_grad_enabled() and \
+            (value.requires_grad or proj.requires_grad or ref.requires_grad):
         from .fused_autograd import EncTileFunction
         return EncTileFunction.apply(value, proj, ref, levels_hw, variant)
     lib = native.load()
     f32 = torch.float32
     _dev(value, 'value', f32)
     _dev(proj, 'proj', f32)
-    _dev(ref, 'ref', f32)
+    if prepared:
+        _require(variant == 0, 'deform_attn_enc_tile: prepared input with the default windows only')
+        variant = 4
+    if ref is not None or not prepared:
+        _dev(ref, 'ref', f32)
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_enc_tile: value must be [frames, S, 8, 32]')
     F_, S = value.shape[0], value.shape[1]
     _require(proj.dim() == 2 and proj.shape[0] == F_ * S, 'deform_attn_enc_tile: proj rows')
-    _require(ref.numel() == F_ * S * 8, 'deform_attn_enc_tile: ref must be [F*S, 4, 2]')
+    _require(ref is None or ref.numel() == F_ * S * 8, 'deform_attn_enc_tile: ref must be [F*S, 4, 2]')
     _require(enc_tile_supported(levels_hw), 'deform_attn_enc_tile: needs a 4-level halving pyramid')
     import ctypes
     flat = [int(v) for hw in levels_hw for v in hw]
@@ -435,8 +471,8 @@ def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift
     out = torch.empty((F_ * S, 256), dtype=f32, device=value.device)
     with torch.cuda.device(value.device), _Timed('enc_tile'):
         st = lib.pave_enc_deform_attn_tile_f32(
-            value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(), F_, S,
-            ctypes.cast(hw_arr, ctypes.c_void_p), proj.stride(0), int(variant),
+            value.data_ptr(), proj.data_ptr(), ref.data_ptr() if ref is not None else None,
+            out.data_ptr(), F_, S, ctypes.cast(hw_arr, ctypes.c_void_p), proj.stride(0), int(variant),
             ctypes.cast(sh_arr, ctypes.c_void_p) if sh_arr is not None else None, _stream_ptr())
     native.check(st, 'deform_attn_enc_tile')
     return out

@@ -9,6 +9,15 @@ def init_random_weights(model, seed=0):
     sampling-offset / attention-logit Linears: their default init is
     all-zero weights (OT:1631-1642), which makes every query sample the same points."""
     torch.manual_seed(seed)
+    # PyTorch draws Linear / Conv / Embedding defaults from the global generator at CONSTRUCTION time,
+    # and init_weights leaves many of them (every bias of the Linears, the attention in-projections) as
+    # they are: re-draw them under the seed first, so that the same seed gives the same weights in
+    # every process (bench parity, detection counts and the full-size tests are then reproducible)
+    for mod in model.modules():
+        reset = getattr(mod, 'reset_parameters', None) or getattr(mod, '_reset_parameters', None)
+        if callable(reset) and not list(mod.children()) or isinstance(mod, torch.nn.MultiheadAttention):
+            if callable(reset):
+                reset()
     for m in (model.backbone, model.neck, model.bbox_head):
         if m is not None:
             m.init_weights()

@@ -1495,35 +1495,34 @@ def test_ref_update_frames_equals_copy_plus_ref_update(cat_dim):
     assert torch.equal(got, exp)
 
 
-@pytest.mark.parametrize('N,Cin,Cout,H,W', [(2, 64, 64, 23, 37), (1, 48, 48, 40, 50), (2, 64, 128, 9, 16),
-                                            (1, 64, 96, 17, 33), (3, 48, 48, 8, 16), (1, 64, 64, 200, 336)])
-def test_conv3x3_lds_window_form_equals_implicit_gemm_form(N, Cin, Cout, H, W):
-    """The 3x3 form with the tile's input window resident in LDS (stride 1, Cin 48 | 64: ResNet
-    layer1, HRNet's 48-channel branch; resnet.py:263-300, hrnet.py:183-260) against the
-    implicit-GEMM form (diag variant 10) -- same products in the same order: bit for bit, partial
-    tiles, image borders, bias + identity + ReLU and a NaN pixel included -- and against fp64."""
-    from pavenet_amd import native
-    from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
-    g = torch.Generator().manual_seed(N * 100 + Cin + Cout + H)
-    x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
-    b = torch.randn(Cout, generator=g)
-    r = torch.randn(N, Cout, H, W, generator=g)
-    xd = x.cuda().contiguous(memory_format=torch.channels_last)
-    rd = r.cuda().contiguous(memory_format=torch.channels_last)
-    wp = split_conv3x3_weight(w.cuda())
-    for kw in (dict(relu=False), dict(relu=True, residual=rd)):
-        win = conv3x3_split(xd, wp, b.cuda(), stride=1, cout=Cout, **kw).clone()
-        with native.diag_build(10):
-            old = conv3x3_split(xd, wp, b.cuda(), stride=1, cout=Cout, **kw).clone()
-        assert torch.equal(win, old), float((win - old).abs().max())
-    exp = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1) + r.double())
-    np.testing.assert_allclose(win.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
-    xn = x.clone()
-    xn[0, 1, H // 2, W // 2] = float('nan')
-    xnd = xn.cuda().contiguous(memory_format=torch.channels_last)
-    win = conv3x3_split(xnd, wp, b.cuda(), stride=1, cout=Cout, relu=False)
-    with native.diag_build(10):
-        old = conv3x3_split(xnd, wp, b.cuda(), stride=1, cout=Cout, relu=False)
-    assert torch.equal(torch.isnan(win), torch.isnan(old))
-    assert int(torch.isnan(win[0]).any(0).sum()) == 9        # exactly the 3 x 3 outputs around it
+@pytest.mark.parametrize('levels,F,sigma', [([(100, 168), (50, 84), (25, 42), (13, 21)], 2, 0.9),
+                                            ([(16, 20), (8, 10), (4, 5), (2, 3)], 3, 3.0)])
+def test_encoder_projection_epilogue_equals_sampler_side_arithmetic(levels, F, sigma):
+    """pave_gemm_bf16x3_encproj_f32 + the sampler in its prepared mode (softmax over the 16 logits
+    and location -> pixel arithmetic done in the merged GEMM's epilogue, MO:373-404) against the
+    plain merged GEMM + the sampler doing that arithmetic itself: the same bits (one definition of
+    the arithmetic, csrc/pave_enc_math.h), value matrix included; non-trivial valid ratios, ragged M."""
+    from pavenet_amd import ops
+    S = sum(h * w for h, w in levels)
+    M, K = F * S, 256
+    g = torch.Generator(device='cuda').manual_seed(S + F)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(640, K, device='cuda', generator=g) * 0.05
+    w[256:512] *= sigma * 0.3          # offsets of ~sigma pixels
+    table = torch.randn(S, 640, device='cuda', generator=g) * 0.1
+    wp = ops.split_weight_bf16x3(w)
+    ys = torch.cat([((torch.arange(h * w_, device='cuda') // w_).float() + 0.5) / h for h, w_ in levels])
+    xs = torch.cat([((torch.arange(h * w_, device='cuda') % w_).float() + 0.5) / w_ for h, w_ in levels])
+    vr = torch.tensor([[0.93, 0.88], [0.95, 0.9], [1.0, 0.85], [0.9, 1.0]], device='cuda')   # per level
+    ref = (torch.stack([xs, ys], -1)[None, :, None, :] * vr[None, None]).expand(F, S, 4, 2).reshape(M, 4, 2).contiguous()
+    v0, proj = ops.gemm_bf16x3_ex(a, wp, None, table, residual_rows=S, n_split=256)
+    v1, samp = ops.gemm_bf16x3_encproj(a, wp, table, ref, levels)
+    assert torch.equal(v0, v1)
+    raw = ops.deform_attn_enc_tile(v0.view(F, S, 8, 32), proj, ref.view(1, M, 4, 2), levels_hw=levels)
+    pre = ops.deform_attn_enc_tile(v1.view(F, S, 8, 32), samp, None, levels_hw=levels, prepared=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pre).all()
+    assert torch.equal(raw, pre), float((raw - pre).abs().max())
+    # the prepared matrix is what it says: softmax weights sum to one per (row, head)
+    wsum = samp[:, 256:].view(M, 8, 16).sum(-1)
+    np.testing.assert_allclose(wsum.cpu().numpy(), 1.0, rtol=0, atol=1e-5)

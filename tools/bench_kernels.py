@@ -39,6 +39,9 @@ def main():
     ap.add_argument('--order', default='none')
     ap.add_argument('--enc-only', action='store_true')
     ap.add_argument('--ablate', action='store_true')
+    ap.add_argument('--prepared', action='store_true',
+                    help='time the sampler in its prepared mode (pixel coordinates + attention weights, as the '
+                         "merged projection GEMM's epilogue leaves them: the product's encoder path)")
     ap.add_argument('--ray', type=float, default=0.0,
                     help='add the reference init pattern to the offsets: head h, point i at (i + 1) '
                          '* ray * dir(h) px (MO:227-240 uses ray = 1)')
@@ -73,6 +76,19 @@ def main():
     alg = 4 * (F * S * 256 + U * 384 + U * 256)
     print(f'enc_fused   frames={F} order={args.order}: {us:9.1f} us  {us / F:8.1f} us/frame  '
           f'alg {alg / us / 1e3:7.1f} GB/s')
+    if args.prepared:
+        sizes = torch.tensor([[w, h] for h, w in LEVELS], dtype=torch.float32, device=dev)   # (W, H) per level
+        off = proj[:, :256].view(U, 8, 4, 4, 2)
+        px = (ref.view(U, 1, 4, 1, 2) + off / sizes[None, None, :, None, :]) * sizes[None, None, :, None, :] - 0.5
+        samp = torch.cat([px.reshape(U, 256), proj[:, 256:].view(U, 8, 16).softmax(-1).reshape(U, 128)], 1).contiguous()
+        us = timeit(lambda: ops.deform_attn_enc_tile(value, samp, None, levels_hw=LEVELS, prepared=True))
+        print(f'enc_tile prepared frames={F} sigma={args.sigma} ray={args.ray}: {us:9.1f} us  {us / F:8.1f} us/frame  '
+              f'alg {alg / us / 1e3:7.1f} GB/s = {alg / us / 1e3 / 8000:.3f} of 8 TB/s')
+        if shift is not None:
+            us = timeit(lambda: ops.deform_attn_enc_tile(value, samp, None, levels_hw=LEVELS, prepared=True,
+                                                         window_shift=shift))
+            print(f'enc_tile prepared ... with the per-head window shift: {us:9.1f} us  '
+                  f'= {alg / us / 1e3 / 8000:.3f} of 8 TB/s')
     for variant in (0, 1):
         us = timeit(lambda: ops.deform_attn_enc_tile(value, proj, ref, levels_hw=LEVELS,
                                                      variant=variant))
@@ -92,11 +108,11 @@ def main():
             [ctypes.c_int] * 3 + [ctypes.c_void_p]
         hw = (ctypes.c_int * 8)(*[v for hw_ in LEVELS for v in hw_])
         out = torch.empty(U, 256, device=dev)
-        for ab in (0, 1, 2, 3, 4, 6):
+        for ab in (0, 1, 2, 3):
             us = timeit(lambda: fn(value.data_ptr(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                    F, S, ctypes.cast(hw, ctypes.c_void_p), 384, 0, ab,
                                    torch.cuda.current_stream().cuda_stream))
-            print(f'enc_tile v0 ablate={ab} (1: no staging, 2: no gather, 4: no softmax / locations): {us:9.1f} us')
+            print(f'enc_tile v0 ablate={ab} (1: no staging, 2: no gather): {us:9.1f} us')
     if args.enc_only:
         return
     # the un-fused reference-shaped op on the same work

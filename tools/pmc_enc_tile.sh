@@ -10,14 +10,14 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM" \
            "TA_BUSY_avr TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/tools/bench_kernels.py --frames 28 --sigma 0.9 --enc-only > $R/gpurun_out/$OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/tools/bench_kernels.py --frames 28 --sigma 0.9 --enc-only --prepared > $R/gpurun_out/$OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob('$R/gpurun_out/$OUT/p*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        if 'enc_tile_kernel<14' in r['Kernel_Name']:
+        if 'enc_tile_kernel<14' in r['Kernel_Name'] and ', true>' in r['Kernel_Name']:   # the prepared-mode instantiation
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 m = {}
 for c, v in sorted(agg.items()):
