@@ -157,6 +157,9 @@ def file_git_blob_sha1(path):
 # launches of the split-operand MFMA GEMM family (pavenet_amd/csrc/pave_gemm_dma.hip, pave_gemm_split.hip)
 SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided', 'conv7x7_stem',
                    'bottleneck_chain')
+# the same kernels on the decoders' / heads' few-hundred-row Linears (M < ops.SMALL_ROWS = 8192: 10 row
+# tiles for 256 CUs, latency-bound by shape): timed too, reported beside the class, not inside it
+SMALL_GEMM_TAGS = ('gemm_bf16x3_small', 'gemm_bf16x3_ln_small')
 
 
 def algorithmic_bytes_encoder_launch(n_frames):
@@ -276,7 +279,7 @@ def secondary_workloads(args, dev, budget_s=75.0):
             t0 = time.perf_counter()
             for _ in range(steps - ev_steps):
                 step()
-            ops.KERNEL_EVENT_TAGS = SPLIT_GEMM_TAGS
+            ops.KERNEL_EVENT_TAGS = SPLIT_GEMM_TAGS      # (rows >= 8192, as the headline's class)
             ops.KERNEL_EVENTS = []
             for _ in range(ev_steps):
                 step()
@@ -472,7 +475,7 @@ def main():
         if args.steps - ev_steps > 0:
             out = run_steps(args.steps - ev_steps, P)
         if ev_on:
-            ops.KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1') + SPLIT_GEMM_TAGS
+            ops.KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1') + SPLIT_GEMM_TAGS + SMALL_GEMM_TAGS
             ops.KERNEL_EVENTS = []
             out = run_steps(ev_steps, P)
         sync()
@@ -533,6 +536,16 @@ def main():
             by_entry_point={k: dict(launches_per_step=round(v[0] / max(1, ev_steps_main), 1),
                                     ms_per_step=round(v[1] / max(1, ev_steps_main) * 1e3, 3),
                                     tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in sorted(by.items())})
+        sm = [(t, fl) for tag, t, fl in timed_ev if tag in SMALL_GEMM_TAGS]
+        if sm:
+            st_, sf_ = sum(t for t, _ in sm), sum(fl for _, fl in sm)
+            roofline_mfma['small_row_launches'] = dict(
+                note='the same kernels at M < 8192 rows (decoder / head Linears): latency-bound by shape, '
+                     'reported beside the class',
+                launches_per_step=round(len(sm) / max(1, ev_steps_main), 1),
+                ms_per_step=round(st_ / max(1, ev_steps_main) * 1e3, 3),
+                tflop_per_step=round(sf_ / max(1, ev_steps_main) / 1e12, 4),
+                tflops=round(sf_ / st_ / 1e12, 1))
     if graphed is not None:
         roofline = dict(skipped='graph replay: kernels are not launched through the timed wrappers')
     elif enc:

@@ -87,7 +87,11 @@ int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_
  *   frame_table [n_clips*T] int32, or NULL: the value slab of frame t of clip c is
  *              frame_table[c*T + t] instead of c*T + t -- `value` is then a per-frame cache
  *              [n_cached_frames, S, 8, 32] shared by overlapping clips (streaming windows of a video,
- *              opera/datasets/posetrack_video_pose.py:578-623: no per-window copy / re-projection)
+ *              opera/datasets/posetrack_video_pose.py:578-623: no per-window copy / re-projection).
+ *              PRECONDITION: 0 <= frame_table[i] < n_cached_frames -- the entries are slab indices read
+ *              on the device and are NOT range-checked (the number of cached slabs is not an argument);
+ *              the caller that builds the table owns the check (pavenet_amd/streaming.py does it on the
+ *              host list the table is made from, FrameSlabs.covers)
  *   out        [n_units, 256]
  *   stat_max, stat_sum  [n_units, 8] or NULL: per-head max logit and sum(exp(logit-max)) over the
  *              frames this call saw (for merging frame-sharded partial results)
@@ -128,6 +132,15 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
 int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
                                  long long table_rows, const float* ref, const int* levels_hw,
                                  float* value, float* samp, long long M, int K, void* stream);
+
+/*
+ * HRNet stem conv1 (third_party/mmdetection/mmdet/models/backbones/hrnet.py:549-556): 3x3 / stride 2
+ * / pad 1 convolution of the NCHW image batch x [N, 3, H, W], 3 -> 64 channels, + bias (the folded
+ * BatchNorm) + optional ReLU -> y [N, Ho, Wo, 64] NHWC, Ho = (H - 1) / 2 + 1.
+ *   w_taps [27][64]: weight[co][c][ky][kx] at w_taps[(c * 3 + ky) * 3 + kx][co]
+ */
+int pave_conv3x3s2_c3_nchw_f32(const float* x, const float* w_taps, const float* bias, float* y, int N,
+                               int H, int W, int relu, void* stream);
 
 /*
  * Scaled-dot-product core of the decoders' self-attention (replaces what nn.MultiheadAttention

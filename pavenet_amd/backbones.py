@@ -791,7 +791,19 @@ class HRNet(BaseModule):
             x = x.flatten(0, 1)
         assert not self.training
         fast = _Folded.ok(x)
-        if fast:
+        if fast and x.is_contiguous() and x.shape[1] == 3 and self.conv1.out_channels == 64 and \
+                self.conv1.stride == (2, 2) and self.conv1.padding == (1, 1) and self.conv1.groups == 1:
+            # conv1 reads the NCHW batch as it is (no channels_last copy of the images, no library
+            # convolution): K = 27 is too thin for the matrix cores, the launch is HBM-bound
+            from . import ops
+            w, b = _Folded.weights(self.conv1, self.bn1)     # (cached on the conv, re-made when it changes)
+            hit = self.conv1.__dict__.get('_pave_taps')
+            if hit is None or hit[0] is not w:
+                hit = (w, w.detach().permute(1, 2, 3, 0).reshape(27, 64).contiguous())
+                self.conv1.__dict__['_pave_taps'] = hit
+            x = ops.conv3x3s2_c3_nchw(x, hit[1], b, relu=True)
+            x = _Folded.conv_bn(x, self.conv2, self.bn2, relu=True)
+        elif fast:
             x = x.contiguous(memory_format=torch.channels_last)
             x = _Folded.conv_bn(x, self.conv1, self.bn1, relu=True)
             x = _Folded.conv_bn(x, self.conv2, self.bn2, relu=True)

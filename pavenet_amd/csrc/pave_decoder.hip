@@ -29,28 +29,16 @@ constexpr int kD = 32;        // channels per head
 constexpr int kPad = 36;      // LDS row pitch in dwords (see header)
 constexpr int kGroup = 4;     // keys per online-softmax group and lane
 
-template <int Q>
-__device__ __forceinline__ float quad_bcast(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
-                                                               Q * 0x55, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float quad_xor1(float v) {   // quad_perm:[1,0,3,2]
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1,
-                                                               0xf, 0xf, true));
-}
-__device__ __forceinline__ float quad_xor2(float v) {   // quad_perm:[2,3,0,1]
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e,
-                                                               0xf, 0xf, true));
-}
-__device__ __forceinline__ float quad_sum(float v) {
-  v += quad_xor1(v);
-  v += quad_xor2(v);
-  return v;
-}
-__device__ __forceinline__ float quad_max(float v) {
-  v = fmaxf(v, quad_xor1(v));
-  v = fmaxf(v, quad_xor2(v));
-  return v;
+// one butterfly step of the partial-row merge: lanes r and r ^ ST exchange halves of the N * 2 live
+// channels (the lane with bit ST set keeps the upper half); register indices are compile-time
+template <int ST, int N>
+__device__ __forceinline__ void merge_step(float (&o)[kD], const int r) {
+  const bool hi = (r & ST) != 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float keep = hi ? o[N + i] : o[i], send = hi ? o[i] : o[N + i];
+    o[i] = keep + __shfl_xor(send, ST, 64);
+  }
 }
 
 struct MhaParams {
@@ -79,12 +67,10 @@ __global__ __launch_bounds__(NW * 64) void mha_core_kernel(const MhaParams p) {
     float4 kreg[SU], vreg[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int i = i0 + u * NW * 64;
-      if (i < L * 8) {
-        const float* src = base + (size_t)(i >> 3) * p.ld + (i & 7) * 4;
-        kreg[u] = *reinterpret_cast<const float4*>(src + E);
-        vreg[u] = *reinterpret_cast<const float4*>(src + 2 * E);
-      }
+      const int i = min(i0 + u * NW * 64, L * 8 - 1);   // (clamped: loaded anyway, stored if in range)
+      const float* src = base + (size_t)(i >> 3) * p.ld + (i & 7) * 4;
+      kreg[u] = *reinterpret_cast<const float4*>(src + E);
+      vreg[u] = *reinterpret_cast<const float4*>(src + 2 * E);
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -171,20 +157,15 @@ __global__ __launch_bounds__(NW * 64) void mha_core_kernel(const MhaParams p) {
   const float inv = 1.f / lsum;
 #pragma unroll
   for (int c = 0; c < kD; ++c) o[c] *= w;
-  {
-    int n = kD;
-#pragma unroll
-    for (int st = LQ / 2; st >= 1; st >>= 1) {
-      n >>= 1;
-      const bool hi = (r & st) != 0;
-#pragma unroll
-      for (int i = 0; i < kD / 2; ++i) {
-        if (i < n) {
-          const float keep = hi ? o[n + i] : o[i], send = hi ? o[i] : o[n + i];
-          o[i] = keep + __shfl_xor(send, st, 64);
-        }
-      }
-    }
+  if constexpr (LQ == 16) {
+    merge_step<8, 16>(o, r);
+    merge_step<4, 8>(o, r);
+    merge_step<2, 4>(o, r);
+    merge_step<1, 2>(o, r);
+  } else {
+    static_assert(LQ == 4, "4 or 16 lanes per query");
+    merge_step<2, 16>(o, r);
+    merge_step<1, 8>(o, r);
   }
   constexpr int CW = kD / LQ;   // channels per lane: 8 (LQ 4) | 2 (LQ 16)
   if (valid) {

@@ -1483,6 +1483,51 @@ __global__ __launch_bounds__(256) void ref_update_kernel(const float* __restrict
   }
 }
 
+// HRNet stem conv1: 3x3 / stride 2 / pad 1 convolution of the NCHW image batch, 3 -> 64 channels,
+// folded BatchNorm bias + ReLU, NHWC output (third_party/mmdetection/mmdet/models/backbones/
+// hrnet.py:549-556: conv1 -> norm1 -> relu).  27 input taps per output pixel: far too thin for the
+// matrix cores (K = 27) and HBM-bound anyway (1.93 GB written per 28 frames), so a lane owns one
+// output pixel and all 64 channels -- 27 x 64 fp32 FMAs with the weights as scalar operands (one
+// s_load burst per tap, uniform over the wave), 16 float4 stores of the pixel's 256-byte row.
+// Taps are accumulated in (channel, ky, kx) order.
+__global__ __launch_bounds__(256) void conv3x3s2_c3_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,   // [27][64]
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           const int N, const int H, const int W,
+                                                           const int Ho, const int Wo, const int relu) {
+  const long long total = (long long)N * Ho * Wo;
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int ox = (int)(pix % Wo);
+  const long long t = pix / Wo;
+  const int oy = (int)(t % Ho), n = (int)(t / Ho);
+  float in[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        in[(c * 3 + ky) * 3 + kx] = ok ? x[(((long long)n * 3 + c) * H + iy) * W + ix] : 0.f;
+      }
+  float acc[64];
+#pragma unroll
+  for (int co = 0; co < 64; ++co) acc[co] = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int co = 0; co < 64; ++co) acc[co] = fmaf(in[k], w[k * 64 + co], acc[co]);
+  float4* o = reinterpret_cast<float4*>(y + pix * 64);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    o[q] = v;
+  }
+}
+
 }  // namespace
 
 int pave_internal_fail(int code, const char* msg) { return fail(code, msg); }
@@ -1827,6 +1872,20 @@ int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* bet
   const long long nb = std::min<long long>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ab, y,
                      y_batch_stride, N, HW, C);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_conv3x3s2_c3_nchw_f32(const float* x, const float* w_taps, const float* bias, float* y, int N,
+                               int H, int W, int relu, void* stream) {
+  if (!x || !w_taps || !y) return fail(PAVE_E_ARG, "conv3x3s2_c3: null pointer");
+  if (N <= 0 || H <= 0 || W <= 0) return fail(PAVE_E_ARG, "conv3x3s2_c3: sizes must be positive");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo;
+  if ((total + 255) / 256 >= (1ll << 31)) return fail(PAVE_E_ARG, "conv3x3s2_c3: grid too large");
+  hipLaunchKernelGGL(conv3x3s2_c3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, w_taps, bias, y, N, H, W, Ho, Wo, relu);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

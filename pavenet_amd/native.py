@@ -52,6 +52,7 @@ SIGNATURES = {
     'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _vp],
     'pave_gemm_bf16x3_encproj_f32': [_vp, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, ctypes.c_longlong,
                                      _c_int, _vp],
+    'pave_conv3x3s2_c3_nchw_f32': [_vp] * 4 + [_c_int] * 4 + [_vp],
     'pave_mha_core_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_topk_rows_f32': [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_gather_frame_poses_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [_vp],

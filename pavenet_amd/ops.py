@@ -51,6 +51,14 @@ class _Timed:
             KERNEL_EVENTS.append((self.tag, self.s, self.e, self.flops))
 
 
+SMALL_ROWS = 8192   # GEMM launches with fewer rows are latency-bound by shape (the decoders' few hundred
+#                     query rows): timed under their own tag, reported beside the dominant class
+
+
+def _gemm_tag(tag, M):
+    return tag if M >= SMALL_ROWS else tag + '_small'
+
+
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)
@@ -186,6 +194,8 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_grid_fused: value must be [frames, S, 8, 32]')
     if frame_table is not None:   # value = per-frame cache, slab of (clip, t) = frame_table[clip*T + t]
+        # (entries must be < value.shape[0]: checked where the table is built, streaming.decode --
+        # a device-side check here would be a host sync per launch)
         _dev(frame_table, 'frame_table', torch.int32)
         _require(frame_table.numel() == n_clips * T, 'deform_attn_grid_fused: frame_table [n_clips*T]')
     else:
@@ -633,7 +643,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
+    with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
                                       PLANES_FP16 if fp16 else int(w_planes.shape[1]),
@@ -671,7 +681,7 @@ def gemm_bf16x3_cat(a, a2, w_planes, bias=None, residual=None, relu=False, out=N
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_cat: out [M, N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'cat', f'k1={K1}')):
+    with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'cat', f'k1={K1}')):
         st = lib.pave_gemm_bf16x3_cat_f32(a.data_ptr(), K1, a2.data_ptr(), w_planes.data_ptr(),
                                           ptr(bias), ptr(residual), out.data_ptr(), M, K, N,
                                           int(bool(relu)), _stream_ptr())
@@ -696,7 +706,7 @@ def gemm_bf16x3_grouped(a, w_planes, bias, group_n, relu=False):
         _dev(bias, 'bias', torch.float32)
         _require(bias.numel() == N, 'gemm_bf16x3_grouped: bias [N]')
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'grouped', f'g{G}')):
+    with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'grouped', f'g{G}')):
         st = lib.pave_gemm_bf16x3_grouped_f32(a.data_ptr(), lda, w_planes.data_ptr(),
                                               bias.data_ptr() if bias is not None else None,
                                               out.data_ptr(), M, K, N, int(group_n), int(bool(relu)),
@@ -728,6 +738,29 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), _stream_ptr())
     native.check(st, 'conv1x1_strided_split')
+    return y.permute(0, 3, 1, 2)
+
+
+def conv3x3s2_c3_nchw(x, w_taps, bias=None, relu=False):
+    """HRNet stem conv1: 3x3 / stride 2 / pad 1, 3 -> 64 channels, read straight from the NCHW batch
+    x [N, 3, H, W] (contiguous) -> [N, 64, Ho, Wo] channels_last; w_taps [27, 64] =
+    weight.permute(1, 2, 3, 0).reshape(27, 64) (pave_conv3x3s2_c3_nchw_f32)."""
+    lib = native.load()
+    _dev(x, 'x', torch.float32)
+    _dev(w_taps, 'w_taps', torch.float32)
+    _require(x.dim() == 4 and x.shape[1] == 3 and tuple(w_taps.shape) == (27, 64),
+             'conv3x3s2_c3_nchw: x [N, 3, H, W], w_taps [27, 64]')
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == 64, 'conv3x3s2_c3_nchw: bias [64]')
+    N, _, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, 64), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.pave_conv3x3s2_c3_nchw_f32(x.data_ptr(), w_taps.data_ptr(),
+                                            bias.data_ptr() if bias is not None else None,
+                                            y.data_ptr(), N, H, W, int(bool(relu)), _stream_ptr())
+    native.check(st, 'conv3x3s2_c3_nchw')
     return y.permute(0, 3, 1, 2)
 
 
@@ -860,7 +893,7 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_ln: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3_ln', 2 * M * K * N, (M, K, N, 'ln', 'res' if residual is not None else '')):
+    with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3_ln', M), 2 * M * K * N, (M, K, N, 'ln', 'res' if residual is not None else '')):
         st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
                                          gamma.data_ptr(), beta.data_ptr(), float(eps),
                                          out.data_ptr(), M, K, N, _stream_ptr())
@@ -900,7 +933,7 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
     out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * N, (M, K, N, 'ex', f'rows{rr}', f'split{n_split}')):
+    with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'ex', f'rows{rr}', f'split{n_split}')):
         st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                          ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
                                          M, K, N, int(bool(relu)),

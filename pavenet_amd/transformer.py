@@ -654,6 +654,10 @@ class VideoPoseTransformerMulFrames(Transformer):
             enc_outputs_sigma_unact = mlp_rows(sigma_branches[self.decoder.num_layers], tgt)
             if frame_shard is not None:
                 from . import dist as pdist
+                # (branch outputs off the 4-column grid are column slices of a padded matrix)
+                tgt, topk_kpts_unact = tgt.contiguous(), topk_kpts_unact.contiguous()
+                enc_outputs_kpt_unact = topk_kpts_unact
+                enc_outputs_sigma_unact = enc_outputs_sigma_unact.contiguous()
                 for t_ in (tgt, topk_kpts_unact, enc_outputs_sigma_unact):
                     pdist.broadcast_from(t_, frame_shard.center_owner, frame_shard.group)
             reference_points = topk_kpts_unact.sigmoid().repeat(1, T, 1)

@@ -1526,3 +1526,27 @@ def test_encoder_projection_epilogue_equals_sampler_side_arithmetic(levels, F, s
     # the prepared matrix is what it says: softmax weights sum to one per (row, head)
     wsum = samp[:, 256:].view(M, 8, 16).sum(-1)
     np.testing.assert_allclose(wsum.cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 33, 47), (1, 64, 96), (3, 7, 5)])
+def test_hrnet_stem_conv3x3s2_c3_vs_torch_fp64(N, H, W):
+    """pave_conv3x3s2_c3_nchw_f32 (HRNet stem conv1 + folded BN + ReLU, hrnet.py:549-556: 3x3 / stride
+    2 / pad 1, 3 -> 64 channels read from the NCHW batch) against torch.conv2d in fp64; odd sizes,
+    borders, and a NaN pixel poisoning exactly the outputs whose window holds it."""
+    from pavenet_amd.ops import conv3x3s2_c3_nchw
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    taps = w.permute(1, 2, 3, 0).reshape(27, 64).contiguous()
+    y = conv3x3s2_c3_nchw(x.cuda(), taps.cuda(), b.cuda(), relu=True)
+    exp = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 1))
+    assert tuple(y.shape) == tuple(exp.shape) and y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    y0 = conv3x3s2_c3_nchw(x.cuda(), taps.cuda(), None, relu=False)
+    exp0 = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 1)
+    np.testing.assert_allclose(y0.cpu().numpy(), exp0.numpy(), rtol=1e-5, atol=1e-5)
+    xn = x.clone()
+    xn[0, 1, H // 2, W // 2] = float('nan')
+    bad = torch.isnan(conv3x3s2_c3_nchw(xn.cuda(), taps.cuda(), b.cuda())[0]).any(0).cpu()
+    assert torch.equal(bad, torch.isnan(torch.nn.functional.conv2d(xn, w, b, 2, 1)[0]).any(0))

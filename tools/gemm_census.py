@@ -30,7 +30,7 @@ def main():
     for _ in range(2):
         m.forward_device(img, metas)
     torch.cuda.synchronize()
-    ops.KERNEL_EVENT_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_strided',
+    ops.KERNEL_EVENT_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'gemm_bf16x3_small', 'gemm_bf16x3_ln_small', 'conv3x3_split', 'conv1x1_strided',
                              'conv7x7_stem', 'bottleneck_chain', 'enc_tile', 'rows_gemm', 'stem_pool', 'groupnorm')
     ops.KERNEL_EVENTS, ops.KERNEL_EVENT_SHAPES = [], []
     for _ in range(steps):
