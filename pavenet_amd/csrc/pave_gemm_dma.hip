@@ -134,6 +134,16 @@ __device__ __forceinline__ void dma16_buf(unsigned voff, i32x4 rsrc, unsigned ld
 // LDS-only barrier of the epilogue (no vector-memory wait)
 #define PAVE_QBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// sum over the 32 lanes of a half wave, result in every lane: DPP butterflies inside the rows of 16
+// (quad xor 1, xor 2, half-row mirror, row mirror), then one exchange between the two rows
+__device__ __forceinline__ float half32_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v + __shfl_xor(v, 16, 64);
+}
+
 __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (zero padding)
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
@@ -178,7 +188,7 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int EPI_OFF = 0;                        // per-wave epilogue chunks reuse the ring
   constexpr int STAT_OFF = NS * STAGE;              // LayerNorm row statistics (WN > 1)
   constexpr int TQ = WIDE ? 2 : TN;                 // column tiles per W fragment set
-  static_assert(!WIDE || (TN == 8 && WN == 1 && !ABIAS && !LNORM), "wide form: 32 x 256 per wave");
+  static_assert(!WIDE || (TN == 8 && WN == 1 && !ABIAS), "wide form: 32 x 256 per wave");
   constexpr int ABOFF = STAT_OFF + (LNORM ? 2 * QBM * WN * 4 : 0);   // a_bias vector
   static_assert(NA % NWAVE == 0, "A DMA instructions divide evenly over the waves");
   static_assert(!LNORM || KIND == 0, "LayerNorm epilogue: plain row GEMM only");
@@ -540,7 +550,7 @@ __device__ __forceinline__ void gemm_q_body(
       mma_q(0, 1, 3);
       split_raw(nslabs - 1, 1);
       PAVE_WQ012(1)   // (every wave has read the last stage: the epilogue reuses the ring)
-      prefetch_residual(em0, en0);
+      if constexpr (!LNORM) prefetch_residual(em0, en0);
       mma_q(1, 1, 3);
 #undef PAVE_WQ012
 #undef PAVE_WSTEP
@@ -554,7 +564,52 @@ __device__ __forceinline__ void gemm_q_body(
                               : out + (os.ks_slabs > 0 ? (long long)blockIdx.y * M * os.n_real : 0);
     const int ldo = os.out2 == nullptr ? os.n_real : (seg2 ? N - os.nsplit : os.nsplit);
     const int csh = seg2 ? os.nsplit : 0;
-    if constexpr (!LNORM) {
+    constexpr bool LNW = LNORM && WIDE;   // LayerNorm computed on the accumulator layout (below)
+    if constexpr (LNW) {
+      __builtin_amdgcn_sched_barrier(0);   // (nothing of the epilogue is hoisted into the last slab)
+      // The wave owns 32 whole rows of the N = 256 output: lane (lr, kh) holds, for r = 0..15, row
+      // (r & 3) + 8 (r >> 2) + 4 kh at the columns lr + 32 j.  v = acc + bias + identity IN PLACE
+      // (the identity read as 128-byte row segments: 32 lanes x 4 B), row statistics = in-lane sums
+      // over the 8 tiles + an all-reduce over the 32 lanes of the half wave (two-pass: mean, then
+      // centred squares), normalised in place -- no second register image of the tile, no LDS sweep,
+      // no workgroup barrier; gamma / beta ride the ordinary store pass below.
+      // identity rows through a buffer resource over [M, BN] (< 4 GiB, the launcher's condition): ONE
+      // 32-bit lane offset, the row / tile part of the address is a scalar offset, and rows past M are
+      // out-of-range reads (zeros) -- no 64-bit address per element
+      const __amdgpu_buffer_rsrc_t idr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(residual ? residual : out), 0, residual ? (int)((unsigned)M * (unsigned)(BN * 4)) : 0,
+          0x00020000);
+      const int id_voff = ((wm * 32 + 4 * kh) * BN + lr) * 4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float bj = bias ? bias[en0 + j * 32 + lr] : 0.f;
+        float idv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          idv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              idr, id_voff, (em0 + (r & 3) + 8 * (r >> 2)) * (BN * 4) + (en0 + j * 32) * 4, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bj) + idv[r];
+        __builtin_amdgcn_sched_barrier(0);   // (one tile's 16 loads in flight at a time: registers)
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sm += acc[j][r];
+        const float mean = half32_sum(sm) * (1.f / (float)BN);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j][r] -= mean;
+          q = fmaf(acc[j][r], acc[j][r], q);
+        }
+        const float rs = rsqrtf(half32_sum(q) * (1.f / (float)BN) + ln.eps);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j][r] *= rs;
+      }
+    }
+    if constexpr (!LNORM || LNW) {
       float2 erf[NPS];          // EPI 1: reference point (x, y) of the lane's level per pass
       float eW = 0.f, eH = 0.f, erW = 0.f, erH = 0.f;
       if constexpr (EPI == 1) {
@@ -571,8 +626,13 @@ __device__ __forceinline__ void gemm_q_body(
       for (int j = 0; j < TN; ++j) {
         const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
         const bool colok = ncol < os.n_real;
-        const float4 b4 = (bias && colok) ? *reinterpret_cast<const float4*>(bias + ncol)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b4 = (!LNW && bias && colok) ? *reinterpret_cast<const float4*>(bias + ncol)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), be4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LNW) {
+          g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
+          be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
@@ -584,8 +644,12 @@ __device__ __forceinline__ void gemm_q_body(
           const int lrow = ps * 8 + erow;
           const long long gm = (long long)em0 + wm * 32 + lrow;
           float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
+          if constexpr (LNW) {
+            v.x = fmaf(v.x, g4.x, be4.x), v.y = fmaf(v.y, g4.y, be4.y);
+            v.z = fmaf(v.z, g4.z, be4.z), v.w = fmaf(v.w, g4.w, be4.w);
+          }
           v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
-          if (residual) {
+          if (!LNW && residual) {
             const float4 rv = resv[j % RB][ps];
             v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
           }
@@ -605,7 +669,7 @@ __device__ __forceinline__ void gemm_q_body(
           }
           if (gm < M && colok) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
         }
-        if (WIDE && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
+        if (WIDE && !LNW && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -648,20 +712,26 @@ __device__ __forceinline__ void gemm_q_body(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      // (WN == 1, the wide form: the wave owns whole rows -- the 8 lanes of a row segment hold the
+      // row's totals after the shuffles, no exchange through LDS and no workgroup barrier)
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         float sm = rsum[ps];
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-        if (ec4 == 0) st1[(wm * 32 + ps * 8 + erow) * WN + wn] = sm;
+        rsum[ps] = sm;
+        if (WN > 1 && ec4 == 0) st1[(wm * 32 + ps * 8 + erow) * WN + wn] = sm;
       }
-      PAVE_QBAR();
+      if constexpr (WN > 1) PAVE_QBAR();
+      float rstd[NPS];
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int brow = wm * 32 + ps * 8 + erow;
-        float sm = 0.f;
+        float sm = WN > 1 ? 0.f : rsum[ps];
+        if constexpr (WN > 1) {
 #pragma unroll
-        for (int w = 0; w < WN; ++w) sm += st1[brow * WN + w];
+          for (int w = 0; w < WN; ++w) sm += st1[brow * WN + w];
+        }
         const float mean = sm * (1.f / (float)BN);
         float q = 0.f;
 #pragma unroll
@@ -672,16 +742,18 @@ __device__ __forceinline__ void gemm_q_body(
         }
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        if (ec4 == 0) st2[brow * WN + wn] = q;
+        if (WN > 1 && ec4 == 0) st2[brow * WN + wn] = q;
+        rstd[ps] = q;
       }
-      PAVE_QBAR();
-      float rstd[NPS];
+      if constexpr (WN > 1) PAVE_QBAR();
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int brow = wm * 32 + ps * 8 + erow;
-        float q = 0.f;
+        float q = WN > 1 ? 0.f : rstd[ps];
+        if constexpr (WN > 1) {
 #pragma unroll
-        for (int w = 0; w < WN; ++w) q += st2[brow * WN + w];
+          for (int w = 0; w < WN; ++w) q += st2[brow * WN + w];
+        }
         rstd[ps] = rsqrtf(q * (1.f / (float)BN) + ln.eps);
       }
       // column tile outermost: gamma / beta of one tile live at a time
@@ -845,6 +917,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // measured: 647 -> 729 us at K = 256, equal at K = 1024.  Not kept.)
   gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
                                     QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
+}
+
+// LayerNorm epilogue on the wide form: 4 waves, a wave owns 32 whole rows of the N = 256 output (no
+// statistics exchange between waves, no workgroup barrier in the epilogue), two blocks per CU.
+// Round 3 built this with a second register image of the tile (spills) and with LDS sweeps (equal to
+// the 8-wave form); here bias + identity are added and the statistics taken IN the accumulator
+// registers (see LNW in gemm_q_body), which costs no registers and no LDS pass.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_ln_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
+  gemm_q_body<8, 1, 0, false, true, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
+                                          QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
 
 // ---------------------------------------------------------------------------
@@ -1215,6 +1299,27 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
     attr_set = true;
   }
   const long long gx = (M + QBM - 1) / QBM;
+  // From two tiles per CU slot on: the wide form (4 waves, a wave owns 32 whole rows; LayerNorm on the
+  // accumulator layout, two blocks per CU) -- 602 -> 548 us at K = 256, 1 715 -> 1 606 us at K = 1024 for
+  // 625 044 rows (tools/ln_ab.py).  Few tiles (the decoders' M = 1 200) keep the 8-wave block: twice the
+  // waves per tile.  (diag variant 13: always the 8-wave form, 14: always the wide form.)  The identity
+  // rows are read through a buffer resource: M * 1024 bytes < 4 GiB.
+  const int dvl = pave_internal_diag_variant();
+  if (dvl != 13 && (gx >= 512 || dvl == 14) && M * 1024ll < (1ll << 32)) {
+    static bool attr_w = false;
+    if (!attr_w) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w_ln_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+        return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w_ln: cannot raise dynamic LDS limit");
+      attr_w = true;
+    }
+    hipLaunchKernelGGL(gemm_w_ln_kernel, dim3((unsigned)gx), dim3(256), W_SMEM,
+                       reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes),
+                       bias, residual, out, (int)M, K, N, QLn{gamma, beta, eps});
+    const hipError_t ew = hipGetLastError();
+    if (ew != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(ew));
+    return PAVE_OK;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), smem,
                      reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes),
                      bias, residual, out, (int)M, K, N, QLn{gamma, beta, eps});

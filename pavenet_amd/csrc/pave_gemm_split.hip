@@ -554,6 +554,7 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // the LDS-DMA generation of pave_gemm_dma.hip, the default),
                          // 5 = 3x3 form with 64-bit lane addresses (not buffer-addressed),
                          // 6 = no split-K plan,
+                         // 13 / 14 = LayerNorm-epilogue GEMM: always the 8-wave / the wide form,
                          // 8 = LDS-DMA generation without its wide tile form, 7 = wide
                          // tile form wherever it applies (default: from 512 tiles up)
 

@@ -1550,3 +1550,34 @@ def test_hrnet_stem_conv3x3s2_c3_vs_torch_fp64(N, H, W):
     xn[0, 1, H // 2, W // 2] = float('nan')
     bad = torch.isnan(conv3x3s2_c3_nchw(xn.cuda(), taps.cuda(), b.cuda())[0]).any(0).cpu()
     assert torch.equal(bad, torch.isnan(torch.nn.functional.conv2d(xn, w, b, 2, 1)[0]).any(0))
+
+
+@pytest.mark.parametrize('M,K,res', [(70000, 256, True), (66001, 1024, True), (300, 256, False), (1200, 1024, True)])
+def test_gemm_ln_wide_form_vs_8wave_form_and_fp64(M, K, res):
+    """Linear + identity + LayerNorm in one launch (bricks/transformer.py:1316-1353): the wide form
+    (LayerNorm statistics on the accumulator layout, diag variant 14) against the 8-wave form (13)
+    -- same products, the LayerNorm sums in another order: <= 4e-6 -- and both against fp64;
+    ragged M, in-place identity."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import gemm_bf16x3_ln, split_weight_bf16x3
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(256, K, device='cuda', generator=g) / K ** 0.5
+    b, ga, be = (torch.randn(256, device='cuda', generator=g) for _ in range(3))
+    r = torch.randn(M, 256, device='cuda', generator=g) if res else None
+    wp = split_weight_bf16x3(w)
+    with native.diag_build(13):
+        eight = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5).clone()
+    with native.diag_build(14):
+        wide = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5).clone()
+        inplace = r.clone() if res else None
+        if res:
+            gemm_bf16x3_ln(a, wp, b, inplace, ga, be, 1e-5, out=inplace)
+    default = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)
+    assert torch.equal(default, wide if M >= 512 * 128 else eight)     # the shipped library's choice
+    if res:
+        assert torch.equal(inplace, wide)
+    np.testing.assert_allclose(wide.cpu().numpy(), eight.cpu().numpy(), rtol=0, atol=4e-6)
+    x = a.double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    exp = torch.nn.functional.layer_norm(x, (256,), ga.double(), be.double(), 1e-5)
+    np.testing.assert_allclose(wide.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
