@@ -1109,6 +1109,117 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   reinterpret_cast<float4*>(out)[i] = v;
 }
 
+// ---------------------------------------------------------------------------
+// Small-row form: the decoders' and heads' Linears have a few hundred to ~1 200 rows (300 queries per
+// clip, 15 joint queries per pose) -- 10 row tiles of the 128-row kernels for 256 CUs, each walking its
+// whole K axis behind one barrier per slab: latency, not throughput (17 us at K = 256, 66 us at
+// K = 1024).  Here a WAVE owns a 32-row x 32 TN-column tile and walks K on its own: the A fragment
+// (8 consecutive fp32 of the lane's row) and the W fragments (the lane's 16-byte piece of each plane)
+// come straight from global memory / L2 into registers, PF slabs ahead -- no LDS, no barrier, no
+// workgroup-level dependence at all -- so a launch is hundreds to thousands of independent waves
+// spread over every CU.  Same six products per slab in the same order per accumulator as the tile
+// kernels: results are bit-identical to them (and to a batch large enough to take the tile kernels).
+// Forms: plain rows (row stride lda), grouped columns (group i = columns [i K, (i + 1) K) of A),
+// bias, full or row-periodic residual, ReLU, zero-padded weight planes (n_real <= N).  The shipped
+// selection uses TN = 1 (32 x 32 per wave) for outputs up to 512 columns.
+// ---------------------------------------------------------------------------
+template <int TN, int PF>
+__global__ __launch_bounds__(256) void gemm_s_kernel(
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
+    const float* residual, float* out, const int M, const int K, const int N, const int relu,
+    const int lda, const int group_n, const int res_rows, const int n_real) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 31, kh = lane >> 5;
+  const int ntn = (N + 32 * TN - 1) / (32 * TN);
+  const int t = blockIdx.x * 4 + wave;                 // the four waves of a block: neighbouring
+  const int tm = t / ntn, tn = t - tm * ntn;           // column tiles of one row tile (A rows via L1)
+  if (tm * 32 >= M) return;                            // (wave-uniform; no barrier anywhere)
+  const int m0 = tm * 32, n0 = tn * 32 * TN;
+  const int nslabs = K >> 4;
+  const int arow = min(m0 + lr, M - 1);                // rows past M: stand-in data, never stored
+  const float* ap = A + (long long)arow * lda + (group_n > 0 ? (n0 / group_n) * K : 0) + kh * 8;
+  // plane row of column n: 16 bf16 = 32 bytes; the lane's half kh
+  const uint16_t* wp = Wp + ((long long)(n0 + lr) * 16 + kh * 8);
+  const long long w_plane = (long long)N * 16, w_slab = 3 * w_plane;   // in bf16 elements
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f32x4 raw[PF][2];
+  u32x4 wf[PF][3][TN];
+  auto load = [&](const int slab, const int set) {
+    raw[set][0] = *reinterpret_cast<const f32x4*>(ap + slab * 16);
+    raw[set][1] = *reinterpret_cast<const f32x4*>(ap + slab * 16 + 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        // (column tiles past the planes' N rows -- N % (32 TN) != 0 -- re-read the last tile: not stored)
+        const long long jo = (n0 + j * 32 < N) ? (long long)j * 32 * 16 : 0;
+        wf[set][p][j] = *reinterpret_cast<const u32x4*>(wp + slab * w_slab + p * w_plane + jo);
+      }
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < nslabs) load(u, u);
+  for (int s = 0; s < nslabs; s += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (s + u < nslabs) {
+        u32x4 apl[3];
+        split8(raw[u][0], raw[u][1], apl);
+        // the products of order o = pa + pb: o = 2, 1, 0 (smallest terms first), as the tile kernels
+#pragma unroll
+        for (int o = 2; o >= 0; --o)
+#pragma unroll
+          for (int pa = 0; pa <= o; ++pa)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, apl[pa]), __builtin_bit_cast(bf16x8, wf[u][o - pa][j]),
+                  acc[j], 0, 0, 0);
+        if (s + u + PF < nslabs) load(s + u + PF, u);
+      }
+    }
+  }
+  // ---- epilogue from the accumulator layout: lane (lr, kh), register r = row (r & 3) + 8 (r >> 2) +
+  // 4 kh, column lr of tile j; a row's 32 columns are one 128-byte segment
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + j * 32 + lr;
+    const bool colok = col < n_real;
+    const float bj = (bias && colok) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row < M && colok) {
+        float v = acc[j][r] + bj;
+        if (residual) {
+          const int rr = res_rows > 0 ? (int)((unsigned)row % (unsigned)res_rows) : row;
+          v += residual[(long long)rr * n_real + col];
+        }
+        if (relu) v = fmaxf(v, 0.f);
+        out[(long long)row * n_real + col] = v;
+      }
+    }
+  }
+}
+
+template <int TN, int PF>
+int launch_s(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
+             long long M, int K, int N, int relu, int lda, int group_n, int res_rows, int n_real,
+             hipStream_t st) {
+  const long long tiles = ((M + 31) / 32) * ((N + 32 * TN - 1) / (32 * TN));
+  hipLaunchKernelGGL((gemm_s_kernel<TN, PF>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w, bias,
+                     residual, out, (int)M, K, N, relu, lda, group_n, res_rows, n_real);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+constexpr long long kSmallRows = 8192;   // launches with fewer rows take the small-row form
+
 constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
 
 template <int KIND>
@@ -1196,6 +1307,18 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (kind == 1 && Cin % 16 != 0) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3x3 form needs Cin %% 16 == 0");
   if (kind == 4 && (!a2 || Cin <= 0 || Cin >= K || Cin % 16 != 0))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: two-source rows need a2 and 0 < K1 < K, K1 %% 16 == 0");
+  // few rows (the decoders' / heads' Linears): the small-row form -- a wave per 32-row tile, no LDS, no
+  // barrier; the shipped selection only (any diag variant keeps the tile kernels, which the
+  // form-equality tests compare it with)
+  // Narrow outputs only (N <= 512: the 256-wide Linears in front of a LayerNorm, the heads' 2 .. 30
+  // output columns): wider ones re-read the A rows once per 32-column tile and measured SLOWER than the
+  // tile kernels (64- and 128-column wave tiles: 1200 x 256 x 10080 45 -> 73 us, the grouped branch MLPs
+  // 38 -> 76 us), so they keep those.  Measured with it: 1200 x 1024 x 256 + LayerNorm 62 -> 35 us,
+  // 1200 x 256 x 256 + LayerNorm 24 -> 19 us.
+  if (kind == 0 && M < kSmallRows && N <= 512 && !a_bias && !out2 && ksplit == 1 &&
+      pave_internal_diag_variant() == 0)
+    return launch_s<1, 4>(a, w, bias, residual, out, M, K, N, relu, H > 0 ? H : K, W > 0 ? W : 0, os.res_rows,
+                          n_real, st);
   // 3x3 form: buffer-addressed below 4 GiB of map (a lane's byte offset is 32 bits wide)
   // (diag variant 5: the 64-bit lane-address form everywhere, for A/B)
   const bool big3 = kind == 1 && ((M / ((long long)Ho * Wo)) * H * W * Cin * 4 >= (1ll << 32) - 65536 ||
@@ -1288,6 +1411,14 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
                             int K, int N, void* stream) {
   if (K % 32 != 0 || K < 64 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_q_ln: K %% 32 == 0, K >= 64 and N == 256 required");
+  if (M < kSmallRows && pave_internal_diag_variant() == 0) {
+    // few rows: the small-row GEMM (bias + identity in its epilogue), then LayerNorm in place -- two
+    // launches of a few microseconds instead of 10 row tiles walking K behind barriers
+    const int st1 = launch_s<1, 4>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K,
+                                   0, 0, N, reinterpret_cast<hipStream_t>(stream));
+    if (st1 != PAVE_OK) return st1;
+    return pave_bias_add_layernorm_f32(out, nullptr, nullptr, gamma, beta, out, M, N, eps, stream);
+  }
   constexpr int STAGE = QBM * 64 + 3 * 256 * 32;
   constexpr int smem = QNS * STAGE + 2 * QBM * 2 * 4;
   auto kern = gemm_q_ln_kernel;

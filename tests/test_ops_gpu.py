@@ -1574,10 +1574,81 @@ def test_gemm_ln_wide_form_vs_8wave_form_and_fp64(M, K, res):
         if res:
             gemm_bf16x3_ln(a, wp, b, inplace, ga, be, 1e-5, out=inplace)
     default = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)
-    assert torch.equal(default, wide if M >= 512 * 128 else eight)     # the shipped library's choice
+    if M >= 512 * 128:          # the shipped library's choice: wide form from 512 row tiles on
+        assert torch.equal(default, wide)
+    elif M >= 8192:             # 8-wave form between 8192 rows and that; below: small-row GEMM + LayerNorm pass
+        assert torch.equal(default, eight)
     if res:
         assert torch.equal(inplace, wide)
     np.testing.assert_allclose(wide.cpu().numpy(), eight.cpu().numpy(), rtol=0, atol=4e-6)
     x = a.double() @ w.double().t() + b.double() + (r.double() if res else 0)
     exp = torch.nn.functional.layer_norm(x, (256,), ga.double(), be.double(), 1e-5)
     np.testing.assert_allclose(wide.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_small_row_gemm_form_equals_tile_kernels_bit_for_bit(seed):
+    """The small-row form of the split GEMM (a wave per 32-row tile, operands straight from L2, no LDS:
+    the decoders' / heads' Linears, M < 8192) against the 128-row tile kernels (diag variant 8) on
+    random shapes and epilogues -- same products in the same order: bit for bit -- incl. zero-padded
+    planes (n_out), the row-periodic residual table, grouped columns, ragged M."""
+    from pavenet_amd import native, ops
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
+    dev = 'cuda'
+    M = ri(1, 1300)
+    K = 32 * ri(2, 40)
+    kind = ('plain', 'pad', 'ex', 'grouped')[seed % 4]
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)   # noqa: E731
+    relu = bool(seed & 1)
+    if kind == 'plain':
+        N = 64 * ri(1, 8)            # (the small-row form takes outputs up to 512 columns)
+        a, w, b, r = rnd(M, K), rnd(N, K, scale=0.05), rnd(N), rnd(M, N)
+        wp = ops.split_weight_bf16x3(w, pad=True)
+        run = lambda: ops.gemm_bf16x3(a, wp, b, r, relu=relu)                 # noqa: E731
+    elif kind == 'pad':
+        N = 4 * ri(1, 128)
+        a, w, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N)
+        wp = ops.split_weight_bf16x3(w, pad=True)
+        run = lambda: ops.gemm_bf16x3(a, wp, b, None, relu=relu, n_out=N)     # noqa: E731
+    elif kind == 'ex':
+        N, rows = 128 * ri(1, 4), ri(1, 400)
+        a, w, tab = rnd(M, K), rnd(N, K, scale=0.05), rnd(rows, N)
+        wp = ops.split_weight_bf16x3(w, pad=True)
+        run = lambda: ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=rows)[0]   # noqa: E731
+    else:
+        G, gn = ri(2, 7), 64
+        G = min(G, 8)             # G * 64 <= 512 columns
+        a, w, b = rnd(M, G * K), rnd(G * gn, K, scale=0.05), rnd(G * gn)
+        wp = ops.split_weight_bf16x3(w, pad=True)
+        run = lambda: ops.gemm_bf16x3_grouped(a, wp, b, gn, relu=relu)        # noqa: E731
+    small = run().clone()
+    with native.diag_build(8):
+        tile = run().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(small).all()
+    assert torch.equal(small, tile), (kind, M, K, float((small - tile).abs().max()))
+
+
+@pytest.mark.parametrize('M,K', [(1200, 256), (1200, 1024), (37, 64), (300, 512)])
+def test_small_row_linear_layernorm_vs_fp64(M, K):
+    """Linear + identity + LayerNorm at few rows: the small-row GEMM + the LayerNorm pass (the shipped
+    selection below 8192 rows) against fp64 and against the one-launch 8-wave form (diag variant 13)."""
+    from pavenet_amd import native
+    from pavenet_amd.ops import gemm_bf16x3_ln, split_weight_bf16x3
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(256, K, device='cuda', generator=g) / K ** 0.5
+    b, ga, be = (torch.randn(256, device='cuda', generator=g) for _ in range(3))
+    r = torch.randn(M, 256, device='cuda', generator=g)
+    wp = split_weight_bf16x3(w)
+    got = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)
+    inplace = r.clone()
+    gemm_bf16x3_ln(a, wp, b, inplace, ga, be, 1e-5, out=inplace)
+    assert torch.equal(inplace, got)
+    with native.diag_build(13):
+        one = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), one.cpu().numpy(), rtol=0, atol=4e-6)
+    x = a.double() @ w.double().t() + b.double() + r.double()
+    exp = torch.nn.functional.layer_norm(x, (256,), ga.double(), be.double(), 1e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
