@@ -1,11 +1,17 @@
-// pave_decoder.hip -- the small kernels of the decoders' self-attention (gfx950, wave64).
+// pave_decoder.hip -- the small kernels of the decoders and the head (gfx950, wave64): what sits between
+// the GEMM launches after the encoder, each replacing a run of library / elementwise launches:
+//   pave_mha_core_f32            scaled-dot-product core of the decoders' self-attention
+//   pave_topk_rows_f32           proposal / score top-k (one launch; torch.topk: up to 22)
+//   pave_gather_frame_poses_f32  the selected queries' poses of all T frames, frame-major
+//   pave_ref_update_frames_f32   reference-point update read from the grouped per-frame MLP output
+//   pave_pose_finalize_f32       post-processing of the refined poses (pixels, box, RLE confidence)
 //
-// Replaces the scaled-dot-product core of nn.MultiheadAttention as the reference uses it in both
+// pave_mha_core_f32
+// replaces the scaled-dot-product core of nn.MultiheadAttention as the reference uses it in both
 // decoders (third_party/mmcv/mmcv/cnn/bricks/transformer.py:406-551: q = k = x + pos, v = x,
 // 8 heads of 32 channels, no masks, no dropout at inference): 300 pose queries per clip in the
 // pose decoder, 15 joint queries per pose in the joint decoder.  The q | k | v projection and
-// out_proj + identity + LayerNorm are launches of the split GEMM (pave_gemm_dma.hip); this file
-// is what sits between them.
+// out_proj + identity + LayerNorm are launches of the split GEMM (pave_gemm_dma.hip).
 //
 // Work layout: one workgroup per (query chunk, head, sequence).  The head's K and V rows
 // ([L, 32] fp32 each) are copied once into LDS with rows padded to 36 dwords, so that the four

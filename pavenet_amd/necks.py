@@ -58,7 +58,8 @@ class ChannelMapper(BaseModule):
         GEMM through the hand-written split-operand kernel, when the GEMM mode and the shape take
         it (bricks.split_gemm_ok / split_conv_weight); None otherwise (library convolution)."""
         from . import ops
-        from .bricks import get_gemm_mode, linear_rows, split_conv_weight, split_gemm_ok
+        from .bricks import (get_gemm_mode, linear_rows, small_split_ok, split_conv_weight,
+                             split_gemm_ok)
         if conv.groups != 1 or conv.dilation != (1, 1) or conv.bias is not None \
                 or torch.is_grad_enabled():
             return None
@@ -67,8 +68,8 @@ class ChannelMapper(BaseModule):
             xc = x.contiguous(memory_format=torch.channels_last)
             rows = xc.permute(0, 2, 3, 1).reshape(-1, c)
             w2 = conv.weight.flatten(1)
-            if not split_gemm_ok(rows, w2):
-                return None
+            if not (split_gemm_ok(rows, w2) or small_split_ok(rows, w2)):    # (HRNet's K = 96 level:
+                return None                                                 #  zero-padded planes)
             y = linear_rows(rows, w2)
             return y.view(n, h, w, -1).permute(0, 3, 1, 2)
         if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and \

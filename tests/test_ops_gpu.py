@@ -1652,3 +1652,25 @@ def test_small_row_linear_layernorm_vs_fp64(M, K):
     x = a.double() @ w.double().t() + b.double() + r.double()
     exp = torch.nn.functional.layer_norm(x, (256,), ga.double(), be.double(), 1e-5)
     np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_neck_1x1_level_with_96_channels_runs_the_split_gemm():
+    """HRNet-w48's first neck level (ChannelMapper, channel_mapper.py:63-78, in_channels 96 -> 256,
+    1x1, no bias): K = 96 is off the 64-grid of the tile kernels' fast shapes but K % 32 == 0, so
+    the level takes the 3-plane kernel on zero-padded planes instead of a library convolution;
+    checked against conv2d in fp64."""
+    from pavenet_amd import bricks
+    from pavenet_amd.necks import ChannelMapper
+    g = torch.Generator().manual_seed(96)
+    conv = torch.nn.Conv2d(96, 256, 1, bias=False).cuda()
+    x = torch.randn(2, 96, 50, 84, generator=g).cuda()
+    old = bricks.get_gemm_mode()
+    try:
+        bricks.set_gemm_mode('bf16x3')
+        with torch.no_grad():
+            y = ChannelMapper._conv_split(conv, x)
+    finally:
+        bricks.set_gemm_mode(old)
+    assert y is not None, 'the K = 96 level fell back to the library'
+    exp = torch.nn.functional.conv2d(x.double(), conv.weight.double())
+    np.testing.assert_allclose(y.cpu().numpy(), exp.cpu().numpy(), rtol=1e-5, atol=1e-5)

@@ -28,8 +28,8 @@ def cls(k):
         return 'hipBLASLt fp32 GEMM ' + re.search(r'MT\\d+x\\d+x\\d+', k).group(0)
     if 'conv_nhwc_kernel' in k:
         return 'pave conv_nhwc_kernel (Bottleneck tail, fp32 MFMA)'
-    if 'gemm_bf16x3' in k or 'gemm_q_' in k or 'gemm_w' in k or 'bottleneck_chain' in k or 'stem7x7_q' in k:
-        return 'pave gemm_q / gemm_w / gemm_wn / gemm_q_ln / bottleneck_chain / stem7x7_q kernels (split GEMM / convolutions, bf16 MFMA x 6)'
+    if 'gemm_bf16x3' in k or 'gemm_q_' in k or 'gemm_w' in k or 'gemm_s_' in k or 'bottleneck_chain' in k or 'stem7x7_q' in k:
+        return 'pave gemm_q / gemm_w / gemm_wn / gemm_q_ln / gemm_s / bottleneck_chain / stem7x7_q kernels (split GEMM / convolutions, bf16 MFMA x 6)'
     if 'enc_tile_kernel' in k:
         return 'pave enc_tile_kernel (encoder sampling, no MFMA)'
     if 'grouped_conv_fwd' in k or k.startswith('igemm_fwd'):
