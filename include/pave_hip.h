@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 15
+#define PAVE_ABI_VERSION 16
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -123,6 +123,9 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
  * per-(query, head) arithmetic done in the GEMM epilogue:
  *   a [M, K] fp32;  w_planes = the 3-plane split of the [640, K] row-concatenated weight;
  *   table [table_rows, 640]: row m adds table[m % table_rows] (bias + positional term);
+ *   value_bias: NULL, or 256 floats added to the value columns INSTEAD of the table's first 256
+ *     columns, which are then not read (value_proj has no positional term: its table columns are
+ *     one bias row repeated);
  *   ref [M, 4, 2] reference points (normalised x, y per level);  levels_hw [4][2] (h, w), HOST memory
  *   -> value [M, 256];  samp [M, 384] = level PIXEL coordinates [8 heads][4 levels][4 points][x, y]
  *      ((ref + off / (w, h)) * (w, h) - 0.5), then softmaxed attention weights [8][16]
@@ -130,8 +133,9 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
  * feeding that kernel the raw projections (one definition of the arithmetic, csrc/pave_enc_math.h).
  */
 int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
-                                 long long table_rows, const float* ref, const int* levels_hw,
-                                 float* value, float* samp, long long M, int K, void* stream);
+                                 long long table_rows, const float* value_bias, const float* ref,
+                                 const int* levels_hw, float* value, float* samp, long long M, int K,
+                                 void* stream);
 
 /*
  * HRNet stem conv1 (third_party/mmdetection/mmdet/models/backbones/hrnet.py:549-556): 3x3 / stride 2

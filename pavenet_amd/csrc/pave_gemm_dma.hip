@@ -35,6 +35,7 @@
 // reads stay ordinary loads, so their lgkmcnt waits are the compiler's.  Results are bit-identical
 // to the first-generation kernel (same products, same order per accumulator).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "pave_hip.h"
@@ -142,6 +143,13 @@ __device__ __forceinline__ float half32_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
   return v + __shfl_xor(v, 16, 64);
+}
+
+// max(x, 0) as the single v_max_f32 fmaxf ends in (the compiler puts a canonicalising v_max in front of it)
+__device__ __forceinline__ float relu_max(float x) {
+  float y;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
 }
 
 __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (zero padding)
@@ -406,36 +414,47 @@ __device__ __forceinline__ void gemm_q_body(
   const int erow = lane >> 3, ec4 = lane & 7;
   constexpr int RB = WIDE ? 4 : TN;      // residual tiles in registers (WIDE: four, rotating)
   float4 resv[RB][NPS];
-  long long rrow[NPS];                   // residual row of the lane per pass
+  // Every global access of the epilogue goes through a buffer resource over THIS TILE's rows (output,
+  // full residual) or over the whole row-periodic table: one 32-bit lane offset per pass, the column
+  // tile as a scalar offset, rows past M and columns past n_real get the offset kOut (>= any range
+  // below 2 GiB: the hardware drops the store / returns zeros) -- no 64-bit address per access and
+  // no predication around it.
+  constexpr unsigned kOut = 0x80000000u;
+  using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+  unsigned rro[NPS];                     // residual byte offset of the lane's row per pass (+ its 16-byte column)
+  __amdgpu_buffer_rsrc_t rrs;
   auto residual_rows = [&](const int em0) {
     // row-periodic table (row m adds residual[m % res_rows]): one modulo per lane, the passes
     // step the row by 8 with a wrap (res_rows >= 32: at most one wrap per step)
-    const long long gm0 = (long long)em0 + wm * 32 + erow;
     const bool table = os.res_rows != 0;
+    const int rows_left = min(QBM, M - em0);
+    rrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(residual) + (table ? 0ll : (long long)em0 * os.n_real), 0,
+        (table ? os.res_rows : rows_left) * os.n_real * 4, 0x00020000);
+    const int lrow0 = wm * 32 + erow;
     const bool stepwise = os.res_rows >= 32;
-    const long long rbase = table ? (long long)((unsigned)gm0 % (unsigned)os.res_rows) : gm0;
+    const unsigned rbase = table ? (unsigned)(em0 + lrow0) % (unsigned)os.res_rows : 0u;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-      const long long gm = gm0 + ps * 8;
-      long long rr = gm;
+      unsigned rr = (unsigned)(lrow0 + ps * 8);
       if (table) {
         if (stepwise) {
           rr = rbase + ps * 8;
-          if (rr >= os.res_rows) rr -= os.res_rows;
+          if (rr >= (unsigned)os.res_rows) rr -= (unsigned)os.res_rows;
         } else {
-          rr = (long long)((unsigned)gm % (unsigned)os.res_rows);
+          rr = (unsigned)(em0 + lrow0 + ps * 8) % (unsigned)os.res_rows;
         }
       }
-      rrow[ps] = gm < M ? rr : -1;
+      rro[ps] = lrow0 + ps * 8 < rows_left ? rr * (unsigned)(os.n_real * 4) + ec4 * 16 : kOut;
     }
   };
   auto prefetch_residual_tile = [&](const int en0, const int j, const int buf) {
-    const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
+    const int ncol0 = en0 + wn * TN * 32 + j * 32;   // wave-uniform
+    const bool colok = WIDE || ncol0 + ec4 * 4 < os.n_real;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps)
-      resv[buf][ps] = (rrow[ps] >= 0 && ncol < os.n_real)
-                          ? *reinterpret_cast<const float4*>(residual + rrow[ps] * os.n_real + ncol)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      resv[buf][ps] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, colok ? rro[ps] : kOut, ncol0 * 4, 0));
   };
   auto prefetch_residual = [&](const int em0, const int en0) {
     if (!residual) return;
@@ -564,6 +583,23 @@ __device__ __forceinline__ void gemm_q_body(
                               : out + (os.ks_slabs > 0 ? (long long)blockIdx.y * M * os.n_real : 0);
     const int ldo = os.out2 == nullptr ? os.n_real : (seg2 ? N - os.nsplit : os.nsplit);
     const int csh = seg2 ? os.nsplit : 0;
+    // the tile's output rows behind a buffer resource (see resv above) that starts at the wave's first
+    // column: rows past M fall outside it.  The column tile is an immediate offset and the scalar offset
+    // stays 0: with a REGISTER there the compiler does not put the wait state between a 16-byte store and a
+    // VALU write of its data registers (GCNHazardRecognizer: "no hazard with an SGPR offset"), and on gfx950
+    // rows stored that way came out with the next instruction's value in them (tools/debug_encproj.py).
+    const int orows = min(QBM, M - em0);
+    const int ocol0 = en0 + wn * TN * 32 - csh;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+        obase + (long long)em0 * ldo + ocol0, 0, (orows * ldo - ocol0) * 4, 0x00020000);
+    unsigned oro[NPS];
+    int late = 0;   // an opaque zero made HERE: the lane offsets below are not computed ahead of the main
+    asm volatile("" : "+v"(late));   // loop (where every register is taken)
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int lrow = wm * 32 + ps * 8 + erow + late;
+      oro[ps] = lrow < orows ? (unsigned)(lrow * ldo * 4 + ec4 * 16) : kOut;
+    }
     constexpr bool LNW = LNORM && WIDE;   // LayerNorm computed on the accumulator layout (below)
     if constexpr (LNW) {
       __builtin_amdgcn_sched_barrier(0);   // (nothing of the epilogue is hoisted into the last slab)
@@ -575,7 +611,8 @@ __device__ __forceinline__ void gemm_q_body(
       // no workgroup barrier; gamma / beta ride the ordinary store pass below.
       // identity rows through a buffer resource over [M, BN] (< 4 GiB, the launcher's condition): ONE
       // 32-bit lane offset, the row / tile part of the address is a scalar offset, and rows past M are
-      // out-of-range reads (zeros) -- no 64-bit address per element
+      // out-of-range reads (zeros: the hardware compares lane offset + scalar offset with num_records,
+      // without wrap-around -- tools/microbench/buffer_range.hip) -- no 64-bit address per element
       const __amdgpu_buffer_rsrc_t idr = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(residual ? residual : out), 0, residual ? (int)((unsigned)M * (unsigned)(BN * 4)) : 0,
           0x00020000);
@@ -624,8 +661,9 @@ __device__ __forceinline__ void gemm_q_body(
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int ncol = en0 + wn * TN * 32 + j * 32 + ec4 * 4;
-        const bool colok = ncol < os.n_real;
+        const int ncol0 = en0 + wn * TN * 32 + j * 32;   // wave-uniform
+        const int ncol = ncol0 + ec4 * 4;
+        const bool colok = WIDE || ncol < os.n_real;   // (wide form: N == n_real, the launcher's condition)
         const float4 b4 = (!LNW && bias && colok) ? *reinterpret_cast<const float4*>(bias + ncol)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), be4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -639,35 +677,58 @@ __device__ __forceinline__ void gemm_q_body(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (LNW) {
+          // (one pass at a time: the 128 accumulators are live until their tile is stored)
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) {
-          const int lrow = ps * 8 + erow;
-          const long long gm = (long long)em0 + wm * 32 + lrow;
-          float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
-          if constexpr (LNW) {
+          for (int ps = 0; ps < NPS; ++ps) {
+            float4 v = *reinterpret_cast<const float4*>(Cs + (ps * 8 + erow) * QCST + ec4 * 4);
             v.x = fmaf(v.x, g4.x, be4.x), v.y = fmaf(v.y, g4.y, be4.y);
             v.z = fmaf(v.z, g4.z, be4.z), v.w = fmaf(v.w, g4.w, be4.w);
+            // (flat stores here: with the buffer form this body, already at 256 registers, spilled 14)
+            const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
+            if (gm < M) *reinterpret_cast<float4*>(obase + gm * ldo + ncol) = v;
           }
-          v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
-          if (!LNW && residual) {
-            const float4 rv = resv[j % RB][ps];
-            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+        } else {
+          // the tile's four passes side by side: the wave-uniform options (residual, ReLU) are ONE branch
+          // per tile each (the empty asm keeps them branches: as selects they cost up to 3 instructions
+          // per value whether the option is on or not)
+          float4 v[NPS];
+#pragma unroll
+          for (int ps = 0; ps < NPS; ++ps) {
+            v[ps] = *reinterpret_cast<const float4*>(Cs + (ps * 8 + erow) * QCST + ec4 * 4);
+            v[ps].x += b4.x, v[ps].y += b4.y, v[ps].z += b4.z, v[ps].w += b4.w;
+          }
+          if (residual) {
+            asm volatile("" ::);
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+              const float4 rv = resv[j % RB][ps];
+              v[ps].x += rv.x, v[ps].y += rv.y, v[ps].z += rv.z, v[ps].w += rv.w;
+            }
           }
           if (relu) {
-            v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            asm volatile("" ::);
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps)
+              v[ps].x = relu_max(v[ps].x), v[ps].y = relu_max(v[ps].y), v[ps].z = relu_max(v[ps].z),
+              v[ps].w = relu_max(v[ps].w);
           }
-          if constexpr (EPI == 1) {   // two points (x, y) of one level
-            v.x = pave_enc::pixel_coord(erf[ps].x, v.x, eW, erW);
-            v.y = pave_enc::pixel_coord(erf[ps].y, v.y, eH, erH);
-            v.z = pave_enc::pixel_coord(erf[ps].x, v.z, eW, erW);
-            v.w = pave_enc::pixel_coord(erf[ps].y, v.w, eH, erH);
+#pragma unroll
+          for (int ps = 0; ps < NPS; ++ps) {
+            if constexpr (EPI == 1) {   // two points (x, y) of one level
+              v[ps].x = pave_enc::pixel_coord(erf[ps].x, v[ps].x, eW, erW);
+              v[ps].y = pave_enc::pixel_coord(erf[ps].y, v[ps].y, eH, erH);
+              v[ps].z = pave_enc::pixel_coord(erf[ps].x, v[ps].z, eW, erW);
+              v[ps].w = pave_enc::pixel_coord(erf[ps].y, v[ps].w, eH, erH);
+            }
+            if constexpr (EPI == 2) {   // the quad holds the 16 logits of (row, head)
+              float e[4], inv;
+              pave_enc::softmax16(v[ps].x, v[ps].y, v[ps].z, v[ps].w, e, inv);
+              v[ps].x = e[0] * inv, v[ps].y = e[1] * inv, v[ps].z = e[2] * inv, v[ps].w = e[3] * inv;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ps]), ors,
+                                                   (colok ? oro[ps] : kOut) + j * 128, 0, 0);
           }
-          if constexpr (EPI == 2) {   // the quad holds the 16 logits of (row, head)
-            float e[4], inv;
-            pave_enc::softmax16(v.x, v.y, v.z, v.w, e, inv);
-            v.x = e[0] * inv, v.y = e[1] * inv, v.z = e[2] * inv, v.w = e[3] * inv;
-          }
-          if (gm < M && colok) *reinterpret_cast<float4*>(obase + gm * ldo + (ncol - csh)) = v;
         }
         if (WIDE && !LNW && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -824,8 +885,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (pave_enc_math.h), so pave_enc_deform_attn_tile_f32 in its `prepared` mode returns the same bits.
 // These waves are ~25 % VALU-active; the sampler is VALU-bound.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wn_enc_kernel(
-    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* residual, float* out,
-    const int M, const int K, const QOut os, const QEpi epi) {
+    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* residual,
+    const float* __restrict__ value_bias, float* out, const int M, const int K, const QOut os, const QEpi epi) {
   constexpr int N = 640, ntl = 3;
   const int ttot = ((M + QBM - 1) / QBM) * ntl;
   const int per = ttot >> 3, rem = ttot & 7;
@@ -834,9 +895,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int row = lb / ntl, c = lb - row * ntl;
   const QLn ln0{nullptr, nullptr, 0.f};
   const QConv g{0, 0, 0, 0, 0, 0, 0u};
-  if (c == 0)
-    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os, ln0,
-                                             nullptr, row * QBM, 0);
+  if (c == 0)   // (value columns: one bias row instead of 256 table columns per row, when the caller has it)
+    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, value_bias, value_bias ? nullptr : residual, out, M, K, N, 0,
+                                             nullptr, g, os, ln0, nullptr, row * QBM, 0);
   else if (c == 1)
     gemm_q_body<8, 1, 0, false, false, true, 1>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
                                                 ln0, nullptr, row * QBM, 256, &epi);
@@ -1299,6 +1360,9 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   if (K % 32 != 0 || K < 64) return pave_internal_fail(PAVE_E_ARG, "gemm_q: K %% 32 == 0, K >= 64");
+  // the epilogue reads a row-periodic table / writes a tile's rows through 32-bit buffer offsets
+  if ((os.res_rows != 0 && (long long)os.res_rows * n_real * 4 >= (1ll << 31)) || (long long)N * 512 >= (1ll << 31))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: row-periodic table of >= 2 GiB, or rows of >= 16 MiB");
   // the row forms address a tile's A bytes with a 32-bit lane offset: (rows - 1) * row length * 4 + 64
   if (kind != 1 && K >= (1 << 23))
     return pave_internal_fail(PAVE_E_ARG, "gemm_q: K < 2^23 (32-bit lane offsets inside a 128-row tile)");
@@ -1337,7 +1401,7 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   // the CUs better
   const int dv = pave_internal_diag_variant();
   const long long wtiles = ((M + QBM - 1) / QBM) * (N / 256) * ksplit;
-  if (N % 256 == 0 && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
+  if (N % 256 == 0 && n_real == N && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
       !(kind == 0 && W > 0 && W % 256 != 0) && (!out2 || n_split % 256 == 0)) {
     if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
     if (kind == 1 && big3) return launch_w<2>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
@@ -1345,7 +1409,7 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
     if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
     return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
   }
-  if (kind == 0 && N % 256 == 128 && N >= 384 && !narrow && !a_bias && dv != 8 && W == 0 && ksplit == 1 &&
+  if (kind == 0 && N % 256 == 128 && N >= 384 && n_real == N && !narrow && !a_bias && dv != 8 && W == 0 && ksplit == 1 &&
       (((M + QBM - 1) / QBM) * (N / 256 + 1) >= 400 || dv == 7) && (!out2 || n_split % 256 == 0)) {
     const long long gx = ((M + QBM - 1) / QBM) * (N / 256 + 1);
     if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_wn: grid too large");
@@ -1377,8 +1441,8 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
 
 // merged encoder projection with the sampler's softmax / location arithmetic in the epilogue
 int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float* table, long long table_rows,
-                               const float* ref, const int* levels_hw, float* value, float* samp,
-                               long long M, int K, void* stream) {
+                               const float* value_bias, const float* ref, const int* levels_hw, float* value,
+                               float* samp, long long M, int K, void* stream) {
   if (K % 32 != 0 || K < 64 || K >= (1 << 23)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: K %% 32 == 0, 64 <= K < 2^23");
   QEpi epi{};
   epi.ref = ref;
@@ -1388,6 +1452,8 @@ int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float
     epi.fH[l] = (float)levels_hw[2 * l], epi.fW[l] = (float)levels_hw[2 * l + 1];
     epi.rH[l] = 1.f / (float)levels_hw[2 * l], epi.rW[l] = 1.f / (float)levels_hw[2 * l + 1];
   }
+  if (table_rows < M && table_rows * 640 * 4 >= (1ll << 31))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: row-periodic table of >= 2 GiB");
   const QOut os{samp, 256, table_rows >= M ? 0 : (int)table_rows, 640, 0};
   const long long gx = ((M + QBM - 1) / QBM) * 3;
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: grid too large");
@@ -1400,7 +1466,7 @@ int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float
   }
   hipLaunchKernelGGL(gemm_wn_enc_kernel, dim3((unsigned)gx), dim3(256), W_SMEM,
                      reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes), table,
-                     value, (int)M, K, os, epi);
+                     value_bias, value, (int)M, K, os, epi);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -624,13 +624,15 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
                             int K, int N, int relu, int nplanes, void* stream, OutSplit os);
 
 int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
-                                 long long table_rows, const float* ref, const int* levels_hw, float* value,
-                                 float* samp, long long M, int K, void* stream) {
+                                 long long table_rows, const float* value_bias, const float* ref,
+                                 const int* levels_hw, float* value, float* samp, long long M, int K,
+                                 void* stream) {
   if (!a || !w_planes || !table || !ref || !levels_hw || !value || !samp)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: null pointer");
   if (M <= 0 || M >= (1ll << 31) || table_rows <= 0 || table_rows >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: bad sizes (0 < M, table_rows < 2^31)");
-  return pave_internal_gemm_encproj(a, w_planes, table, table_rows, ref, levels_hw, value, samp, M, K, stream);
+  return pave_internal_gemm_encproj(a, w_planes, table, table_rows, value_bias, ref, levels_hw, value, samp, M, K,
+                                    stream);
 }
 
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,

@@ -16,8 +16,8 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
                             const float* gamma, const float* beta, float eps, float* out, long long M,
                             int K, int N, void* stream);
 int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float* table, long long table_rows,
-                               const float* ref, const int* levels_hw, float* value, float* samp,
-                               long long M, int K, void* stream);
+                               const float* value_bias, const float* ref, const int* levels_hw, float* value,
+                               float* samp, long long M, int K, void* stream);
 /* Kernel-form override for A/B runs and the form-equality tests.  Only the -DPAVE_DIAG build
    (lib/libpave_hip_diag.so, loaded by tests/ and tools/ through native.diag_build()) has the
    process-global and its setter pave_diag_gemm_variant(); in the shipped library the form

@@ -227,7 +227,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             # the sampler's softmax / location arithmetic runs in this GEMM's epilogue (its waves are
             # ~25 % VALU-active, the sampler is VALU-bound): same code, same bits (pave_enc_math.h)
             v, samp = ops.gemm_bf16x3_encproj(q.reshape(bs * S, C), _split_weight(w_all), table, ref,
-                                              tile_levels)
+                                              tile_levels, value_bias=self.value_proj.bias.detach())
             out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), samp, None,
                                            levels_hw=tile_levels, window_shift=self._tile_shift(),
                                            prepared=True)

@@ -415,12 +415,13 @@ def enc_tile_window_shift(offset_bias):
     return tuple(int(v) for v in m.flatten().tolist())
 
 
-def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw):
+def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None):
     """The encoder layer's merged N = 640 projection with the sampler's softmax / location
     arithmetic in the GEMM epilogue (pave_gemm_bf16x3_encproj_f32): a [M, K], w_planes = 3-plane
     split of the [640, K] weight, table [rows, 640] (row m adds table[m % rows]), ref [M, 4, 2]
     -> (value [M, 256], samp [M, 384]): samp = level pixel coordinates + attention weights, the
-    `prepared=True` input of deform_attn_enc_tile."""
+    `prepared=True` input of deform_attn_enc_tile.  value_bias [256]: added to the value columns
+    instead of table[:, :256] (not read then: value_proj has no positional term)."""
     lib = native.load()
     for t, nm in ((a, 'a'), (table, 'table'), (ref, 'ref')):
         _dev(t, nm, torch.float32)
@@ -431,13 +432,18 @@ def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw):
     _require(table.dim() == 2 and table.shape[1] == 640 and ref.numel() == M * 8,
              'gemm_bf16x3_encproj: table [rows, 640], ref [M, 4, 2]')
     _require(len(levels_hw) == 4, 'gemm_bf16x3_encproj: four (h, w) levels')
+    if value_bias is not None:
+        _dev(value_bias, 'value_bias', torch.float32)
+        _require(value_bias.numel() == 256 and value_bias.is_contiguous(), 'gemm_bf16x3_encproj: value_bias [256]')
     import ctypes
     hw_arr = (ctypes.c_int * 8)(*[int(v) for hw in levels_hw for v in hw])
     value = torch.empty((M, 256), dtype=torch.float32, device=a.device)
     samp = torch.empty((M, 384), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * 640, (M, K, 640, 'encproj')):
         st = lib.pave_gemm_bf16x3_encproj_f32(a.data_ptr(), w_planes.data_ptr(), table.data_ptr(),
-                                              table.shape[0], ref.data_ptr(),
+                                              table.shape[0],
+                                              value_bias.data_ptr() if value_bias is not None else None,
+                                              ref.data_ptr(),
                                               ctypes.cast(hw_arr, ctypes.c_void_p), value.data_ptr(),
                                               samp.data_ptr(), M, K, _stream_ptr())
     native.check(st, 'gemm_bf16x3_encproj')

@@ -1526,6 +1526,14 @@ def test_encoder_projection_epilogue_equals_sampler_side_arithmetic(levels, F, s
     # the prepared matrix is what it says: softmax weights sum to one per (row, head)
     wsum = samp[:, 256:].view(M, 8, 16).sum(-1)
     np.testing.assert_allclose(wsum.cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+    # value_bias: the value columns take one bias row and the table's first 256 columns are not read
+    vb = torch.randn(256, device='cuda', generator=g)
+    tb = table.clone()
+    tb[:, :256] = vb
+    v2, samp2 = ops.gemm_bf16x3_encproj(a, wp, tb, ref, levels)
+    tb[:, :256] = float('nan')
+    v3, samp3 = ops.gemm_bf16x3_encproj(a, wp, tb, ref, levels, value_bias=vb)
+    assert torch.equal(v2, v3) and torch.equal(samp2, samp3) and torch.equal(samp2, samp)
 
 
 @pytest.mark.parametrize('N,H,W', [(2, 33, 47), (1, 64, 96), (3, 7, 5)])
@@ -1673,4 +1681,4 @@ def test_neck_1x1_level_with_96_channels_runs_the_split_gemm():
         bricks.set_gemm_mode(old)
     assert y is not None, 'the K = 96 level fell back to the library'
     exp = torch.nn.functional.conv2d(x.double(), conv.weight.double())
-    np.testing.assert_allclose(y.cpu().numpy(), exp.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), exp.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
