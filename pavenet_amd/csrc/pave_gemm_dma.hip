@@ -616,18 +616,34 @@ __device__ __forceinline__ void gemm_q_body(
       const __amdgpu_buffer_rsrc_t idr = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(residual ? residual : out), 0, residual ? (int)((unsigned)M * (unsigned)(BN * 4)) : 0,
           0x00020000);
-      const int id_voff = ((wm * 32 + 4 * kh) * BN + lr) * 4;
+      // three tiles of identity values in flight (48 registers), not more: the lane offset is made to
+      // depend on the tile added last, so the compiler cannot hoist every tile's loads to the front
+      // (it did: 128 more live registers, spills once anything else of the epilogue needed one)
+#ifndef PAVE_IDD
+#define PAVE_IDD 3
+#endif
+      constexpr int IDD = PAVE_IDD;
+      float idv[IDD][16];
+      int id_voff = ((wm * 32 + 4 * kh) * BN + lr) * 4;
+      auto load_identity = [&](const int j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          // (the column tile rides the instruction's immediate offset: 16 scalar offsets serve all tiles)
+          idv[j % IDD][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              idr, id_voff + j * 128, (em0 + (r & 3) + 8 * (r >> 2)) * (BN * 4) + en0 * 4, 0));
+      };
+#pragma unroll
+      for (int j = 0; j < IDD - 1; ++j) load_identity(j);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const float bj = bias ? bias[en0 + j * 32 + lr] : 0.f;
-        float idv[16];
+        if (j + IDD - 1 < TN) load_identity(j + IDD - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          idv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-              idr, id_voff, (em0 + (r & 3) + 8 * (r >> 2)) * (BN * 4) + (en0 + j * 32) * 4, 0));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bj) + idv[r];
-        __builtin_amdgcn_sched_barrier(0);   // (one tile's 16 loads in flight at a time: registers)
+        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bj) + idv[j % IDD][r];
+        asm volatile("" : "+v"(id_voff) : "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]),
+                     "v"(acc[j][4]), "v"(acc[j][5]), "v"(acc[j][6]), "v"(acc[j][7]), "v"(acc[j][8]), "v"(acc[j][9]),
+                     "v"(acc[j][10]), "v"(acc[j][11]), "v"(acc[j][12]), "v"(acc[j][13]), "v"(acc[j][14]),
+                     "v"(acc[j][15]));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -684,9 +700,7 @@ __device__ __forceinline__ void gemm_q_body(
             float4 v = *reinterpret_cast<const float4*>(Cs + (ps * 8 + erow) * QCST + ec4 * 4);
             v.x = fmaf(v.x, g4.x, be4.x), v.y = fmaf(v.y, g4.y, be4.y);
             v.z = fmaf(v.z, g4.z, be4.z), v.w = fmaf(v.w, g4.w, be4.w);
-            // (flat stores here: with the buffer form this body, already at 256 registers, spilled 14)
-            const long long gm = (long long)em0 + wm * 32 + ps * 8 + erow;
-            if (gm < M) *reinterpret_cast<float4*>(obase + gm * ldo + ncol) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, oro[ps] + j * 128, 0, 0);
           }
         } else {
           // the tile's four passes side by side: the wave-uniform options (residual, ReLU) are ONE branch

@@ -1,0 +1,70 @@
+"""A/B of two builds of the C-ABI library in ONE process, interleaved, on the encoder layer's GEMM
+launches at the bench size: pavenet_amd/lib/libpave_hip.so against a second build with the same ABI
+(default lib/libpave_hip_prev.so: `git archive <commit> pavenet_amd/csrc include`, hipcc as
+build_native.py does, linked into that path).   python tools/lib_ab.py [other.so]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pavenet_amd import native, ops  # noqa: E402
+
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
+S = sum(h * w for h, w in LEVELS)
+
+
+def timed(fn, iters=8):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def main():
+    other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(native.LIB_PATH), 'libpave_hip_prev.so')
+    cur = native.load()
+    prev = native._open(other)
+    M = 28 * S
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(0)
+    a256 = torch.randn(M, 256, device=dev, generator=g)
+    a1024 = torch.randn(M, 1024, device=dev, generator=g)
+    idt = torch.randn(M, 256, device=dev, generator=g)
+    mk = lambda n, k: ops.split_weight_bf16x3(torch.randn(n, k, device=dev, generator=g) * 0.05)   # noqa: E731
+    w_out, w_ffn1, w_ffn2, w_enc, w_v = mk(256, 256), mk(1024, 256), mk(256, 1024), mk(640, 256), mk(512, 256)
+    b256, gam, bet = (torch.randn(256, device=dev, generator=g) for _ in range(3))
+    b1024 = torch.randn(1024, device=dev, generator=g)
+    table = torch.randn(S, 640, device=dev, generator=g) * 0.1
+    ref = torch.rand(M, 4, 2, device=dev, generator=g)
+    o1, o2 = idt.clone(), idt.clone()
+    cases = [
+        ('out_proj + identity + LayerNorm, K = 256, in place', lambda: ops.gemm_bf16x3_ln(a256, w_out, b256, o1, gam, bet, 1e-5, out=o1)),
+        ('FFN2 + identity + LayerNorm, K = 1024, in place', lambda: ops.gemm_bf16x3_ln(a1024, w_ffn2, b256, o2, gam, bet, 1e-5, out=o2)),
+        ('FFN1 256 -> 1024 + ReLU', lambda: ops.gemm_bf16x3(a256, w_ffn1, b1024, relu=True)),
+        ('merged projection N = 640 + sampler epilogue', lambda: ops.gemm_bf16x3_encproj(a256, w_enc, table, ref, LEVELS, value_bias=b256)),
+        ('value projections N = 512, two outputs', lambda: ops.gemm_bf16x3_ex(a256, w_v, None, None, n_split=256)),
+    ]
+    res = {(n, w): [] for n, _ in cases for w in ('this', 'other')}
+    for rnd in range(4):
+        for name, fn in cases:
+            for which, lib in (('this', cur), ('other', prev)):
+                native._lib = lib
+                try:
+                    t = timed(fn)
+                finally:
+                    native._lib = cur
+                if rnd:
+                    res[(name, which)].append(t)
+    for name, _ in cases:
+        a, b = sorted(res[(name, 'this')])[1], sorted(res[(name, 'other')])[1]
+        print(f'{name:58s} this {a:8.1f} us   other {b:8.1f} us   {100 * (a / b - 1):+5.1f} %')
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,13 @@ def main():
                 res['wide'].append(timed(fn))
         for k, v in res.items():
             print(f'K={K:5d} {k:7s} ' + ' '.join(f'{x:8.1f}' for x in v) + f'   min {min(v):8.1f} us')
+        # the shipped build's own choice, out of place and in place (identity == out: the encoder layer's call)
+        r2 = r.clone()
+        inplace = lambda: ops.gemm_bf16x3_ln(a, wp, b, r2, g, be, 1e-5, out=r2)   # noqa: E731
+        t_out = [timed(fn) for _ in range(3)]
+        t_in = [timed(inplace) for _ in range(3)]
+        print(f'K={K:5d} shipped, out of place ' + ' '.join(f'{x:8.1f}' for x in t_out))
+        print(f'K={K:5d} shipped, in place     ' + ' '.join(f'{x:8.1f}' for x in t_in))
 
 
 if __name__ == '__main__':
