@@ -123,7 +123,7 @@ class ResNet(BaseModule):
         self.chain_stage64 = True
         # ... with the 3x3 as a launch of its own (three blocks per CU) and the chain from conv3 on
         # ('tail'), or the 3x3 as the chain's first phase ('full'); measured: see DESIGN.md 4.2
-        self.chain_mode = 'tail'
+        self.chain_mode = 'full'
         # 3x3 convolutions: MIOpen's searched fp32 kernels are 10-30 % faster than the
         # hand-written MFMA implicit GEMM (tools/bench_conv.py) but NOT run-to-run deterministic
         # (tools/debug_determinism.py); True routes them through pave_conv3x3_nhwc_f32

@@ -1,6 +1,7 @@
 """A/B of one model switch on the bench workload inside ONE process (boxes of the pool differ by
 ~2 %): alternates the two settings, 3 rounds of N steps each.
-python tools/ab_switch.py <attr path under model, e.g. bbox_head.transformer.overlap_value_proj> [steps=10]"""
+python tools/ab_switch.py <attr path under model, e.g. bbox_head.transformer.overlap_value_proj> [steps=10] [value A] [value B]
+(values default to True / False; given, they are strings: backbone.chain_mode 10 tail full)"""
 import os
 import sys
 import time
@@ -31,17 +32,18 @@ def run(n):
             r['kpts'].cpu()
 
 
-for v in (True, False):
+VALUES = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else (True, False)
+for v in VALUES:
     setattr(obj, path[-1], v)
     run(3)
-res = {True: [], False: []}
+res = {v: [] for v in VALUES}
 for rnd in range(3):
-    for v in (True, False):
+    for v in VALUES:
         setattr(obj, path[-1], v)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(steps)
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / steps * 1e3)
-for v in (True, False):
+for v in VALUES:
     print(f'{sys.argv[1]} = {v}: ' + ', '.join(f'{t:.2f}' for t in res[v]) + ' ms/step')
