@@ -50,6 +50,14 @@ def main():
         ('merged projection N = 640 + sampler epilogue', lambda: ops.gemm_bf16x3_encproj(a256, w_enc, table, ref, LEVELS, value_bias=b256)),
         ('value projections N = 512, two outputs', lambda: ops.gemm_bf16x3_ex(a256, w_v, None, None, n_split=256)),
     ]
+    # ResNet layer1 Bottleneck as one launch (3x3 -> conv3 + identity -> next conv1), in place on the identity
+    c1 = torch.randn(28, 200, 336, 64, device=dev, generator=g).relu_().permute(0, 3, 1, 2)
+    idm = torch.randn(28, 200, 336, 256, device=dev, generator=g).relu_().permute(0, 3, 1, 2)
+    w2 = ops.split_conv3x3_weight(torch.randn(64, 64, 3, 3, device=dev, generator=g) * 0.05)
+    w3, w1n = mk(256, 64), mk(64, 256)
+    b64, b64n = (torch.randn(64, device=dev, generator=g) for _ in range(2))
+    cases.append(('layer1 Bottleneck chain (3x3 | conv3 + identity | next conv1)',
+                  lambda: ops.bottleneck_chain(c1, w2, b64, w3, b256, residual=idm, w1n_planes=w1n, b1n=b64n, out=idm)))
     res = {(n, w): [] for n, _ in cases for w in ('this', 'other')}
     for rnd in range(4):
         for name, fn in cases:
