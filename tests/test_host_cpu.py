@@ -47,6 +47,31 @@ def test_shipped_library_has_no_diagnostic_switches():
     assert native.load() is not dlib
 
 
+def test_no_buffer_store_carries_a_register_scalar_offset(tmp_path):
+    """A 16-byte `buffer_store` whose scalar offset is a REGISTER gets no wait state from the compiler
+    in front of a VALU write of its data registers, and on gfx950 such stores wrote the NEXT
+    instruction's value into part of the wave (tools/debug_encproj.py): every buffer store
+    of the GEMM translation unit must carry the literal scalar offset 0 (column tiles ride the
+    immediate offset).  Checked on the ISA the shipped flags produce."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = tmp_path / 'gemm.s'
+    subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '--cuda-device-only', '-S',
+                    '-I' + os.path.join(root, 'include'), '-I' + os.path.join(root, 'pavenet_amd', 'csrc'),
+                    '-o', str(asm), os.path.join(root, 'pavenet_amd', 'csrc', 'pave_gemm_dma.hip')],
+                   check=True, capture_output=True)
+    stores = re.findall(r'^\s*buffer_store_dword\w*\s+(.*)$', asm.read_text(), flags=re.M)
+    assert len(stores) > 100, 'the epilogue stores are buffer stores'
+    for ops_ in stores:
+        fields = [f.strip() for f in ops_.split(',')]
+        # vdata, vaddr, srsrc, soffset [modifiers]
+        assert fields[3].split()[0] == '0', ops_
+
+
 def test_pybind_ext_module_surface():
     """pavenet_amd._ext (csrc/pave_mmcv_ext.cpp) builds against the installed torch headers, loads
     on a CPU-only host and exposes the two entry points of mmcv._ext with the keyword names of
