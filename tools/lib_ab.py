@@ -58,6 +58,23 @@ def main():
     b64, b64n = (torch.randn(64, device=dev, generator=g) for _ in range(2))
     cases.append(('layer1 Bottleneck chain (3x3 | conv3 + identity | next conv1)',
                   lambda: ops.bottleneck_chain(c1, w2, b64, w3, b256, residual=idm, w1n_planes=w1n, b1n=b64n, out=idm)))
+    # the decoders' small Linears: 50 dependent launches each (1 200 rows), cold weights every launch
+    xs = torch.randn(1200, 256, device=dev, generator=g)
+    x4 = torch.randn(1200, 1024, device=dev, generator=g)
+    wsm = [mk(256, 256) for _ in range(50)]
+    wsl = [mk(256, 1024) for _ in range(50)]
+
+    def chain_small():
+        y = xs
+        for w_ in wsm:
+            y = ops.gemm_bf16x3(y, w_)
+        return y
+
+    def chain_small_k1024():
+        for w_ in wsl:
+            ops.gemm_bf16x3(x4, w_)
+    cases.append(('50 dependent small launches 1200 x 256 x 256 (us per 50)', chain_small))
+    cases.append(('50 small launches 1200 x 1024 x 256 (us per 50)', chain_small_k1024))
     res = {(n, w): [] for n, _ in cases for w in ('this', 'other')}
     for rnd in range(4):
         for name, fn in cases:
