@@ -73,6 +73,20 @@ def main():
     def chain_small_k1024():
         for w_ in wsl:
             ops.gemm_bf16x3(x4, w_)
+    gsm, bsm = torch.randn(256, device=dev, generator=g), torch.randn(256, device=dev, generator=g)
+    rsm = torch.randn(1200, 256, device=dev, generator=g)
+
+    def chain_small_ln():
+        y = xs
+        for w_ in wsm:
+            y = ops.gemm_bf16x3_ln(y, w_, b256, rsm, gsm, bsm, 1e-5)
+        return y
+
+    def chain_small_ln_k1024():
+        for w_ in wsl:
+            ops.gemm_bf16x3_ln(x4, w_, b256, rsm, gsm, bsm, 1e-5)
+    cases.append(('50 dependent small Linear + LayerNorm 1200 x 256 x 256 (us per 50)', chain_small_ln))
+    cases.append(('50 small Linear + LayerNorm 1200 x 1024 x 256 (us per 50)', chain_small_ln_k1024))
     cases.append(('50 dependent small launches 1200 x 256 x 256 (us per 50)', chain_small))
     cases.append(('50 small launches 1200 x 1024 x 256 (us per 50)', chain_small_k1024))
     res = {(n, w): [] for n, _ in cases for w in ('this', 'other')}
