@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---------------------------------------------------------------------------
 // ResNet / HRNet stem: 7x7 / stride 2 / pad 3 convolution of the NCHW image batch, 3 -> 64
 // channels, NHWC output (third_party/mmdetection/mmdet/models/backbones/resnet.py:607-611 conv1).
-// Block = 3 waves = 96 output pixels of ONE output row; the 21 input rows (3 channels x 7) of its
+// Block = 3 waves = 96 output pixels of R output rows; the 3 x (2 R + 5) input rows of its
 // window are copied ONCE into LDS by LDS-DMA (aligned 16-byte chunks, coalesced; chunks outside
 // the image come from a zero chunk = the zero padding) and every wave builds its MFMA A operands
 // from there: K axis = (c, ky, kx' = 0..7) where kx' = kx + 1 is the tap shifted by one so that
@@ -1021,11 +1021,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---------------------------------------------------------------------------
 constexpr int SBM = 96;                 // output pixels per block
 constexpr int SWC = 50;                 // window chunks (16 B) per row: 2 * 95 + 8 = 198 floats -> 200
-constexpr int SROWS = 22;               // 21 window rows + one zero row
 constexpr int SNSLAB = 11;
-constexpr int SWIN = ((SROWS * SWC + 63) / 64) * 1024;   // window bytes, whole DMA instructions
 
-__global__ __launch_bounds__(192) void stem7x7_q_kernel(
+// R output rows per block (rows R b .. R b + R - 1): a wave's 32 pixels of every row share each W fragment
+// -- 12 R MFMAs per fetched slab of weight planes, 1 / R of the L2 traffic for them (with one row per block
+// 78 400 blocks read the 67 KB of planes once each: ~14 TB/s of L2 reads) -- and the rows' windows overlap
+// (2 R + 5 window rows per channel instead of 7 R).  K row (c, ky) of output row r sits at window row
+// (2 R + 5) c + ky + 2 r; the products of an accumulator keep their order whatever R is: R = 1, 2, 3, 4 are
+// bit-identical.  Measured (28 x 800 x 1344, tools/lib_ab.py): R = 1 1 139 us, R = 2 969, R = 3 1 073,
+// R = 4 1 036 (228 registers: two waves per SIMD) -- R = 2 (136 registers, 22 KB of LDS) is the launcher's.
+template <int R>
+struct StemRows {
+  static constexpr int WPC = 2 * R + 5;           // window rows per channel
+  static constexpr int ROWS = 3 * WPC + 1;        // + one zero row
+  static constexpr int WIN = ((ROWS * SWC + 63) / 64) * 1024;
+};
+
+template <int R>
+__global__ __launch_bounds__(192) void stem7x7_qr_kernel(
     const float* __restrict__ x, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, const int H, const int W, const int Ho, const int Wo, const int relu) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1033,31 +1046,32 @@ __global__ __launch_bounds__(192) void stem7x7_q_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, kh = lane >> 5;
   const int segs = (Wo + SBM - 1) / SBM;
+  constexpr int WPC = StemRows<R>::WPC, ZROW = 3 * WPC;
+  const int Hp = (Ho + R - 1) / R;      // row groups
   const int seg = blockIdx.x % segs;
-  const int oy = (blockIdx.x / segs) % Ho;
-  const int n = blockIdx.x / (segs * Ho);
+  const int oy = R * ((blockIdx.x / segs) % Hp);
+  const int n = blockIdx.x / (segs * Hp);
   const int ox0 = seg * SBM;
   const int xs = 2 * ox0 - 4;           // image column of window column 0 (a multiple of 4)
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  // ---- window -> LDS: chunk ci = (row, cc) at LDS byte 16 ci
-  constexpr int NCH = SROWS * SWC;
-  constexpr int NINS = SWIN / 1024;     // 18 instructions, 6 per wave
+  constexpr int NCH = StemRows<R>::ROWS * SWC;
+  constexpr int NINS = StemRows<R>::WIN / 1024;    // (R = 2: 22 instructions over 3 waves)
 #pragma unroll
-  for (int q = 0; q < NINS / 3; ++q) {
+  for (int q = 0; q < (NINS + 2) / 3; ++q) {
     const int ins = wave + 3 * q;
-    const int ci = ins * 64 + lane;
-    const int row = ci / SWC, cc = ci - row * SWC;
-    const int c = row / 7, ky = row - 7 * c;
-    const int iy = 2 * oy - 3 + ky, ix = xs + 4 * cc;
-    const bool ok = ci < NCH && row < 21 && iy >= 0 && iy < H && ix >= 0 && ix + 4 <= W;
-    const float* src = ok ? x + (((long long)n * 3 + c) * H + iy) * W + ix
-                          : reinterpret_cast<const float*>(g_zero_chunk);
-    dma16_flat(src, lds0 + ins * 1024);
+    if (ins < NINS) {
+      const int ci = ins * 64 + lane;
+      const int row = ci / SWC, cc = ci - row * SWC;
+      const int c = row / WPC, wy = row - WPC * c;
+      const int iy = 2 * oy - 3 + wy, ix = xs + 4 * cc;
+      const bool ok = ci < NCH && row < ZROW && iy >= 0 && iy < H && ix >= 0 && ix + 4 <= W;
+      const float* src = ok ? x + (((long long)n * 3 + c) * H + iy) * W + ix
+                            : reinterpret_cast<const float*>(g_zero_chunk);
+      dma16_flat(src, lds0 + ins * 1024);
+    }
   }
-  // ---- W fragments of slab 0 (ordinary loads: younger than the DMAs, so their arrival implies
-  // the window's), operand addresses
-  const uint16_t* wl = Wp + ((long long)lr * 16 + kh * 8);        // + ((slab * 3 + p) * 64 + 32 j) * 16
+  const uint16_t* wl = Wp + ((long long)lr * 16 + kh * 8);
   u32x4 wf[2][3][2];
   auto load_w = [&](const int slab, const int set) {
 #pragma unroll
@@ -1067,71 +1081,75 @@ __global__ __launch_bounds__(192) void stem7x7_q_kernel(
         wf[set][p][j] = *reinterpret_cast<const u32x4*>(wl + ((slab * 3 + p) * 64 + 32 * j) * 16);
   };
   load_w(0, 0);
-  const int a_rd = (wave * 32 + lr) * 8 + kh * (SWC * 16);        // + slab * 2 rows
-  f32x4 raw[2];
-  u32x4 apl[2][3];
-  auto read_a = [&](const int slab) {
-    const unsigned char* p = smem + a_rd + slab * (2 * SWC * 16);
+  const int a_px = (wave * 32 + lr) * 8;
+  u32x4 apl[R][3];
+  // A operand of output row r, slab s: K row 2 s + kh = (c, ky) -> window row WPC c + ky + 2 r (21 -> the zero row)
+  auto read_split = [&](const int slab, const int r) {
+    const int k0 = 2 * slab, k1 = 2 * slab + 1;
+    const int w0 = k0 >= 21 ? ZROW : WPC * (k0 / 7) + k0 % 7 + 2 * r;
+    const int w1 = k1 >= 21 ? ZROW : WPC * (k1 / 7) + k1 % 7 + 2 * r;
+    const unsigned char* p = smem + a_px + (kh ? w1 : w0) * (SWC * 16);
     const f32x2 v0 = *reinterpret_cast<const f32x2*>(p);
     const f32x2 v1 = *reinterpret_cast<const f32x2*>(p + 8);
     const f32x2 v2 = *reinterpret_cast<const f32x2*>(p + 16);
     const f32x2 v3 = *reinterpret_cast<const f32x2*>(p + 24);
-    raw[0] = f32x4{0.f, v0.y, v1.x, v1.y};   // tap kx' = 0 is outside the 7-wide kernel: zeroed
-    raw[1] = f32x4{v2.x, v2.y, v3.x, v3.y};
+    split8(f32x4{0.f, v0.y, v1.x, v1.y}, f32x4{v2.x, v2.y, v3.x, v3.y}, apl[r]);   // tap kx' = 0: zeroed
   };
-  f32x16 acc[2];
+  f32x16 acc[R][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][j][i] = 0.f;
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // the window has landed everywhere
-  read_a(0);
-  split8(raw[0], raw[1], apl[0]);
 #pragma unroll
   for (int s = 0; s < SNSLAB; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < SNSLAB) {
-      load_w(s + 1, nxt);
-      read_a(s + 1);
+    if (s + 1 < SNSLAB) load_w(s + 1, nxt);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      read_split(s, r);
+#pragma unroll
+      for (int o = 2; o >= 0; --o)
+#pragma unroll
+        for (int pa = 0; pa <= o; ++pa)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, apl[r][pa]), __builtin_bit_cast(bf16x8, wf[cur][o - pa][j]),
+                acc[r][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int o = 2; o >= 0; --o)
-#pragma unroll
-      for (int pa = 0; pa <= o; ++pa)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, apl[cur][pa]), __builtin_bit_cast(bf16x8, wf[cur][o - pa][j]),
-              acc[j], 0, 0, 0);
-    if (s + 1 < SNSLAB) split8(raw[0], raw[1], apl[nxt]);
   }
-  // ---- epilogue: per wave 32 pixels x 64 channels, one accumulator tile at a time through LDS
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the window
   float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * QCST;
   const int erow = lane >> 3, ec4 = lane & 7;
-  float* const orow = y + ((long long)n * Ho + oy) * Wo * 64;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = j * 32 + ec4 * 4;
-    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < R; ++r) {
+    float* const orow = y + ((long long)n * Ho + oy + r) * Wo * 64;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = 0; j < 2; ++j) {
+      const int col = j * 32 + ec4 * 4;
+      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int lrow = ps * 8 + erow;
-      const int ox = ox0 + wave * 32 + lrow;
-      float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
-      v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+      for (int i = 0; i < 16; ++i) Cs[((i & 3) + 8 * (i >> 2) + 4 * kh) * QCST + lr] = acc[r][j][i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int lrow = ps * 8 + erow;
+        const int ox = ox0 + wave * 32 + lrow;
+        float4 v = *reinterpret_cast<const float4*>(Cs + lrow * QCST + ec4 * 4);
+        v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        }
+        if (ox < Wo && oy + r < Ho) *reinterpret_cast<float4*>(orow + (long long)ox * 64 + col) = v;
       }
-      if (ox < Wo) *reinterpret_cast<float4*>(orow + (long long)ox * 64 + col) = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1600,7 +1618,12 @@ int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bia
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long gx = (long long)N * Ho * ((Wo + SBM - 1) / SBM);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "stem7x7: grid too large");
-  hipLaunchKernelGGL(stem7x7_q_kernel, dim3((unsigned)gx), dim3(192), SWIN,
+#ifndef PAVE_STEM_ROWS
+#define PAVE_STEM_ROWS 2
+#endif
+  constexpr int R = PAVE_STEM_ROWS;
+  const long long g2 = (long long)N * ((Ho + R - 1) / R) * ((Wo + SBM - 1) / SBM);
+  hipLaunchKernelGGL(stem7x7_qr_kernel<R>, dim3((unsigned)g2), dim3(192), StemRows<R>::WIN,
                      reinterpret_cast<hipStream_t>(stream), x, static_cast<const uint16_t*>(w_stem), bias,
                      y, H, W, Ho, Wo, relu);
   const hipError_t e = hipGetLastError();

@@ -58,6 +58,15 @@ def main():
     b64, b64n = (torch.randn(64, device=dev, generator=g) for _ in range(2))
     cases.append(('layer1 Bottleneck chain (3x3 | conv3 + identity | next conv1)',
                   lambda: ops.bottleneck_chain(c1, w2, b64, w3, b256, residual=idm, w1n_planes=w1n, b1n=b64n, out=idm)))
+    # ResNet stem: 7x7 / stride 2 on the 28-frame batch
+    img = torch.randn(28, 3, 800, 1344, device=dev, generator=g)
+    wst = ops.split_stem7x7_weight(torch.randn(64, 3, 7, 7, device=dev, generator=g) * 0.05)
+    cases.append(('stem 7x7 / 2, 28 x 800 x 1344', lambda: ops.conv7x7s2_nchw_split(img, wst, b64, relu=True)))
+    native._lib = prev
+    y_other = ops.conv7x7s2_nchw_split(img, wst, b64, relu=True)
+    native._lib = cur
+    print('stem: same bits in both builds:', torch.equal(y_other, ops.conv7x7s2_nchw_split(img, wst, b64, relu=True)))
+    del y_other
     # the decoders' small Linears: 50 dependent launches each (1 200 rows), cold weights every launch
     xs = torch.randn(1200, 256, device=dev, generator=g)
     x4 = torch.randn(1200, 1024, device=dev, generator=g)
