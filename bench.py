@@ -518,7 +518,7 @@ def main():
             d[2] += fl
         roofline_mfma = dict(
             bound='mfma',
-            kernel='gemm_q / gemm_w / gemm_wn(_enc) / gemm_w_ln / gemm_q_ln / bottleneck_chain / stem7x7_q '
+            kernel='gemm_q / gemm_w / gemm_wn(_enc) / gemm_w_ln / gemm_q_ln / bottleneck_chain / stem7x7_qr '
                    'kernels (pave_gemm_dma.hip, the LDS-DMA split GEMM): every Linear / FFN / 1x1, 3x3, 7x7 '
                    'convolution launch of the step with >= 8192 rows (the decoders\' few-hundred-row '
                    'launches of the same kernels: small_row_launches)' if args.gemm == 'bf16x3' else
