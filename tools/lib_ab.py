@@ -67,6 +67,14 @@ def main():
     native._lib = cur
     print('stem: same bits in both builds:', torch.equal(y_other, ops.conv7x7s2_nchw_split(img, wst, b64, relu=True)))
     del y_other
+    # HRNet stem conv1: 3x3 / stride 2, 3 -> 64 channels
+    taps = torch.randn(27, 64, device=dev, generator=g) * 0.1
+    cases.append(('HRNet stem conv1 3x3 / 2, 28 x 800 x 1344', lambda: ops.conv3x3s2_c3_nchw(img, taps, b64, relu=True)))
+    native._lib = prev
+    y_other = ops.conv3x3s2_c3_nchw(img, taps, b64, relu=True)
+    native._lib = cur
+    print('HRNet stem conv1: same bits in both builds:', torch.equal(y_other, ops.conv3x3s2_c3_nchw(img, taps, b64, relu=True)))
+    del y_other
     # the decoders' small Linears: 50 dependent launches each (1 200 rows), cold weights every launch
     xs = torch.randn(1200, 256, device=dev, generator=g)
     x4 = torch.randn(1200, 1024, device=dev, generator=g)
