@@ -19,7 +19,8 @@ SOURCES = [os.path.join(_HERE, 'csrc', 'pave_kernels.hip'),
            os.path.join(_HERE, 'csrc', 'pave_enc_tile.hip'),
            os.path.join(_HERE, 'csrc', 'pave_gemm_dma.hip'),
            os.path.join(_HERE, 'csrc', 'pave_decoder.hip')]
-HEADERS = [os.path.join(_HERE, 'csrc', 'pave_internal.h'), os.path.join(ROOT, 'include', 'pave_hip.h')]
+HEADERS = sorted(os.path.join(_HERE, 'csrc', f) for f in os.listdir(os.path.join(_HERE, 'csrc')) if f.endswith('.h')) + \
+          [os.path.join(ROOT, 'include', 'pave_hip.h')]
 OUT = os.path.join(_HERE, 'lib', 'libpave_hip.so')
 OUT_DIAG = os.path.join(_HERE, 'lib', 'libpave_hip_diag.so')
 EXT_SOURCE = os.path.join(_HERE, 'csrc', 'pave_mmcv_ext.cpp')

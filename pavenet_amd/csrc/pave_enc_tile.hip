@@ -425,8 +425,13 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
                            const int* window_shift, void* stream) {
   // variant bit 2 (value 4): `proj` is PREPARED (pave_gemm_bf16x3_encproj_f32): attention weights and
   // level pixel coordinates instead of logits and offsets; ref is not read
+  // every unsupported combination is refused HERE, before anything is enqueued
+  if (variant < 0 || (variant & ~7) != 0)
+    return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: variant is a 3-bit mask (1 = wide windows, 4 = prepared input)");
   const bool prepared = (variant & 4) != 0;
   variant &= 3;
+  if (prepared && variant != 0)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "enc_deform_attn_tile: prepared input with the default windows only");
   if (!value || !proj || (!ref && !prepared) || !out || !levels_hw)
     return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: null pointer");
   if (n_frames <= 0 || S <= 0) return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: sizes must be positive");
@@ -489,8 +494,6 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
     else
       hipLaunchKernelGGL((enc_tile_kernel<14, 10, 8, 7, 3, 3, 3, 3, 5, ABL>), dim3((unsigned)nb), dim3(384), 0, st, p);
   }
-  if (prepared && variant != 0)
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "enc_deform_attn_tile: prepared input with the default windows only");
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

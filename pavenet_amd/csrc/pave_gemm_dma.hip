@@ -173,7 +173,12 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 //   1 = the columns are sampling offsets [head][level][point][x, y] of the encoder's deformable
 //       attention: stored as level pixel coordinates (ref + off / size) * size - 0.5;
 //   2 = the columns are attention logits [head][16]: stored as their softmax over each 16
-template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0>
+// RM (narrow form, WN = 1): row tiles per wave.  RM = 2: the block is 256 rows, wave wm owns rows
+// [64 wm, 64 wm + 64) = two 32-row tiles that share every W fragment -- 12 TN MFMAs per slab behind the same
+// wait, barrier and W fragment reads as the 6 TN of RM = 1 (the 64-column-tile forms, TN = 2, are bound by
+// that per-slab overhead, not by the matrix pipe).  Per accumulator the products keep their order:
+// bit-identical to RM = 1.
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -183,7 +188,9 @@ __device__ __forceinline__ void gemm_q_body(
   // (tile_m0 >= 0: the caller names the tile -- kernels that run several bodies per block)
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
-  constexpr int A_STAGE = QBM * 64;          // raw fp32: 128 rows x 64 B
+  constexpr int BM = QBM * RM;               // rows per block
+  constexpr int A_STAGE = BM * 64;           // raw fp32: BM rows x 64 B
+  static_assert(RM == 1 || (RM == 2 && WN == 1 && !WIDE && !LNORM && EPI == 0), "two row tiles per wave: narrow form");
   constexpr int W_STAGE = 3 * BN * 32;       // 3 planes x BN rows x 32 B
   constexpr int STAGE = A_STAGE + W_STAGE;
   constexpr int NA = A_STAGE / 1024;         // DMA instructions per slab: A (8)
@@ -208,7 +215,7 @@ __device__ __forceinline__ void gemm_q_body(
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, kh = lane >> 5;
   const int ntiles = N / BN;
-  const int ttot = ((M + QBM - 1) / QBM) * ntiles;
+  const int ttot = ((M + BM - 1) / BM) * ntiles;
   // XCD-aware bijective tile order (the hardware deals blocks round-robin over the 8 XCDs; each
   // XCD gets a contiguous run of logical tiles, column tile fastest, so the column tiles of one
   // row tile run side by side on ONE XCD and its A rows cross HBM -> L2 once)
@@ -244,7 +251,7 @@ __device__ __forceinline__ void gemm_q_body(
   auto setup_tile = [&](const int t) {
     const int xcd = t & 7, idx = t >> 3;
     const int lb = xcd * per + (xcd < rem ? xcd : rem) + idx;
-    m0 = (lb / ntiles) * QBM;
+    m0 = (lb / ntiles) * BM;
     n0 = (lb % ntiles) * BN;
     if (tile_m0 >= 0) m0 = tile_m0, n0 = tile_n0;
 #pragma unroll
@@ -342,20 +349,23 @@ __device__ __forceinline__ void gemm_q_body(
 
   // ---- operand fragment addresses (bytes inside a stage)
   const int sw = (lr >> 2) & 3;
-  const int a_rd0 = (wm * 32 + lr) * 64 + (((2 * kh) ^ sw) * 16);
+  const int a_rd0 = (wm * 32 * RM + lr) * 64 + (((2 * kh) ^ sw) * 16);   // (+ 2 KiB per further row tile)
   const int a_rd1 = a_rd0 ^ 16;
   const int w_rd = A_STAGE + (wn * TN * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);
 
-  f32x16 acc[TN];
-  f32x4 raw[2];            // the lane's 8 fp32 of the next slab
-  u32x4 apl[2][3];         // A planes: [set][plane]
+  f32x16 acc[RM * TN];     // [row tile][column tile]
+  f32x4 raw[RM][2];        // the lane's 8 fp32 of the next slab, per row tile
+  u32x4 apl[2][RM][3];     // A planes: [set][row tile][plane]
   u32x4 wf[2][3][TQ];      // W fragments: [set][plane][column tile (of the quarter, WIDE)]
   const float* const ab_lds = reinterpret_cast<const float*>(smem + ABOFF);
 
   auto read_raw = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE;
-    raw[0] = *reinterpret_cast<const f32x4*>(st + a_rd0);
-    raw[1] = *reinterpret_cast<const f32x4*>(st + a_rd1);
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+      raw[rt][0] = *reinterpret_cast<const f32x4*>(st + a_rd0 + rt * 2048);
+      raw[rt][1] = *reinterpret_cast<const f32x4*>(st + a_rd1 + rt * 2048);
+    }
   };
   // column tiles [TQ quarter, TQ quarter + TQ) of the stage's W planes
   auto read_wq = [&](const int stage, const int quarter, const int set) {
@@ -372,7 +382,9 @@ __device__ __forceinline__ void gemm_q_body(
     read_wq(stage, 0, set);
   };
   auto split_raw = [&](const int slab, const int set) {
-    f32x4 lo = raw[0], hi = raw[1];
+#pragma unroll
+   for (int rt = 0; rt < RM; ++rt) {
+    f32x4 lo = raw[rt][0], hi = raw[rt][1];
     if (ABIAS) {   // A' = relu(A + a_bias[k]) (the previous BatchNorm + ReLU), a_bias staged in LDS
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(ab_lds + slab * 16 + kh * 8);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(ab_lds + slab * 16 + kh * 8 + 4);
@@ -382,18 +394,21 @@ __device__ __forceinline__ void gemm_q_body(
         hi[i] = fmaxf(hi[i] + b1[i], 0.f);
       }
     }
-    split8(lo, hi, apl[set]);
+    split8(lo, hi, apl[set][rt]);
+   }
   };
   // the products of order o = pa + pb (o = 2, 1, 0: smallest terms first), column tiles innermost
   auto mma = [&](const int set, const int o) {
 #pragma unroll
     for (int pa = 0; pa <= o; ++pa)
 #pragma unroll
-      for (int j = 0; j < TQ; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, apl[set][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
-            acc[j], 0, 0, 0);
-      }
+      for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          acc[rt * TN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, apl[set][rt][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
+              acc[rt * TN + j], 0, 0, 0);
+        }
   };
   // WIDE: all six products of one quarter (A planes of set aset, W fragments of set wset)
   auto mma_q = [&](const int aset, const int wset, const int quarter) {
@@ -404,7 +419,7 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
           acc[quarter * TQ + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, apl[aset][pa]),
+              __builtin_bit_cast(bf16x8, apl[aset][0][pa]),
               __builtin_bit_cast(bf16x8, wf[wset][o - pa][j]), acc[quarter * TQ + j], 0, 0, 0);
         }
   };
@@ -412,7 +427,9 @@ __device__ __forceinline__ void gemm_q_body(
   // ---- epilogue state
   constexpr int NPS = 4;                 // passes per accumulator tile: 8 rows x 8 float4 each
   const int erow = lane >> 3, ec4 = lane & 7;
-  constexpr int RB = WIDE ? 4 : TN;      // residual tiles in registers (WIDE: four, rotating)
+  constexpr int NPR = NPS * RM;          // 8-row passes over the wave's rows
+  constexpr int NT = RM * TN;            // accumulator tiles of the wave: t = row tile * TN + column tile
+  constexpr int RB = WIDE ? 4 : TN;      // residual tiles in registers (WIDE, RM > 1: rotating)
   float4 resv[RB][NPS];
   // Every global access of the epilogue goes through a buffer resource over THIS TILE's rows (output,
   // full residual) or over the whole row-periodic table: one 32-bit lane offset per pass, the column
@@ -421,21 +438,21 @@ __device__ __forceinline__ void gemm_q_body(
   // no predication around it.
   constexpr unsigned kOut = 0x80000000u;
   using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
-  unsigned rro[NPS];                     // residual byte offset of the lane's row per pass (+ its 16-byte column)
+  unsigned rro[NPR];                     // residual byte offset of the lane's row per pass (+ its 16-byte column)
   __amdgpu_buffer_rsrc_t rrs;
   auto residual_rows = [&](const int em0) {
     // row-periodic table (row m adds residual[m % res_rows]): one modulo per lane, the passes
     // step the row by 8 with a wrap (res_rows >= 32: at most one wrap per step)
     const bool table = os.res_rows != 0;
-    const int rows_left = min(QBM, M - em0);
+    const int rows_left = min(BM, M - em0);
     rrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(residual) + (table ? 0ll : (long long)em0 * os.n_real), 0,
         (table ? os.res_rows : rows_left) * os.n_real * 4, 0x00020000);
-    const int lrow0 = wm * 32 + erow;
-    const bool stepwise = os.res_rows >= 32;
+    const int lrow0 = wm * 32 * RM + erow;
+    const bool stepwise = os.res_rows >= 32 * RM;
     const unsigned rbase = table ? (unsigned)(em0 + lrow0) % (unsigned)os.res_rows : 0u;
 #pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
+    for (int ps = 0; ps < NPR; ++ps) {
       unsigned rr = (unsigned)(lrow0 + ps * 8);
       if (table) {
         if (stepwise) {
@@ -448,13 +465,14 @@ __device__ __forceinline__ void gemm_q_body(
       rro[ps] = lrow0 + ps * 8 < rows_left ? rr * (unsigned)(os.n_real * 4) + ec4 * 16 : kOut;
     }
   };
-  auto prefetch_residual_tile = [&](const int en0, const int j, const int buf) {
+  auto prefetch_residual_tile = [&](const int en0, const int t, const int buf) {
+    const int rt = t / TN, j = t % TN;
     const int ncol0 = en0 + wn * TN * 32 + j * 32;   // wave-uniform
     const bool colok = WIDE || ncol0 + ec4 * 4 < os.n_real;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps)
       resv[buf][ps] = __builtin_bit_cast(
-          float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, colok ? rro[ps] : kOut, ncol0 * 4, 0));
+          float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, colok ? rro[rt * NPS + ps] : kOut, ncol0 * 4, 0));
   };
   auto prefetch_residual = [&](const int em0, const int en0) {
     if (!residual) return;
@@ -476,7 +494,7 @@ __device__ __forceinline__ void gemm_q_body(
       issue(1, 1);
       issue(2, 2);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       PAVE_QWAIT(2 * QMIN);                  // slab 0 has landed everywhere
@@ -588,16 +606,16 @@ __device__ __forceinline__ void gemm_q_body(
     // stays 0: with a REGISTER there the compiler does not put the wait state between a 16-byte store and a
     // VALU write of its data registers (GCNHazardRecognizer: "no hazard with an SGPR offset"), and on gfx950
     // rows stored that way came out with the next instruction's value in them (tools/debug_encproj.py).
-    const int orows = min(QBM, M - em0);
+    const int orows = min(BM, M - em0);
     const int ocol0 = en0 + wn * TN * 32 - csh;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
         obase + (long long)em0 * ldo + ocol0, 0, (orows * ldo - ocol0) * 4, 0x00020000);
-    unsigned oro[NPS];
+    unsigned oro[NPR];
     int late = 0;   // an opaque zero made HERE: the lane offsets below are not computed ahead of the main
     asm volatile("" : "+v"(late));   // loop (where every register is taken)
 #pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      const int lrow = wm * 32 + ps * 8 + erow + late;
+    for (int ps = 0; ps < NPR; ++ps) {
+      const int lrow = wm * 32 * RM + ps * 8 + erow + late;
       oro[ps] = lrow < orows ? (unsigned)(lrow * ldo * 4 + ec4 * 16) : kOut;
     }
     constexpr bool LNW = LNORM && WIDE;   // LayerNorm computed on the accumulator layout (below)
@@ -676,7 +694,8 @@ __device__ __forceinline__ void gemm_q_body(
         }
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+      for (int t = 0; t < NT; ++t) {
+        const int rt = t / TN, j = t % TN;
         const int ncol0 = en0 + wn * TN * 32 + j * 32;   // wave-uniform
         const int ncol = ncol0 + ec4 * 4;
         const bool colok = WIDE || ncol < os.n_real;   // (wide form: N == n_real, the launcher's condition)
@@ -689,7 +708,7 @@ __device__ __forceinline__ void gemm_q_body(
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[j][r];
+          Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[t][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -716,7 +735,7 @@ __device__ __forceinline__ void gemm_q_body(
             asm volatile("" ::);
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
-              const float4 rv = resv[j % RB][ps];
+              const float4 rv = resv[t % RB][ps];
               v[ps].x += rv.x, v[ps].y += rv.y, v[ps].z += rv.z, v[ps].w += rv.w;
             }
           }
@@ -741,10 +760,10 @@ __device__ __forceinline__ void gemm_q_body(
               v[ps].x = e[0] * inv, v[ps].y = e[1] * inv, v[ps].z = e[2] * inv, v[ps].w = e[3] * inv;
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ps]), ors,
-                                                   (colok ? oro[ps] : kOut) + j * 128, 0, 0);
+                                                   (colok ? oro[rt * NPS + ps] : kOut) + j * 128, 0, 0);
           }
         }
-        if (WIDE && !LNW && residual && j + RB < TN) prefetch_residual_tile(en0, j + RB, j % RB);
+        if ((WIDE || RM > 1) && !LNW && residual && t + RB < NT) prefetch_residual_tile(en0, t + RB, t % RB);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -854,13 +873,14 @@ __device__ __forceinline__ void gemm_q_body(
 
 // (64-column tiles, TN = 2: 136 VGPRs and 42 KB of LDS -- three blocks per CU; these launches are
 // issue-bound, not MFMA-bound, and take the extra wave per SIMD)
-template <int TN, int KIND, bool ABIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2))) void gemm_q_kernel(
+// (RM = 2: 256-row blocks, a wave owns two row tiles; ~200 VGPRs and 66 KB of LDS -- two blocks per CU)
+template <int TN, int KIND, bool ABIAS, int RM = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 && RM == 1) ? 3 : 2, (TN == 2 && RM == 1) ? 3 : 2))) void gemm_q_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const float* __restrict__ A2) {
-  gemm_q_body<TN, 1, KIND, ABIAS, false>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
-                                         QLn{nullptr, nullptr, 0.f}, A2);
+  gemm_q_body<TN, 1, KIND, ABIAS, false, false, 0, RM>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
+                                                       QLn{nullptr, nullptr, 0.f}, A2);
 }
 // the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
 template <int KIND>
@@ -951,29 +971,48 @@ __device__ __forceinline__ void chain_sync() {
 // HAS_A = false: the launch starts at conv3 (the 3x3 was a launch of its own: at three blocks per CU
 // the 64-column-tile 3x3 runs faster alone than as the first phase of a two-blocks-per-CU chain);
 // CN = outputs of the next conv1 (0: none; 64 | 128: narrow form)
-template <bool HAS_A, int KIND2, int CN>
+// RMC = 2: the workgroup carries a 256-row tile -- the 64-column bodies (3x3, a 64-output conv1) as ONE body
+// with two row tiles per wave, the 256- / 128-column bodies as two 128-row halves back to back
+template <bool HAS_A, int KIND2, int CN, int RMC = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_chain_kernel(
     const ChainArgs p) {
   const QLn ln0{nullptr, nullptr, 0.f};
   // the block's row tile (XCD-aware order over the row tiles), the same for every body
-  const int ttot = (p.M + QBM - 1) / QBM;
+  constexpr int CBM = QBM * RMC;
+  const int ttot = (p.M + CBM - 1) / CBM;
   const int per = ttot >> 3, rem = ttot & 7;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int tm0 = (xcd * per + (xcd < rem ? xcd : rem) + idx) * QBM;
+  const int tm0 = (xcd * per + (xcd < rem ? xcd : rem) + idx) * CBM;
   if constexpr (HAS_A) {
-    gemm_q_body<2, 1, 1, false, false>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
-                                       QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30},
-                                       QOut{nullptr, 0, 0, 64, 0}, ln0, nullptr, tm0, 0);
+    gemm_q_body<2, 1, 1, false, false, false, 0, RMC>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
+                                                      QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30},
+                                                      QOut{nullptr, 0, 0, 64, 0}, ln0, nullptr, tm0, 0);
     chain_sync();
   }
-  gemm_q_body<8, 1, KIND2, false, false, true>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
-                                               nullptr, QConv{0, 0, p.k1, 0, 0, 0},
-                                               QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2, tm0, 0);
+#pragma unroll
+  for (int h = 0; h < RMC; ++h) {
+    if (h > 0) PAVE_QBAR();   // (every wave is done with the previous half's epilogue chunks in the ring)
+    if (tm0 + h * QBM < p.M)
+      gemm_q_body<8, 1, KIND2, false, false, true>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
+                                                   nullptr, QConv{0, 0, p.k1, 0, 0, 0},
+                                                   QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2, tm0 + h * QBM, 0);
+  }
   if constexpr (CN > 0) {
     chain_sync();
-    gemm_q_body<(CN > 0 ? CN / 32 : 2), 1, 0, false, false>(
-        p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
-        QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0, 0);
+    if constexpr (CN == 64 && RMC == 2) {
+      gemm_q_body<2, 1, 0, false, false, false, 0, 2>(
+          p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
+          QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0, 0);
+    } else {
+#pragma unroll
+      for (int h = 0; h < RMC; ++h) {
+        if (h > 0) PAVE_QBAR();
+        if (tm0 + h * QBM < p.M)
+          gemm_q_body<(CN > 0 ? CN / 32 : 2), 1, 0, false, false>(
+              p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
+              QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0 + h * QBM, 0);
+      }
+    }
   }
 }
 
@@ -1153,16 +1192,17 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
   }
 }
 
-template <int TN, int KIND, bool ABIAS>
+template <int TN, int KIND, bool ABIAS, int RM = 1>
 int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
              const QOut os, const float* a2 = nullptr, int ksplit = 1) {
   constexpr int BN = TN * 32;
-  constexpr int STAGE = QBM * 64 + 3 * BN * 32;
+  constexpr int BM = QBM * RM;
+  constexpr int STAGE = BM * 64 + 3 * BN * 32;
   const int smem = QNS * STAGE + (ABIAS ? K * 4 : 0);
-  const long long gx = ((M + QBM - 1) / QBM) * (N / BN);
+  const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_q: grid too large");
-  auto kern = gemm_q_kernel<TN, KIND, ABIAS>;
+  auto kern = gemm_q_kernel<TN, KIND, ABIAS, RM>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1462,10 +1502,20 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (N == 128 && n_real <= 96 && n_real > 64 && !narrow && !out2 && pave_internal_diag_variant() != 8 &&
       ksplit == 1 && (kind == 1 || kind == 0) && !a_bias) {
     if (kind == 1 && big3) return launch_q<3, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    if (kind == 1 && dv != 15 && (((M + 255) / 256) >= 1024 || dv == 16) && (os.res_rows == 0 || os.res_rows >= 64))
+      return launch_q<3, 1, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
     if (kind == 1) return launch_q<3, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
     return launch_q<3, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
+  // 64-column tiles over many rows (HRNet's 48-channel branch, ResNet layer1): two row tiles per wave, 256-row
+  // blocks, from two blocks per CU slot of the chip on (diag variant 15: never, 16: whenever the form exists)
+  if (N % 64 == 0 && (kind == 0 || (kind == 1 && !big3)) && !a_bias && ksplit == 1 && dv != 15 &&
+      (((M + 255) / 256) * (N / 64) >= 1024 || dv == 16) && (os.res_rows == 0 || os.res_rows >= 64) &&
+      (long long)N * 1024 < (1ll << 31)) {
+    if (kind == 1) return launch_q<2, 1, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    return launch_q<2, 0, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+  }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO
   return pave_internal_fail(PAVE_E_ARG, "gemm_q: N %% 64 == 0 required");
@@ -1557,17 +1607,20 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   return PAVE_OK;
 }
 
-template <bool HAS_A, int KIND2, int CN>
+template <bool HAS_A, int KIND2, int CN, int RMC = 1>
 static int launch_chain(const ChainArgs& p, hipStream_t st) {
-  auto kern = bottleneck_chain_kernel<HAS_A, KIND2, CN>;
+  auto kern = bottleneck_chain_kernel<HAS_A, KIND2, CN, RMC>;
+  // (the 256-row 64-column body: ring of 3 x 22 KiB)
+  constexpr int smem = RMC == 2 ? (3 * (2 * QBM * 64 + 3 * 64 * 32) > W_SMEM ? 3 * (2 * QBM * 64 + 3 * 64 * 32) : W_SMEM) : W_SMEM;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return pave_internal_fail(PAVE_E_LAUNCH, "bottleneck_chain: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + QBM - 1) / QBM)), dim3(256), W_SMEM, st, p);
+  constexpr int CBM = QBM * RMC;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + CBM - 1) / CBM)), dim3(256), smem, st, p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
@@ -1605,6 +1658,17 @@ extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes,
   if (cn == 64) return launch_chain<HA, 0, 64>(p, st);                 \
   if (cn == 128) return launch_chain<HA, 0, 128>(p, st);               \
   return launch_chain<HA, 0, 0>(p, st)
+  // from two 256-row tiles per block slot of the chip on: 256-row tiles (the 3x3 and a 64-output conv1 with two
+  // row tiles per wave); diag variant 15: never, 16: always
+  const int dvc = pave_internal_diag_variant();
+  if (c1 && cn > 0 && dvc != 15 && (p.M >= 256 * 1024 || dvc == 16)) {
+    if (a2) {
+      if (cn == 64) return launch_chain<true, 4, 64, 2>(p, st);
+      return launch_chain<true, 4, 128, 2>(p, st);
+    }
+    if (cn == 64) return launch_chain<true, 0, 64, 2>(p, st);
+    return launch_chain<true, 0, 128, 2>(p, st);
+  }
   if (c1) { PAVE_CHAIN_GO(true); }
   PAVE_CHAIN_GO(false);
 #undef PAVE_CHAIN_GO

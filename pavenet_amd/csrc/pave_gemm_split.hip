@@ -556,7 +556,9 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // 6 = no split-K plan,
                          // 13 / 14 = LayerNorm-epilogue GEMM: always the 8-wave / the wide form,
                          // 8 = LDS-DMA generation without its wide tile form, 7 = wide
-                         // tile form wherever it applies (default: from 512 tiles up)
+                         // tile form wherever it applies (default: from 512 tiles up),
+                         // 15 / 16 = two row tiles per wave (256-row blocks) for the 64- / 96-column
+                         // tile forms and the ResNet layer1 chain: never / wherever the form exists
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {

@@ -963,6 +963,18 @@ def test_bottleneck_chain_equals_separate_launches(form):
         assert torch.equal(c1n.permute(0, 2, 3, 1).reshape(-1, cn), exp_c1n)
     else:
         assert c1n is None
+    if cn and not form.startswith('tail'):
+        # the 256-row tile form of the launch (two row tiles per wave in the 3x3 and the 64-output conv1,
+        # the wide bodies as two 128-row halves; diag variant 16 forces it at this size)
+        from pavenet_amd import native
+        res2 = x_in.clone(memory_format=torch.channels_last) if inplace else x_in
+        with native.diag_build(16):
+            out2, c1n2 = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=None if down else res2,
+                                              a2=x_in if down else None, w1n_planes=w1np, b1n=b1n,
+                                              out=res2 if inplace else None)
+            torch.cuda.synchronize()
+        assert torch.equal(out2.permute(0, 2, 3, 1).reshape(-1, 256), exp_out)
+        assert torch.equal(c1n2.permute(0, 2, 3, 1).reshape(-1, cn), exp_c1n)
     with pytest.raises(RuntimeError):
         ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=res, a2=x_in if down else cl(rnd(N, 64, H, W)))
 
@@ -1167,6 +1179,75 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
     for v in (8, 7, 0):
         assert torch.equal(outs[v], outs[9]), (seed, M, K, N, v, float((outs[v] - outs[9]).abs().max()))
     assert torch.isfinite(outs[0]).all()
+
+
+def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
+    """pave_enc_deform_attn_tile_f32 called directly (ctypes): prepared input with the wide-window variant
+    (5: the non-prepared kernel would read the null `ref`), (6) and bits above the 3-bit mask must come back
+    as an error with NOTHING enqueued -- `out` keeps its contents."""
+    import ctypes
+    from pavenet_amd import native
+    lib = native.load()
+    levels = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    S = sum(h * w for h, w in levels)
+    value = torch.randn(1, S, 8, 32, device='cuda')
+    proj = torch.rand(S, 384, device='cuda')
+    out = torch.full((S, 256), 3.0, device='cuda')
+    hw = (ctypes.c_int * 8)(*[v for l in levels for v in l])
+    for variant in (5, 6, 7, 8, 12, -1):
+        st = lib.pave_enc_deform_attn_tile_f32(value.data_ptr(), proj.data_ptr(), None, out.data_ptr(), 1, S,
+                                               ctypes.cast(hw, ctypes.c_void_p), 384, variant, None, None)
+        assert st != 0, variant
+    torch.cuda.synchronize()
+    assert bool((out == 3.0).all())
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_gemm_two_row_tiles_per_wave_form_is_bit_identical(seed):
+    """The 64- / 96-column tile forms with TWO row tiles per wave (256-row blocks, every W fragment read once
+    for both tiles; diag variant 16 forces the form, 15 forbids it) against one row tile per wave: the
+    products of an accumulator keep their order, so plain rows (bias / residual / ReLU /
+    padded output width) and the 3x3 implicit GEMM (48-, 64- and 96-channel maps, identity + ReLU, image
+    borders, a NaN pixel) must agree bit for bit -- single rows, partial and exact 256-row tiles included."""
+    from pavenet_amd import native, ops
+    rs = np.random.RandomState(3000 + seed)
+    g = torch.Generator().manual_seed(4000 + seed)
+    if seed % 2 == 0:
+        M = int(rs.choice([1, 200, 255, 256, 257, 1000, 2049]))
+        K = int(rs.choice([64, 96, 256, 576]))
+        N = int(rs.choice([48, 64, 192]))
+        use_res, use_bias, relu = bool(rs.randint(2)), bool(rs.randint(2)), bool(rs.randint(2))
+        rows = 0
+        a = torch.randn(M, K, generator=g).cuda()
+        wp = ops.split_weight_bf16x3((torch.randn(N, K, generator=g) * 0.05).cuda(), pad=True)
+        b = torch.randn(N, generator=g).cuda() if use_bias else None
+        r = torch.randn(rows if rows else M, N, generator=g).cuda() if use_res else None
+
+        def run():
+            return ops.gemm_bf16x3(a, wp, b, r, relu=relu, n_out=N)
+        what = ('rows', M, K, N, use_res, rows, relu)
+    else:
+        n, H, W = int(rs.choice([1, 2, 3])), int(rs.choice([8, 19, 33])), int(rs.choice([11, 16, 27]))
+        C = int(rs.choice([48, 64, 96]))
+        use_res, relu = bool(rs.randint(2)), bool(rs.randint(2))
+        x = torch.randn(n, C, H, W, generator=g)
+        x[0, 1, 0, 0] = float('nan')
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        wp = ops.split_conv3x3_weight((torch.randn(C, C, 3, 3, generator=g) * 0.05).cuda())
+        b = torch.randn(C, generator=g).cuda()
+        r = torch.randn(n, C, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last) \
+            if use_res else None
+
+        def run():
+            return torch.nan_to_num(ops.conv3x3_split(xd, wp, b, stride=1, relu=relu, residual=r, cout=C), nan=7.0)
+        what = ('3x3', n, H, W, C, use_res, relu)
+    with native.diag_build(15):
+        one = run().clone()
+    with native.diag_build(16):
+        two = run().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), (what, float((one - two).abs().max()))
+    assert torch.isfinite(two).all()
 
 
 @pytest.mark.parametrize('M,K,N,rows,nsplit', [(1000, 256, 640, 125, 256), (777, 64, 384, 0, 128),
