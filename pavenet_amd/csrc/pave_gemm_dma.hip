@@ -1508,11 +1508,13 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
     return launch_q<3, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
-  // 64-column tiles over many rows (HRNet's 48-channel branch, ResNet layer1): two row tiles per wave, 256-row
-  // blocks, from two blocks per CU slot of the chip on (diag variant 15: never, 16: whenever the form exists)
-  if (N % 64 == 0 && (kind == 0 || (kind == 1 && !big3)) && !a_bias && ksplit == 1 && dv != 15 &&
-      (((M + 255) / 256) * (N / 64) >= 1024 || dv == 16) && (os.res_rows == 0 || os.res_rows >= 64) &&
-      (long long)N * 1024 < (1ll << 31)) {
+  // 64-column tiles with two row tiles per wave (256-row blocks): only on request (diag variant 16).  Measured
+  // at 28 x 200 x 336 pixels (tools/rm_ab.py, profiles/r05_rm_ab.txt): 3x3 48 -> 48 + identity 628 -> 653 us,
+  // 64 -> 64 801 -> 817, conv1 256 -> 64 470 -> 478 -- as launches of their own these forms lose more from two
+  // blocks per CU (196 registers) instead of three than they gain from sharing the W fragments; the 96-column
+  // 3x3 (two blocks per CU either way: 442 -> 428 us) and the layer1 chain (-3 ... -4 %) take the form.
+  if (N % 64 == 0 && (kind == 0 || (kind == 1 && !big3)) && !a_bias && ksplit == 1 && dv == 16 &&
+      (os.res_rows == 0 || os.res_rows >= 64) && (long long)N * 1024 < (1ll << 31)) {
     if (kind == 1) return launch_q<2, 1, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
     return launch_q<2, 0, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
