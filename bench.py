@@ -162,6 +162,30 @@ SPLIT_GEMM_TAGS = ('gemm_bf16x3', 'gemm_bf16x3_ln', 'conv3x3_split', 'conv1x1_st
 SMALL_GEMM_TAGS = ('gemm_bf16x3_small', 'gemm_bf16x3_ln_small')
 
 
+def algorithmic_bytes_gemm_launch(tag, shape):
+    """Algorithmic HBM bytes of one GEMM / convolution launch from the wrapper's shape note: the fp32
+    activation rows read once, the output written once, a residual / identity read once (weights: a few
+    hundred KB, not counted).  3x3 / stride s: the input map = M s^2 Cin values; the layer1 chain: c1 + identity
+    (or the downsample input) in, out + the next conv1 out (its 64-channel scratch stays in L2); the stem: 4 input
+    pixels x 3 channels per output pixel."""
+    if not shape:
+        return 0
+    M, K, N = int(shape[0]), int(shape[1]), int(shape[2])
+    notes = [str(x) for x in shape[3:]]
+    if tag == 'bottleneck_chain':     # (M, 64, 256, cn, 'k2=..', 'tail' | '')
+        cn, k2 = int(shape[3]), int(notes[1][3:])
+        return 4 * M * (64 + (k2 if k2 else 256) + 256 + cn)
+    if tag == 'conv7x7_stem':
+        return M * (4 * 3 + 64) * 4
+    a = M * K * 4
+    for n in notes:
+        if n.startswith('3x3 s'):
+            s_ = int(n[5])
+            a = M * s_ * s_ * (K // 9) * 4
+    res = M * 32 if 'encproj' in notes else (M * N * 4 if 'res' in notes else 0)
+    return a + M * N * 4 + res
+
+
 def algorithmic_bytes_encoder_launch(n_frames):
     """4 B x [value S*256 + offsets/logits S*8*16*3 + out S*256] per frame-layer
     = 80.0 MB at S = 22 323; one launch covers all frames of the batch."""
@@ -272,29 +296,50 @@ def secondary_workloads(args, dev, budget_s=75.0):
                 host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
             host.copy_(packed, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        with torch.no_grad():
-            for _ in range(warmup):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps - ev_steps):
-                step()
-            ops.KERNEL_EVENT_TAGS = SPLIT_GEMM_TAGS      # (rows >= 8192, as the headline's class)
-            ops.KERNEL_EVENTS = []
-            for _ in range(ev_steps):
-                step()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        try:
+            with torch.no_grad():
+                for _ in range(warmup):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps - ev_steps):
+                    step()
+                ops.KERNEL_EVENT_TAGS = SPLIT_GEMM_TAGS      # (rows >= 8192, as the headline's class)
+                ops.KERNEL_EVENTS, ops.KERNEL_EVENT_SHAPES = [], []
+                for _ in range(ev_steps):
+                    step()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+        except Exception as e:      # an `extra` workload must not take the headline line with it
+            ops.KERNEL_EVENTS = ops.KERNEL_EVENT_SHAPES = None
+            out.append(dict(workload=label, error=f'{type(e).__name__}: {e}'[:300]))
+            del img
+            continue
+        ev, shapes = ops.KERNEL_EVENTS, ops.KERNEL_EVENT_SHAPES
+        ops.KERNEL_EVENTS = ops.KERNEL_EVENT_SHAPES = None
         tt = sum(s_.elapsed_time(e_) for _, s_, e_, _ in ev) * 1e-3
         fl = sum(f for _, _, _, f in ev)
+        nbytes = sum(algorithmic_bytes_gemm_launch(e_[0], sh) for e_, sh in zip(ev, shapes))
         peak = MFMA_PEAK[gemm]
-        out.append(dict(workload=label, steps=steps, warmup=warmup,
-                        ms_per_step=round(dt / steps * 1e3, 3), clips_per_s=round(B * steps / dt, 3),
-                        split_class_tflops=round(fl / tt / 1e12, 1) if tt > 0 else None,
-                        split_class_ms_per_step=round(tt / ev_steps * 1e3, 3),
-                        split_class_tflop_per_step=round(fl / ev_steps / 1e12, 3),
-                        peak_tflops=round(peak, 1), frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None))
+        rec = dict(workload=label, steps=steps, warmup=warmup,
+                   ms_per_step=round(dt / steps * 1e3, 3), clips_per_s=round(B * steps / dt, 3),
+                   split_class_tflops=round(fl / tt / 1e12, 1) if tt > 0 else None,
+                   split_class_ms_per_step=round(tt / ev_steps * 1e3, 3),
+                   split_class_tflop_per_step=round(fl / ev_steps / 1e12, 3),
+                   split_class_gb_per_step=round(nbytes / ev_steps / 1e9, 2),
+                   split_class_gbps=round(nbytes / tt / 1e9, 1) if tt > 0 else None)
+        if gemm == 'fp16':
+            # one fp16 product per tile: these launches move fp32 activations and are HBM-bound, so the class is
+            # scored against the HBM peak on its algorithmic bytes (the MFMA fraction is printed for reference)
+            rec.update(bound='hbm', peak_gbps=HBM_PEAK_GBS,
+                       frac=round(nbytes / tt / 1e9 / HBM_PEAK_GBS, 4) if tt > 0 else None,
+                       mfma_frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None,
+                       bytes_are='fp32 activation rows read once + output written once + residual read once per '
+                                 'launch (bench.algorithmic_bytes_gemm_launch)')
+        else:
+            rec.update(bound='mfma', peak_tflops=round(peak, 1),
+                       frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None)
+        out.append(rec)
         del img
     model = None
     torch.cuda.empty_cache()
@@ -476,12 +521,14 @@ def main():
             out = run_steps(args.steps - ev_steps, P)
         if ev_on:
             ops.KERNEL_EVENT_TAGS = ('enc_tile', 'enc_grid_T1') + SPLIT_GEMM_TAGS + SMALL_GEMM_TAGS
-            ops.KERNEL_EVENTS = []
+            ops.KERNEL_EVENTS, ops.KERNEL_EVENT_SHAPES = [], []
             out = run_steps(ev_steps, P)
         sync()
         dt = time.perf_counter() - t0
         ev = ops.KERNEL_EVENTS or []
-        ops.KERNEL_EVENTS = None
+        # (one shape note per recorded launch, in the same order)
+        ev = [e_ + (sh,) for e_, sh in zip(ev, ops.KERNEL_EVENT_SHAPES or [None] * len(ev))]
+        ops.KERNEL_EVENTS = ops.KERNEL_EVENT_SHAPES = None
         if dist is not None:
             tt = torch.tensor([dt], device='cpu' if host_collectives else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -502,7 +549,8 @@ def main():
         # the same K steps with two batches in flight (two HIP streams): throughput of a serving loop;
         # reported beside the headline, whose kernels run alone (clean per-kernel event times)
         pipe_dt, _, _ = timed(False, 2)
-    timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl in events]
+    timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl, _ in events]
+    shaped_ev = [(tag, s.elapsed_time(e) * 1e-3, fl, sh) for tag, s, e, fl, sh in events]
     enc = [(tag, t) for tag, t, _ in timed_ev if tag in ('enc_tile', 'enc_grid_T1')]
     n_frames = img.shape[0] * img.shape[1]   # frames this rank encodes per step
     roofline_mfma = None
@@ -537,6 +585,25 @@ def main():
             by_entry_point={k: dict(launches_per_step=round(v[0] / max(1, ev_steps_main), 1),
                                     ms_per_step=round(v[1] / max(1, ev_steps_main) * 1e3, 3),
                                     tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in sorted(by.items())})
+        # the single dominant kernel of the class on its own: the launches of ONE shape that take the most time
+        # (the wide-tile row GEMM gemm_w_kernel<0> on the encoder's FFN1 shape in the headline workload)
+        groups = {}
+        for tag, t, fl, sh in shaped_ev:
+            if tag in SPLIT_GEMM_TAGS and sh:
+                d = groups.setdefault((tag,) + tuple(str(x) for x in sh), [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += t
+                d[2] += fl
+        if groups:
+            gk, gv = max(groups.items(), key=lambda kv: kv[1][1])
+            roofline_mfma['dominant_kernel'] = dict(
+                launch=f'{gk[0]} M x K x N = {gk[1]} x {gk[2]} x {gk[3]} ' + ' '.join(x for x in gk[4:] if x),
+                kernel='gemm_w_kernel<0> (wide tile form: 32 rows x 256 columns per wave)'
+                       if gk[0] == 'gemm_bf16x3' and int(gk[3]) % 256 == 0 else gk[0],
+                launches_per_step=round(gv[0] / max(1, ev_steps_main), 1),
+                avg_us=round(gv[1] / gv[0] * 1e6, 1), ms_per_step=round(gv[1] / max(1, ev_steps_main) * 1e3, 3),
+                achieved=round(gv[2] / gv[1] / 1e12, 1), peak=round(peak, 1), unit='TFLOP/s',
+                frac=round(gv[2] / gv[1] / 1e12 / peak, 4))
         sm = [(t, fl) for tag, t, fl in timed_ev if tag in SMALL_GEMM_TAGS]
         if sm:
             st_, sf_ = sum(t for t, _ in sm), sum(fl for _, fl in sm)

@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 16
+#define PAVE_ABI_VERSION 17
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -131,11 +131,12 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
  *      ((ref + off / (w, h)) * (w, h) - 0.5), then softmaxed attention weights [8][16]
  * i.e. `proj` of pave_enc_deform_attn_tile_f32 in its prepared form (variant | 4): same bits as
  * feeding that kernel the raw projections (one definition of the arithmetic, csrc/pave_enc_math.h).
+ * nplanes: 3 or PAVE_PLANES_FP16 (below).
  */
 int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
                                  long long table_rows, const float* value_bias, const float* ref,
                                  const int* levels_hw, float* value, float* samp, long long M, int K,
-                                 void* stream);
+                                 int nplanes, void* stream);
 
 /*
  * HRNet stem conv1 (third_party/mmdetection/mmdet/models/backbones/hrnet.py:549-556): 3x3 / stride 2
@@ -343,7 +344,12 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
  * residual may alias out.  M < 2^31.
  *   3 planes: K %% 32 == 0 (K >= 64), N %% 4 == 0; for N %% 64 != 0 the weight planes carry
  *   roundup(N, 64) rows (zero rows beyond N) while out / bias / residual have N columns.
- *   1 / 2 planes, fp16: K %% 64 == 0, N %% 128 == 0.
+ *   PAVE_PLANES_FP16: the same kernels and shape rules as 3 planes (one fp16 plane [K/16][1][N][16], the
+ *   fp32 activation rows converted to fp16, round to nearest even, where the 3-plane form splits them;
+ *   one v_mfma_f32_32x32x16_f16 per tile and 16-wide K slab).
+ *   1 / 2 bf16 planes: K %% 64 == 0, N %% 128 == 0 (first-generation kernels).
+ * Every entry point below that takes `nplanes` accepts 3 or PAVE_PLANES_FP16 (pave_gemm_bf16x3_f32,
+ * _ex_f32 and pave_conv3x3_split_f32 also 1 and 2).
  */
 #define PAVE_PLANES_FP16 16 /* nplanes value: ONE plane of fp16 (not bf16) operands */
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
@@ -398,7 +404,7 @@ int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* bet
  */
 int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, const void* w_planes,
                              const float* bias, const float* residual, float* out, long long M, int K,
-                             int N, int relu, void* stream);
+                             int N, int relu, int nplanes, void* stream);
 
 /*
  * Grouped row GEMM (3 bf16 planes): the N axis is cut into N / group_n groups; group i computes
@@ -412,7 +418,7 @@ int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, cons
  */
 int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_planes, const float* bias,
                                  float* out, long long M, int K, int N, int group_n, int relu,
-                                 void* stream);
+                                 int nplanes, void* stream);
 
 /*
  * out[M, 256] = LayerNorm(a @ W^T + bias + residual) * gamma + beta  (3 bf16 planes, N == 256): the
@@ -423,7 +429,7 @@ int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_pl
  */
 int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
                             const float* residual, const float* gamma, const float* beta, float eps,
-                            float* out, long long M, int K, int N, void* stream);
+                            float* out, long long M, int K, int N, int nplanes, void* stream);
 
 /*
  * 3x3 / pad 1 / stride 1|2 convolution, NHWC fp32 in and out, as an implicit GEMM through the same
@@ -436,7 +442,7 @@ int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* b
  *   3 planes: Cin %% 16 == 0, Cout %% 4 == 0; the weight planes are ZERO-PADDED to
  *   roundup(9 Cin, 32) columns and roundup(Cout, 64) rows (HRNet's 48- / 96-channel branches);
  *   residual [N, Ho, Wo, Cout] (may be NULL or alias y) is added before the ReLU.
- *   1 / 2 planes, fp16: Cin %% 64 == 0, Cout %% 64 == 0, residual == NULL.
+ *   PAVE_PLANES_FP16: as 3 planes.  1 / 2 bf16 planes: Cin %% 64 == 0, Cout %% 64 == 0, residual == NULL.
  */
 int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bias,
                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
@@ -458,7 +464,7 @@ long long pave_conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int 
 int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* bias,
                             const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                             int stride, int relu, void* workspace, long long workspace_bytes,
-                            void* stream);
+                            int nplanes, void* stream);
 
 /*
  * ResNet Bottleneck of the 64-channel stage from its 3x3 convolution on, CHAINED with the next
@@ -484,7 +490,8 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
 int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const float* b2, float* c2,
                               const void* w3_planes, const float* b3, const float* residual,
                               const float* a2, int k2, float* out, const void* w1n_planes,
-                              const float* b1n, float* c1n, int cn, int N, int H, int W, void* stream);
+                              const float* b1n, float* c1n, int cn, int N, int H, int W, int nplanes,
+                              void* stream);
 
 /*
  * 1x1 convolution with a stride on an NHWC map (the ResNet downsample branch,
@@ -494,7 +501,7 @@ int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const floa
  */
 int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                    int N, int H, int W, int Cin, int Cout, int stride, int relu,
-                                   void* stream);
+                                   int nplanes, void* stream);
 
 /*
  * The ResNet / HRNet stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; folded BatchNorm as
@@ -507,9 +514,11 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
  *                 (176) -- the kernel that stages the block's input window in LDS by LDS-DMA,
  *                 taken when W %% 4 == 0 and x is 16-byte aligned.
  * y [N, Ho, Wo, 64] NHWC, Ho = (H - 1) / 2 + 1.
+ * nplanes = PAVE_PLANES_FP16: w_planes = [23][1][64][16] fp16 (the same two layouts, one plane); only the
+ * LDS-window kernel exists for it (W %% 4 == 0, x 16-byte aligned; PAVE_E_UNSUPPORTED otherwise).
  */
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                                  int N, int H, int W, int Cout, int relu, void* stream);
+                                  int N, int H, int W, int Cout, int relu, int nplanes, void* stream);
 
 /* x[n] fp32 -> planes[nplanes][n] bf16: truncation terms, the last rounded to nearest even
  * (nplanes = 3: x = p0 + p1 + p2 exactly). */

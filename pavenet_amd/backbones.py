@@ -203,12 +203,16 @@ class ResNet(BaseModule):
         """7x7 / stride 2 stem through the hand-written 3-plane split kernel, read straight from
         the NCHW image batch (bf16x3 GEMM mode); None when the mode / shape does not take it."""
         from . import ops
-        from .bricks import _split_cached, get_gemm_mode
-        if get_gemm_mode() != 'bf16x3' or torch.is_grad_enabled() or not x_nchw.is_cuda \
+        from .bricks import _split_cached, fused_mode, get_gemm_mode
+        if not fused_mode() or torch.is_grad_enabled() or not x_nchw.is_cuda \
                 or x_nchw.dtype != torch.float32 or tuple(w.shape) != (64, 3, 7, 7) \
                 or x_nchw.shape[1] != 3 or x_nchw.shape[3] < 8 or not x_nchw.is_contiguous():
             return None
-        wp = _split_cached(w, 'stem7x7', lambda planes: ops.split_stem7x7_weight(w.detach()))
+        if get_gemm_mode() == 'fp16' and (x_nchw.shape[3] % 4 or x_nchw.data_ptr() % 16):
+            # (the fp16 stem exists as the LDS-window kernel only: odd widths take the exact planes)
+            wp = _split_cached(w, 'stem7x7_x3', lambda planes: ops.split_stem7x7_weight(w.detach(), 3))
+        else:
+            wp = _split_cached(w, 'stem7x7', lambda planes: ops.split_stem7x7_weight(w.detach(), planes))
         return ops.conv7x7s2_nchw_split(x_nchw, wp)
 
     @staticmethod
@@ -231,11 +235,11 @@ class ResNet(BaseModule):
         return rows.view(n, h, w, rows.shape[-1]).permute(0, 3, 1, 2)  # channels_last 4-D
 
     def _stage64_chain_ok(self, name, x, f):
-        from .bricks import _GEMM, get_gemm_mode
+        from .bricks import _GEMM, fused_mode
         blocks = list(getattr(self, name))
         if blocks[0].downsample is not None and (name, 0, 'tail_ds_kn') not in f:
             return False
-        if not (self.chain_stage64 and get_gemm_mode() == 'bf16x3' and not torch.is_grad_enabled()
+        if not (self.chain_stage64 and fused_mode() and not torch.is_grad_enabled()
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and x.shape[0] * x.shape[2] * x.shape[3] >= _GEMM['min_rows']
                 and all(isinstance(b, Bottleneck) for b in blocks)):
@@ -343,8 +347,8 @@ class ResNet(BaseModule):
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
             tail = f.get((name, bi, 'tail_ds_kn'))
-            from .bricks import _GEMM, _split_weight, get_gemm_mode
-            if (s > 1 and tail is None and get_gemm_mode() == 'bf16x3' and not torch.is_grad_enabled()
+            from .bricks import _GEMM, _split_weight, fused_mode
+            if (s > 1 and tail is None and fused_mode() and not torch.is_grad_enabled()
                     and wd.shape[0] % 128 == 0 and wd.shape[1] % 64 == 0
                     and yrows.shape[0] >= _GEMM['min_rows']
                     and (w3_kn is not None or split_gemm_ok(yrows, w3.flatten(1)))):
@@ -362,7 +366,7 @@ class ResNet(BaseModule):
             xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
             xrows, _ = self._as_rows(xs)
             from .bricks import _split_cached
-            if tail is not None and b2 is None and get_gemm_mode() == 'bf16x3' \
+            if tail is not None and b2 is None and fused_mode() \
                     and not torch.is_grad_enabled() and yrows.shape[0] >= _GEMM['min_rows'] \
                     and tail[0].shape[0] % 32 == 0 and tail[0].shape[1] % 64 == 0 \
                     and yrows.shape[1] % 16 == 0:
@@ -496,13 +500,13 @@ class _Folded:
     def conv_bn(cls, x, conv, bn, relu=False, residual=None):
         """act(bn(conv(x)) + residual); x, residual channels_last; the result is a fresh tensor."""
         from . import ops
-        from .bricks import get_gemm_mode, split_conv_weight
+        from .bricks import fused_mode, get_gemm_mode, split_conv_weight
         w, b = cls.weights(conv, bn)
         if conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) \
                 and conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
             wsplit = split_conv_weight(w)   # split / 16-bit GEMM modes
-            if wsplit is not None and wsplit.shape[1] == 3:
-                # exact 3-plane kernel: any Cin % 16, Cout % 4 (zero-padded planes); bias, identity
+            if wsplit is not None and fused_mode():
+                # 3-plane / fp16 kernel: any Cin % 16, Cout % 4 (zero-padded planes); bias, identity
                 # and ReLU in its epilogue (no separate pass)
                 return ops.conv3x3_split(x, wsplit, b, stride=conv.stride[0], relu=relu,
                                          residual=residual, cout=w.shape[0])
@@ -512,7 +516,7 @@ class _Folded:
                                       fp16=get_gemm_mode() == 'fp16')
                 return y if residual is None else ops.bias_act_rows_(y, None, residual, relu=relu)
         if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) \
-                and conv.groups == 1 and get_gemm_mode() == 'bf16x3' and w.shape[1] % 32 == 0 \
+                and conv.groups == 1 and fused_mode() and w.shape[1] % 32 == 0 \
                 and w.shape[1] >= 64 and w.shape[0] % 4 == 0 \
                 and x.is_contiguous(memory_format=torch.channels_last):
             # 1x1 convolution = row GEMM on the NHWC map through the exact 3-plane kernel (planes

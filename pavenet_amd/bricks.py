@@ -134,6 +134,21 @@ def get_gemm_mode():
     return _GEMM['mode']
 
 
+# The modes of the LDS-DMA kernel generation: the exact 3-plane split and fp16 operands (one plane).  Every
+# fused form of the package (LayerNorm / encoder-projection / chain / grouped / small-row launches, padded
+# planes) exists for both; the 1- / 2-plane bf16 modes keep the first-generation row GEMM and 3x3 only.
+_QMODES = ('bf16x3', 'fp16')
+
+
+def fused_mode():
+    return _GEMM['mode'] in _QMODES
+
+
+def mode_planes():
+    """The `planes` argument of ops.split_* for the current GEMM mode."""
+    return _PLANES[_GEMM['mode']]
+
+
 _CACHE_EPOCH = [0]
 
 
@@ -198,8 +213,8 @@ def _split_slots(weight):
     return slots
 
 
-def _split_cached(weight, kind, make):
-    planes = _PLANES[_GEMM['mode']]
+def _split_cached(weight, kind, make, planes=None):
+    planes = planes or _PLANES[_GEMM['mode']]
     slots = _split_slots(weight)
     slot = (tuple(weight.shape), tuple(weight.stride()), weight.storage_offset(), planes, kind)
     hit = slots.get(slot)
@@ -215,11 +230,21 @@ def _split_cached(weight, kind, make):
 _SPLIT_STATS = {'made': 0}   # number of weight splits performed (tests: the path was exercised)
 
 
-def _split_weight(weight):
-    """Weight [N, K] -> cached slab-major bf16x3 planes (re-split when the tensor changes)."""
+def exact_planes(rows):
+    """'fp16' mode = BASELINE configs[4]'s "fp16 MFMA projections": the throughput-bound launches (projections,
+    FFNs and convolutions over >= min_rows rows) take fp16 operands; the decoders' and heads' few-hundred-row
+    Linears -- latency-bound, and the ones whose outputs are logits, key points and sigmas -- stay on the exact
+    3-plane split.  Returns the `planes` override for _split_cached (None: the mode's own)."""
+    return 3 if (_GEMM['mode'] == 'fp16' and rows < _GEMM['min_rows']) else None
+
+
+def _split_weight(weight, rows=None):
+    """Weight [N, K] -> cached slab-major bf16x3 planes (re-split when the tensor changes).  rows: the
+    row count of the launch (see exact_planes)."""
     from . import ops
     return _split_cached(weight, 'gemm',
-                         lambda planes: ops.split_weight_bf16x3(weight.detach().contiguous(), planes))
+                         lambda planes: ops.split_weight_bf16x3(weight.detach().contiguous(), planes),
+                         exact_planes(rows) if rows is not None else None)
 
 
 def split_conv_weight(weight):
@@ -228,7 +253,7 @@ def split_conv_weight(weight):
     if _GEMM['mode'] not in _PLANES or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) \
             or not weight.is_cuda or weight.dtype != torch.float32:
         return None
-    if _GEMM['mode'] == 'bf16x3':      # 3 planes: zero-padded planes (HRNet's 48 / 96 channels)
+    if _GEMM['mode'] in _QMODES:       # 3 planes / fp16: zero-padded planes (HRNet's 48 / 96 channels)
         if weight.shape[0] % 4 or weight.shape[1] % 16:
             return None
     elif weight.shape[0] % 64 or weight.shape[1] % 64:
@@ -245,7 +270,7 @@ def split_gemm_ok(x2, weight):
     return (_GEMM['mode'] in _PLANES and x2.is_cuda and x2.dtype == torch.float32
             and x2.dim() == 2 and x2.is_contiguous() and weight.dtype == torch.float32
             and weight.shape[1] % 64 == 0
-            and (weight.shape[0] % 128 == 0 or (weight.shape[0] == 64 and _GEMM['mode'] == 'bf16x3'))
+            and (weight.shape[0] % 128 == 0 or (weight.shape[0] == 64 and _GEMM['mode'] in _QMODES))
             and x2.shape[0] >= _GEMM['min_rows']
             and not (torch.is_grad_enabled() and (x2.requires_grad or weight.requires_grad)))
 
@@ -253,7 +278,7 @@ def split_gemm_ok(x2, weight):
 def small_split_ok(x2, weight):
     """Shapes below split_gemm_ok's row threshold or off its column grid that still take the
     3-plane kernel (zero-padded planes): inference only, exact split mode only."""
-    return (_GEMM['mode'] == 'bf16x3' and _GEMM['small'] and x2.is_cuda and x2.dtype == torch.float32
+    return (_GEMM['mode'] in _QMODES and _GEMM['small'] and x2.is_cuda and x2.dtype == torch.float32
             and x2.dim() == 2 and x2.is_contiguous() and x2.shape[0] >= 1
             and weight.dtype == torch.float32 and weight.dim() == 2
             and weight.shape[1] % 32 == 0 and weight.shape[1] >= 64
@@ -265,7 +290,7 @@ def mlp_rows(module, x):
     nn.Sequential of those and nn.ReLU, every Linear through linear_rows (ReLU in its epilogue)
     -- on the device in the exact split mode these are launches of this package's GEMM; anything
     else (other layer types, training) is the module's own forward."""
-    if not (x.is_cuda and x.dtype == torch.float32 and _GEMM['mode'] == 'bf16x3'
+    if not (x.is_cuda and x.dtype == torch.float32 and _GEMM['mode'] in _QMODES
             and not torch.is_grad_enabled()):
         return module(x)
     layers = list(module) if isinstance(module, nn.Sequential) else [module]
@@ -285,7 +310,7 @@ def mlp_rows(module, x):
     if not rows.is_contiguous():
         rows = rows.contiguous()
     for i, (w, b, relu) in enumerate(plan):
-        rows = linear_rows(rows, w, b, relu=relu)
+        rows = linear_rows(rows, w, b, relu=relu, exact=True)     # (head branches: never 16-bit operands)
         if i + 1 < len(plan) and not rows.is_contiguous():
             rows = rows.contiguous()
     # (an output width off the 4-column grid comes back as a column slice of a padded matrix: kept
@@ -294,15 +319,16 @@ def mlp_rows(module, x):
 
 
 def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residual=False,
-                a_bias=None):
+                a_bias=None, exact=False):
     """act(A' @ weight^T + bias + residual) on rows [M, K]: the split GEMM when enabled and
     applicable, else hipBLASLt with the same fusions (bias / ReLU / residual in the epilogue).
-    A' = relu(x2 + a_bias) when a_bias is given."""
+    A' = relu(x2 + a_bias) when a_bias is given.  exact: never 16-bit operands ('fp16' mode: the
+    3-plane split for this launch)."""
     if split_gemm_ok(x2, weight):
         from . import ops
         out = residual if (residual is not None and inplace_residual) else None
-        return ops.gemm_bf16x3(x2, _split_weight(weight), bias, residual, relu=relu, out=out,
-                               a_bias=a_bias, fp16=_GEMM['mode'] == 'fp16')
+        return ops.gemm_bf16x3(x2, _split_weight(weight, 0 if exact else x2.shape[0]), bias, residual,
+                               relu=relu, out=out, a_bias=a_bias)
     if small_split_ok(x2, weight) and a_bias is None:
         # every other Linear of the path -- the decoders' and heads' few-hundred-row projections,
         # FFNs and branch MLPs, any output width: the same 3-plane kernel with planes zero-padded
@@ -311,7 +337,7 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
         N = weight.shape[0]
         N4 = (N + 3) // 4 * 4
         wp = _split_cached(weight, 'gemm_pad', lambda planes: ops.split_weight_bf16x3(
-            weight.detach().contiguous(), planes, pad=True))
+            weight.detach().contiguous(), planes, pad=True), exact_planes(0))
         if N4 == N:
             out = residual if (residual is not None and inplace_residual) else None
             return ops.gemm_bf16x3(x2, wp, bias, residual, relu=relu, out=out, n_out=N)
@@ -344,13 +370,13 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
         from . import ops
         idt2 = identity_bf.reshape(-1, C_out)
         x2 = x_bf.reshape(-1, x_bf.shape[-1])
-        if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and post_norm is not None
+        if (_GEMM['ln_fused'] and _GEMM['mode'] in _QMODES and post_norm is not None
                 and pos_rows is None and C_out == 256 and tuple(post_norm.normalized_shape) == (256,)
                 and post_norm.weight is not None and post_norm.bias is not None
                 and linear.weight.shape[1] % 64 == 0
                 and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
             # Linear + bias + residual + LayerNorm as ONE launch (the block tile owns whole rows)
-            t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, idt2,
+            t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight, x2.shape[0]), linear.bias, idt2,
                                    post_norm.weight, post_norm.bias, post_norm.eps,
                                    out=idt2 if inplace else None)
             return t.view(identity_bf.shape)
@@ -380,13 +406,13 @@ def linear_norm(x, linear, norm):
     """LayerNorm(Linear(x)) on [..., C] rows: ONE launch of the Linear + LayerNorm kernel in the
     exact split mode (256-wide rows, device fp32, no grad), plain torch modules otherwise."""
     x2 = x.reshape(-1, x.shape[-1])
-    if (_GEMM['ln_fused'] and _GEMM['mode'] == 'bf16x3' and linear.out_features == 256
+    if (_GEMM['ln_fused'] and _GEMM['mode'] in _QMODES and linear.out_features == 256
             and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (256,)
             and norm.weight is not None and norm.bias is not None and x2.is_contiguous()
             and not torch.is_grad_enabled() and linear.weight.shape[1] % 64 == 0
             and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
         from . import ops
-        t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight), linear.bias, None, norm.weight,
+        t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight, x2.shape[0]), linear.bias, None, norm.weight,
                                norm.bias, norm.eps)
         return t.view(*x.shape[:-1], 256)
     return norm(linear(x))
@@ -581,9 +607,9 @@ class MultiheadAttention(BaseModule):
                 tab = torch.cat([t.float(), b[2 * E:].float().expand(L, E)], 1).contiguous()
             hit = self.__dict__['_pave_qkv'] = (key, tab)
         xb = batch_first(x).reshape(N * L, E)
-        qkv, _ = ops.gemm_bf16x3_ex(xb, _split_weight(w), None, hit[1], residual_rows=L)
+        qkv, _ = ops.gemm_bf16x3_ex(xb, _split_weight(w, N * L), None, hit[1], residual_rows=L)
         o = ops.mha_core(qkv, N, L, H)
-        t = ops.gemm_bf16x3_ln(o, _split_weight(a.out_proj.weight), a.out_proj.bias,
+        t = ops.gemm_bf16x3_ln(o, _split_weight(a.out_proj.weight, N * L), a.out_proj.bias,
                                batch_first(identity).reshape(N * L, E), post_norm.weight,
                                post_norm.bias, post_norm.eps)
         return seq_first_view(t.view(N, L, E))
@@ -631,7 +657,7 @@ class MultiheadAttention(BaseModule):
                 and a.bias_k is None and not a.add_zero_attn
                 and (post_norm is None or (isinstance(post_norm, nn.LayerNorm)
                                            and post_norm.elementwise_affine))):
-            if _GEMM['mode'] == 'bf16x3':
+            if _GEMM['mode'] in _QMODES:
                 out = self._self_attention_split(query, query_pos,
                                                  query if identity is None else identity, post_norm)
                 if out is not None:

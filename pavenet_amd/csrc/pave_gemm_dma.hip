@@ -86,6 +86,13 @@ __device__ __forceinline__ unsigned pack_rne(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_rne_f16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
 // 8 consecutive fp32 (two 16-byte chunks) -> the three bf16 planes of an MFMA A operand
 // (4 dwords each): truncation, truncation, exact remainder.
 __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 (&pl)[3]) {
@@ -178,7 +185,11 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 // wait, barrier and W fragment reads as the 6 TN of RM = 1 (the 64-column-tile forms, TN = 2, are bound by
 // that per-slab overhead, not by the matrix pipe).  Per accumulator the products keep their order:
 // bit-identical to RM = 1.
-template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1>
+// PL: operand planes.  3 = the exact bf16 split (six products per tile);  1 = fp16 operands ("fp16 MFMA
+// projections", BASELINE configs[4]): ONE plane of fp16 weights in the same slab-major layout, the raw fp32
+// activation rows converted (round to nearest even) where the 3-plane form splits them, one
+// v_mfma_f32_32x32x16_f16 per tile and slab -- every row source, tile form and epilogue of this file as it is.
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1, int PL = 3>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -191,7 +202,8 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int BM = QBM * RM;               // rows per block
   constexpr int A_STAGE = BM * 64;           // raw fp32: BM rows x 64 B
   static_assert(RM == 1 || (RM == 2 && WN == 1 && !WIDE && !LNORM && EPI == 0), "two row tiles per wave: narrow form");
-  constexpr int W_STAGE = 3 * BN * 32;       // 3 planes x BN rows x 32 B
+  static_assert(PL == 3 || PL == 1, "operand planes: 3 (bf16 split) or 1 (fp16)");
+  constexpr int W_STAGE = PL * BN * 32;      // PL planes x BN rows x 32 B
   constexpr int STAGE = A_STAGE + W_STAGE;
   constexpr int NA = A_STAGE / 1024;         // DMA instructions per slab: A (8)
   constexpr int NWI = W_STAGE / 1024;        //                            W (6 | 12 | 24)
@@ -224,7 +236,7 @@ __device__ __forceinline__ void gemm_q_body(
   // split-K: this block's part of the K axis
   const int s0 = os.ks_slabs > 0 ? (int)blockIdx.y * os.ks_slabs : 0;
   const int nslabs = os.ks_slabs > 0 ? min(os.ks_slabs, K / 16 - s0) : K / 16;
-  const long long w_slab = (long long)3 * N * 32;   // bytes per K slab of the weight planes
+  const long long w_slab = (long long)PL * N * 32;  // bytes per K slab of the weight planes
   const unsigned char* const w_base = reinterpret_cast<const unsigned char*>(Wp);
 
   // ---- DMA roles of this wave: instructions d = wave + NWAVE q;  q < QA: A rows, else W rows
@@ -300,8 +312,8 @@ __device__ __forceinline__ void gemm_q_body(
     }
 #pragma unroll
     for (int q = QA; q < QMAX; ++q) {
-      const int j = wave + NWAVE * (q - QA);         // W instruction: plane j / (NWI/3), 32 rows
-      const int p = j / (NWI / 3), row = (j % (NWI / 3)) * 32 + (lane >> 1);
+      const int j = wave + NWAVE * (q - QA);         // W instruction: plane j / (NWI/PL), 32 rows
+      const int p = j / (NWI / PL), row = (j % (NWI / PL)) * 32 + (lane >> 1);
       const int h = (lane & 1) ^ ((row >> 3) & 1);
       w_voff[q - QA] = (unsigned)((((long long)p * N + n0 + row) * 32 + h * 16));
     }
@@ -355,8 +367,8 @@ __device__ __forceinline__ void gemm_q_body(
 
   f32x16 acc[RM * TN];     // [row tile][column tile]
   f32x4 raw[RM][2];        // the lane's 8 fp32 of the next slab, per row tile
-  u32x4 apl[2][RM][3];     // A planes: [set][row tile][plane]
-  u32x4 wf[2][3][TQ];      // W fragments: [set][plane][column tile (of the quarter, WIDE)]
+  u32x4 apl[2][RM][PL];    // A planes: [set][row tile][plane]
+  u32x4 wf[2][PL][TQ];     // W fragments: [set][plane][column tile (of the quarter, WIDE)]
   const float* const ab_lds = reinterpret_cast<const float*>(smem + ABOFF);
 
   auto read_raw = [&](const int stage) {
@@ -371,7 +383,7 @@ __device__ __forceinline__ void gemm_q_body(
   auto read_wq = [&](const int stage, const int quarter, const int set) {
     const unsigned char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PL; ++p)
 #pragma unroll
       for (int j = 0; j < TQ; ++j)
         wf[set][p][j] =
@@ -394,11 +406,26 @@ __device__ __forceinline__ void gemm_q_body(
         hi[i] = fmaxf(hi[i] + b1[i], 0.f);
       }
     }
-    split8(lo, hi, apl[set][rt]);
+    if constexpr (PL == 3) {
+      split8(lo, hi, apl[set][rt]);
+    } else {
+      apl[set][rt][0] = u32x4{pack_rne_f16(lo.x, lo.y), pack_rne_f16(lo.z, lo.w), pack_rne_f16(hi.x, hi.y),
+                              pack_rne_f16(hi.z, hi.w)};
+    }
    }
   };
   // the products of order o = pa + pb (o = 2, 1, 0: smallest terms first), column tiles innermost
   auto mma = [&](const int set, const int o) {
+    if constexpr (PL == 1) {   // fp16 operands: the slab's one product per tile (scheduled where o = 0 sits)
+      if (o != 0) return;
+#pragma unroll
+      for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+          acc[rt * TN + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              __builtin_bit_cast(f16x8, apl[set][rt][0]), __builtin_bit_cast(f16x8, wf[set][0][j]),
+              acc[rt * TN + j], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int pa = 0; pa <= o; ++pa)
 #pragma unroll
@@ -409,9 +436,17 @@ __device__ __forceinline__ void gemm_q_body(
               __builtin_bit_cast(bf16x8, apl[set][rt][pa]), __builtin_bit_cast(bf16x8, wf[set][o - pa][j]),
               acc[rt * TN + j], 0, 0, 0);
         }
+    }
   };
   // WIDE: all six products of one quarter (A planes of set aset, W fragments of set wset)
   auto mma_q = [&](const int aset, const int wset, const int quarter) {
+    if constexpr (PL == 1) {
+#pragma unroll
+      for (int j = 0; j < TQ; ++j)
+        acc[quarter * TQ + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            __builtin_bit_cast(f16x8, apl[aset][0][0]), __builtin_bit_cast(f16x8, wf[wset][0][j]),
+            acc[quarter * TQ + j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int o = 2; o >= 0; --o)
 #pragma unroll
@@ -874,26 +909,27 @@ __device__ __forceinline__ void gemm_q_body(
 // (64-column tiles, TN = 2: 136 VGPRs and 42 KB of LDS -- three blocks per CU; these launches are
 // issue-bound, not MFMA-bound, and take the extra wave per SIMD)
 // (RM = 2: 256-row blocks, a wave owns two row tiles; ~200 VGPRs and 66 KB of LDS -- two blocks per CU)
-template <int TN, int KIND, bool ABIAS, int RM = 1>
+template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 && RM == 1) ? 3 : 2, (TN == 2 && RM == 1) ? 3 : 2))) void gemm_q_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const float* __restrict__ A2) {
-  gemm_q_body<TN, 1, KIND, ABIAS, false, false, 0, RM>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
-                                                       QLn{nullptr, nullptr, 0.f}, A2);
+  gemm_q_body<TN, 1, KIND, ABIAS, false, false, 0, RM, PL>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
+                                                           QLn{nullptr, nullptr, 0.f}, A2);
 }
 // the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
-template <int KIND>
+template <int KIND, int PL = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const QConv g, const QOut os, const float* __restrict__ A2) {
-  gemm_q_body<8, 1, KIND, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
-                                              QLn{nullptr, nullptr, 0.f}, A2);
+  gemm_q_body<8, 1, KIND, false, false, true, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
+                                                        QLn{nullptr, nullptr, 0.f}, A2);
 }
 // mixed tiles for N % 256 == 128 (the encoder's merged projection, N = 640): the first N / 256 column
 // tiles of a row tile run the wide body, its last 128 columns the narrow one; the blocks of a row
 // tile stay neighbours on one XCD
+template <int PL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wn_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -906,11 +942,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int row = lb / ntl, c = lb - row * ntl;
   const QLn ln0{nullptr, nullptr, 0.f};
   if (c < nw)
-    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
-                                             nullptr, row * QBM, c * 256);
+    gemm_q_body<8, 1, 0, false, false, true, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
+                                                       nullptr, row * QBM, c * 256);
   else
-    gemm_q_body<4, 1, 0, false, false>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
-                                       nullptr, row * QBM, nw * 256);
+    gemm_q_body<4, 1, 0, false, false, false, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os, ln0,
+                                                        nullptr, row * QBM, nw * 256);
 }
 // The encoder layer's merged projection (N = 640 = value 256 | sampling offsets 256 | attention
 // logits 128, multi_scale_deform_attn.py:357-384) with the sampler's per-(query, head) arithmetic in
@@ -918,6 +954,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // tail as softmaxed attention weights -- with the code the sampling kernel itself uses
 // (pave_enc_math.h), so pave_enc_deform_attn_tile_f32 in its `prepared` mode returns the same bits.
 // These waves are ~25 % VALU-active; the sampler is VALU-bound.
+template <int PL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wn_enc_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* residual,
     const float* __restrict__ value_bias, float* out, const int M, const int K, const QOut os, const QEpi epi) {
@@ -930,14 +967,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const QLn ln0{nullptr, nullptr, 0.f};
   const QConv g{0, 0, 0, 0, 0, 0, 0u};
   if (c == 0)   // (value columns: one bias row instead of 256 table columns per row, when the caller has it)
-    gemm_q_body<8, 1, 0, false, false, true>(A, Wp, value_bias, value_bias ? nullptr : residual, out, M, K, N, 0,
-                                             nullptr, g, os, ln0, nullptr, row * QBM, 0);
+    gemm_q_body<8, 1, 0, false, false, true, 0, 1, PL>(A, Wp, value_bias, value_bias ? nullptr : residual, out, M, K, N, 0,
+                                                       nullptr, g, os, ln0, nullptr, row * QBM, 0);
   else if (c == 1)
-    gemm_q_body<8, 1, 0, false, false, true, 1>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
-                                                ln0, nullptr, row * QBM, 256, &epi);
+    gemm_q_body<8, 1, 0, false, false, true, 1, 1, PL>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
+                                                       ln0, nullptr, row * QBM, 256, &epi);
   else
-    gemm_q_body<4, 1, 0, false, false, false, 2>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
-                                                 ln0, nullptr, row * QBM, 512, &epi);
+    gemm_q_body<4, 1, 0, false, false, false, 2, 1, PL>(A, Wp, nullptr, residual, out, M, K, N, 0, nullptr, g, os,
+                                                        ln0, nullptr, row * QBM, 512, &epi);
 }
 // ---------------------------------------------------------------------------
 // ResNet Bottleneck (64-channel stage) from its 3x3 convolution on, chained with the NEXT block's
@@ -973,7 +1010,7 @@ __device__ __forceinline__ void chain_sync() {
 // CN = outputs of the next conv1 (0: none; 64 | 128: narrow form)
 // RMC = 2: the workgroup carries a 256-row tile -- the 64-column bodies (3x3, a 64-output conv1) as ONE body
 // with two row tiles per wave, the 256- / 128-column bodies as two 128-row halves back to back
-template <bool HAS_A, int KIND2, int CN, int RMC = 1>
+template <bool HAS_A, int KIND2, int CN, int RMC = 1, int PL = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_chain_kernel(
     const ChainArgs p) {
   const QLn ln0{nullptr, nullptr, 0.f};
@@ -984,7 +1021,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int tm0 = (xcd * per + (xcd < rem ? xcd : rem) + idx) * CBM;
   if constexpr (HAS_A) {
-    gemm_q_body<2, 1, 1, false, false, false, 0, RMC>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
+    gemm_q_body<2, 1, 1, false, false, false, 0, RMC, PL>(p.c1, p.w2, p.b2, nullptr, p.c2, p.M, 576, 64, 1, nullptr,
                                                       QConv{p.H, p.W, 64, p.H, p.W, 1, 1u << 30},
                                                       QOut{nullptr, 0, 0, 64, 0}, ln0, nullptr, tm0, 0);
     chain_sync();
@@ -993,14 +1030,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int h = 0; h < RMC; ++h) {
     if (h > 0) PAVE_QBAR();   // (every wave is done with the previous half's epilogue chunks in the ring)
     if (tm0 + h * QBM < p.M)
-      gemm_q_body<8, 1, KIND2, false, false, true>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
+      gemm_q_body<8, 1, KIND2, false, false, true, 0, 1, PL>(p.c2, p.w3, p.b3, p.residual, p.out, p.M, p.K3, 256, 1,
                                                    nullptr, QConv{0, 0, p.k1, 0, 0, 0},
                                                    QOut{nullptr, 0, 0, 256, 0}, ln0, p.a2, tm0 + h * QBM, 0);
   }
   if constexpr (CN > 0) {
     chain_sync();
     if constexpr (CN == 64 && RMC == 2) {
-      gemm_q_body<2, 1, 0, false, false, false, 0, 2>(
+      gemm_q_body<2, 1, 0, false, false, false, 0, 2, PL>(
           p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
           QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0, 0);
     } else {
@@ -1008,7 +1045,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int h = 0; h < RMC; ++h) {
         if (h > 0) PAVE_QBAR();
         if (tm0 + h * QBM < p.M)
-          gemm_q_body<(CN > 0 ? CN / 32 : 2), 1, 0, false, false>(
+          gemm_q_body<(CN > 0 ? CN / 32 : 2), 1, 0, false, false, false, 0, 1, PL>(
               p.out, p.w1n, p.b1n, nullptr, p.c1n, p.M, 256, CN, 1, nullptr, QConv{0, 0, 0, 0, 0, 0},
               QOut{nullptr, 0, 0, CN, 0}, ln0, nullptr, tm0 + h * QBM, 0);
       }
@@ -1023,14 +1060,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // with three sweeps of the accumulators through the LDS chunk (sum, centred squares, normalise)
 // it ran EQUAL, 1.736 vs 1.743 ms at K = 1024 and 0.612 vs 0.615 ms at K = 256: these launches sit
 // on a mixed HBM / MFMA bound that the tile form does not move.  Not kept.)
+template <int PL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_q_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
   // (A first-tile stagger of every other CU -- half a tile of s_sleep, so that main loops and the
   // HBM-heavy LayerNorm epilogues of different CUs interleave instead of running in lockstep -- was
   // measured: 647 -> 729 us at K = 256, equal at K = 1024.  Not kept.)
-  gemm_q_body<4, 2, 0, false, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
-                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
+  gemm_q_body<4, 2, 0, false, true, false, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
+                                                     QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
 
 // LayerNorm epilogue on the wide form: 4 waves, a wave owns 32 whole rows of the N = 256 output (no
@@ -1038,11 +1076,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Round 3 built this with a second register image of the tile (spills) and with LDS sweeps (equal to
 // the 8-wave form); here bias + identity are added and the statistics taken IN the accumulator
 // registers (see LNW in gemm_q_body), which costs no registers and no LDS pass.
+template <int PL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
-  gemm_q_body<8, 1, 0, false, true, true>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
-                                          QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
+  gemm_q_body<8, 1, 0, false, true, true, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
+                                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
 
 // ---------------------------------------------------------------------------
@@ -1076,7 +1115,7 @@ struct StemRows {
   static constexpr int WIN = ((ROWS * SWC + 63) / 64) * 1024;
 };
 
-template <int R>
+template <int R, int PL = 3>
 __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
     const float* __restrict__ x, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     float* __restrict__ y, const int H, const int W, const int Ho, const int Wo, const int relu) {
@@ -1111,17 +1150,17 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
     }
   }
   const uint16_t* wl = Wp + ((long long)lr * 16 + kh * 8);
-  u32x4 wf[2][3][2];
+  u32x4 wf[2][PL][2];
   auto load_w = [&](const int slab, const int set) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PL; ++p)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        wf[set][p][j] = *reinterpret_cast<const u32x4*>(wl + ((slab * 3 + p) * 64 + 32 * j) * 16);
+        wf[set][p][j] = *reinterpret_cast<const u32x4*>(wl + ((slab * PL + p) * 64 + 32 * j) * 16);
   };
   load_w(0, 0);
   const int a_px = (wave * 32 + lr) * 8;
-  u32x4 apl[R][3];
+  u32x4 apl[R][PL];
   // A operand of output row r, slab s: K row 2 s + kh = (c, ky) -> window row WPC c + ky + 2 r (21 -> the zero row)
   auto read_split = [&](const int slab, const int r) {
     const int k0 = 2 * slab, k1 = 2 * slab + 1;
@@ -1132,7 +1171,11 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
     const f32x2 v1 = *reinterpret_cast<const f32x2*>(p + 8);
     const f32x2 v2 = *reinterpret_cast<const f32x2*>(p + 16);
     const f32x2 v3 = *reinterpret_cast<const f32x2*>(p + 24);
-    split8(f32x4{0.f, v0.y, v1.x, v1.y}, f32x4{v2.x, v2.y, v3.x, v3.y}, apl[r]);   // tap kx' = 0: zeroed
+    if constexpr (PL == 3)
+      split8(f32x4{0.f, v0.y, v1.x, v1.y}, f32x4{v2.x, v2.y, v3.x, v3.y}, apl[r]);   // tap kx' = 0: zeroed
+    else
+      apl[r][0] = u32x4{pack_rne_f16(0.f, v0.y), pack_rne_f16(v1.x, v1.y), pack_rne_f16(v2.x, v2.y),
+                        pack_rne_f16(v3.x, v3.y)};
   };
   f32x16 acc[R][2];
 #pragma unroll
@@ -1149,6 +1192,12 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       read_split(s, r);
+      if constexpr (PL == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              __builtin_bit_cast(f16x8, apl[r][0]), __builtin_bit_cast(f16x8, wf[cur][0][j]), acc[r][j], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int o = 2; o >= 0; --o)
 #pragma unroll
@@ -1158,6 +1207,7 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
             acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 __builtin_bit_cast(bf16x8, apl[r][pa]), __builtin_bit_cast(bf16x8, wf[cur][o - pa][j]),
                 acc[r][j], 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the window
@@ -1192,17 +1242,19 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
   }
 }
 
-template <int TN, int KIND, bool ABIAS, int RM = 1>
+template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3>
 int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
              const QOut os, const float* a2 = nullptr, int ksplit = 1) {
   constexpr int BN = TN * 32;
   constexpr int BM = QBM * RM;
-  constexpr int STAGE = BM * 64 + 3 * BN * 32;
-  const int smem = QNS * STAGE + (ABIAS ? K * 4 : 0);
+  constexpr int STAGE = BM * 64 + PL * BN * 32;
+  // (the per-wave epilogue chunks reuse the ring: 4 x 32 rows x QCST floats)
+  constexpr int EPIB = 4 * 32 * QCST * 4;
+  const int smem = (QNS * STAGE > EPIB ? QNS * STAGE : EPIB) + (ABIAS ? K * 4 : 0);
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_q: grid too large");
-  auto kern = gemm_q_kernel<TN, KIND, ABIAS, RM>;
+  auto kern = gemm_q_kernel<TN, KIND, ABIAS, RM, PL>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1256,7 +1308,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
 // bias, full or row-periodic residual, ReLU, zero-padded weight planes (n_real <= N).  The shipped
 // selection uses TN = 1 (32 x 32 per wave) for outputs up to 512 columns.
 // ---------------------------------------------------------------------------
-template <int TN, int PF>
+template <int TN, int PF, int PL = 3>
 __global__ __launch_bounds__(256) void gemm_s_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -1274,19 +1326,19 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
   const float* ap = A + (long long)arow * lda + (group_n > 0 ? (n0 / group_n) * K : 0) + kh * 8;
   // plane row of column n: 16 bf16 = 32 bytes; the lane's half kh
   const uint16_t* wp = Wp + ((long long)(n0 + lr) * 16 + kh * 8);
-  const long long w_plane = (long long)N * 16, w_slab = 3 * w_plane;   // in bf16 elements
+  const long long w_plane = (long long)N * 16, w_slab = PL * w_plane;   // in 16-bit elements
   f32x16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   f32x4 raw[PF][2];
-  u32x4 wf[PF][3][TN];
+  u32x4 wf[PF][PL][TN];
   auto load = [&](const int slab, const int set) {
     raw[set][0] = *reinterpret_cast<const f32x4*>(ap + slab * 16);
     raw[set][1] = *reinterpret_cast<const f32x4*>(ap + slab * 16 + 4);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PL; ++p)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         // (column tiles past the planes' N rows -- N % (32 TN) != 0 -- re-read the last tile: not stored)
@@ -1301,7 +1353,15 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       if (s + u < nslabs) {
-        u32x4 apl[3];
+        u32x4 apl[PL];
+        if constexpr (PL == 1) {
+          apl[0] = u32x4{pack_rne_f16(raw[u][0].x, raw[u][0].y), pack_rne_f16(raw[u][0].z, raw[u][0].w),
+                         pack_rne_f16(raw[u][1].x, raw[u][1].y), pack_rne_f16(raw[u][1].z, raw[u][1].w)};
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(f16x8, apl[0]), __builtin_bit_cast(f16x8, wf[u][0][j]), acc[j], 0, 0, 0);
+        } else {
         split8(raw[u][0], raw[u][1], apl);
         // the products of order o = pa + pb: o = 2, 1, 0 (smallest terms first), as the tile kernels
 #pragma unroll
@@ -1313,6 +1373,7 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                   __builtin_bit_cast(bf16x8, apl[pa]), __builtin_bit_cast(bf16x8, wf[u][o - pa][j]),
                   acc[j], 0, 0, 0);
+        }
         if (s + u + PF < nslabs) load(s + u + PF, u);
       }
     }
@@ -1340,12 +1401,12 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
   }
 }
 
-template <int TN, int PF>
+template <int TN, int PF, int PL = 3>
 int launch_s(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, int lda, int group_n, int res_rows, int n_real,
              hipStream_t st) {
   const long long tiles = ((M + 31) / 32) * ((N + 32 * TN - 1) / (32 * TN));
-  hipLaunchKernelGGL((gemm_s_kernel<TN, PF>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w, bias,
+  hipLaunchKernelGGL((gemm_s_kernel<TN, PF, PL>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w, bias,
                      residual, out, (int)M, K, N, relu, lda, group_n, res_rows, n_real);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
@@ -1354,22 +1415,29 @@ int launch_s(const float* a, const uint16_t* w, const float* bias, const float* 
 constexpr long long kSmallRows = 8192;   // launches with fewer rows take the small-row form
 
 constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
+template <int PL>
+constexpr int w_smem() { return 2 * (QBM * 64 + PL * 256 * 32); }   // (fp16: 2 x 16 KiB; >= the epilogue chunks)
+// the mixed-tile kernels (wide tiles + a 128-column narrow tail with its ring of 3): the larger of the two
+template <int PL>
+constexpr int wn_smem() {
+  return w_smem<PL>() > QNS * (QBM * 64 + PL * 128 * 32) ? w_smem<PL>() : QNS * (QBM * 64 + PL * 128 * 32);
+}
 
-template <int KIND>
+template <int KIND, int PL = 3>
 int launch_w(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, hipStream_t st, const QConv g, const QOut os,
              const float* a2 = nullptr, int ksplit = 1) {
   const long long gx = ((M + QBM - 1) / QBM) * (N / 256);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_w: grid too large");
-  auto kern = gemm_w_kernel<KIND>;
+  auto kern = gemm_w_kernel<KIND, PL>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, w_smem<PL>()) != hipSuccess)
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), W_SMEM, st, a, w, bias,
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), w_smem<PL>(), st, a, w, bias,
                      residual, out, (int)M, K, N, relu, g, os, a2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
@@ -1411,11 +1479,12 @@ int pave_internal_splitk_reduce(const float* ws, int parts, long long M, int n, 
 
 // Internal entries (pave_gemm_split.hip dispatches here).  kind as the kernel's KIND; the geometry
 // is ignored for kind 0.
-int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
-                         const float* residual, long long residual_rows, float* out, float* out2,
-                         int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
-                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real,
-                         int ksplit, int ks_slabs) {
+template <int PL>
+static int gemm_q_dispatch(const float* a, const float* a_bias, const void* w_planes, const float* bias,
+                           const float* residual, long long residual_rows, float* out, float* out2,
+                           int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
+                           int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real,
+                           int ksplit, int ks_slabs) {
   const QConv g{H, W, Cin, Ho, Wo, stride,
                 (kind == 1 && Cin > 16) ? (unsigned)(((1ull << 32) + (Cin >> 4) - 1) / (unsigned)(Cin >> 4)) : 0u};
   const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
@@ -1453,7 +1522,7 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   // 1200 x 256 x 256 + LayerNorm 24 -> 19 us.
   if (kind == 0 && M < kSmallRows && N <= 512 && !a_bias && !out2 && ksplit == 1 &&
       pave_internal_diag_variant() == 0)
-    return launch_s<1, 4>(a, w, bias, residual, out, M, K, N, relu, H > 0 ? H : K, W > 0 ? W : 0, os.res_rows,
+    return launch_s<1, 4, PL>(a, w, bias, residual, out, M, K, N, relu, H > 0 ? H : K, W > 0 ? W : 0, os.res_rows,
                           n_real, st);
   // 3x3 form: buffer-addressed below 4 GiB of map (a lane's byte offset is 32 bits wide)
   // (diag variant 5: the 64-bit lane-address form everywhere, for A/B)
@@ -1461,13 +1530,13 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
                                   pave_internal_diag_variant() == 5);
 #define PAVE_QGO(TN_)                                                                               \
   if (kind == 0) {                                                                                  \
-    if (a_bias) return launch_q<TN_, 0, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
-    return launch_q<TN_, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
+    if (a_bias) return launch_q<TN_, 0, true, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os); \
+    return launch_q<TN_, 0, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
   }                                                                                                 \
-  if (kind == 1 && big3) return launch_q<TN_, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
-  if (kind == 1) return launch_q<TN_, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
-  if (kind == 4) return launch_q<TN_, 4, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2, ksplit); \
-  return launch_q<TN_, 3, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit)
+  if (kind == 1 && big3) return launch_q<TN_, 2, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
+  if (kind == 1) return launch_q<TN_, 1, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit); \
+  if (kind == 4) return launch_q<TN_, 4, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, a2, ksplit); \
+  return launch_q<TN_, 3, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os, nullptr, ksplit)
   // the wide form (32 x 256 per wave): whole 256-column tiles, about one tile per block slot
   // of the chip (2 blocks x 256 CUs) -- below that the narrow form's twice as many tiles fill
   // the CUs better
@@ -1475,11 +1544,11 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   const long long wtiles = ((M + QBM - 1) / QBM) * (N / 256) * ksplit;
   if (N % 256 == 0 && n_real == N && !narrow && !a_bias && dv != 8 && (wtiles >= 400 || dv == 7) &&
       !(kind == 0 && W > 0 && W % 256 != 0) && (!out2 || n_split % 256 == 0)) {
-    if (kind == 0) return launch_w<0>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
-    if (kind == 1 && big3) return launch_w<2>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
-    if (kind == 1) return launch_w<1>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
-    if (kind == 4) return launch_w<4>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
-    return launch_w<3>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 0) return launch_w<0, PL>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 1 && big3) return launch_w<2, PL>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 1) return launch_w<1, PL>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
+    if (kind == 4) return launch_w<4, PL>(a, w, bias, residual, out, M, K, N, relu, st, g, os, a2, ksplit);
+    return launch_w<3, PL>(a, w, bias, residual, out, M, K, N, relu, st, g, os, nullptr, ksplit);
   }
   if (kind == 0 && N % 256 == 128 && N >= 384 && n_real == N && !narrow && !a_bias && dv != 8 && W == 0 && ksplit == 1 &&
       (((M + QBM - 1) / QBM) * (N / 256 + 1) >= 400 || dv == 7) && (!out2 || n_split % 256 == 0)) {
@@ -1487,12 +1556,12 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
     if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_wn: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_kernel<PL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, wn_smem<PL>()) != hipSuccess)
         return pave_internal_fail(PAVE_E_LAUNCH, "gemm_wn: cannot raise dynamic LDS limit");
       attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_wn_kernel, dim3((unsigned)gx), dim3(256), W_SMEM, st, a, w, bias, residual, out,
+    hipLaunchKernelGGL(gemm_wn_kernel<PL>, dim3((unsigned)gx), dim3(256), wn_smem<PL>(), st, a, w, bias, residual, out,
                        (int)M, K, N, relu, g, os);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
@@ -1501,11 +1570,11 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   // 65..96 real outputs in 128-row planes (HRNet's 96-channel branch): three column tiles instead of four
   if (N == 128 && n_real <= 96 && n_real > 64 && !narrow && !out2 && pave_internal_diag_variant() != 8 &&
       ksplit == 1 && (kind == 1 || kind == 0) && !a_bias) {
-    if (kind == 1 && big3) return launch_q<3, 2, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    if (kind == 1 && big3) return launch_q<3, 2, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
     if (kind == 1 && dv != 15 && (((M + 255) / 256) >= 1024 || dv == 16) && (os.res_rows == 0 || os.res_rows >= 64))
-      return launch_q<3, 1, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
-    if (kind == 1) return launch_q<3, 1, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
-    return launch_q<3, 0, false>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+      return launch_q<3, 1, false, 2, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    if (kind == 1) return launch_q<3, 1, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    return launch_q<3, 0, false, 1, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
   if (N % 128 == 0 && !narrow) { PAVE_QGO(4); }
   // 64-column tiles with two row tiles per wave (256-row blocks): only on request (diag variant 16).  Measured
@@ -1515,18 +1584,33 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   // 3x3 (two blocks per CU either way: 442 -> 428 us) and the layer1 chain (-3 ... -4 %) take the form.
   if (N % 64 == 0 && (kind == 0 || (kind == 1 && !big3)) && !a_bias && ksplit == 1 && dv == 16 &&
       (os.res_rows == 0 || os.res_rows >= 64) && (long long)N * 1024 < (1ll << 31)) {
-    if (kind == 1) return launch_q<2, 1, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
-    return launch_q<2, 0, false, 2>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    if (kind == 1) return launch_q<2, 1, false, 2, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+    return launch_q<2, 0, false, 2, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO
   return pave_internal_fail(PAVE_E_ARG, "gemm_q: N %% 64 == 0 required");
 }
 
+int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_planes, const float* bias,
+                         const float* residual, long long residual_rows, float* out, float* out2,
+                         int n_split, long long M, int K, int N, int relu, int kind, int H, int W,
+                         int Cin, int Ho, int Wo, int stride, void* stream, const float* a2, int n_real,
+                         int ksplit, int ks_slabs, int planes) {
+  // planes: 3 = the exact bf16 split, 1 = one plane of fp16 operands (PAVE_PLANES_FP16 at the C ABI)
+  if (planes == 1)
+    return gemm_q_dispatch<1>(a, a_bias, w_planes, bias, residual, residual_rows, out, out2, n_split, M, K, N, relu,
+                              kind, H, W, Cin, Ho, Wo, stride, stream, a2, n_real, ksplit, ks_slabs);
+  if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3 bf16 planes or 1 fp16 plane");
+  return gemm_q_dispatch<3>(a, a_bias, w_planes, bias, residual, residual_rows, out, out2, n_split, M, K, N, relu,
+                            kind, H, W, Cin, Ho, Wo, stride, stream, a2, n_real, ksplit, ks_slabs);
+}
+
 // merged encoder projection with the sampler's softmax / location arithmetic in the epilogue
-int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float* table, long long table_rows,
-                               const float* value_bias, const float* ref, const int* levels_hw, float* value,
-                               float* samp, long long M, int K, void* stream) {
+template <int PL>
+static int gemm_encproj_go(const float* a, const void* w_planes, const float* table, long long table_rows,
+                           const float* value_bias, const float* ref, const int* levels_hw, float* value,
+                           float* samp, long long M, int K, void* stream) {
   if (K % 32 != 0 || K < 64 || K >= (1 << 23)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: K %% 32 == 0, 64 <= K < 2^23");
   QEpi epi{};
   epi.ref = ref;
@@ -1543,35 +1627,44 @@ int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_enc_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wn_enc_kernel<PL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, wn_smem<PL>()) != hipSuccess)
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_encproj: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_wn_enc_kernel, dim3((unsigned)gx), dim3(256), W_SMEM,
+  hipLaunchKernelGGL(gemm_wn_enc_kernel<PL>, dim3((unsigned)gx), dim3(256), wn_smem<PL>(),
                      reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes), table,
                      value_bias, value, (int)M, K, os, epi);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
+int pave_internal_gemm_encproj(const float* a, const void* w_planes, const float* table, long long table_rows,
+                               const float* value_bias, const float* ref, const int* levels_hw, float* value,
+                               float* samp, long long M, int K, void* stream, int planes) {
+  if (planes == 1)
+    return gemm_encproj_go<1>(a, w_planes, table, table_rows, value_bias, ref, levels_hw, value, samp, M, K, stream);
+  if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_encproj: 3 bf16 planes or 1 fp16 plane");
+  return gemm_encproj_go<3>(a, w_planes, table, table_rows, value_bias, ref, levels_hw, value, samp, M, K, stream);
+}
 
-int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
-                            const float* gamma, const float* beta, float eps, float* out, long long M,
-                            int K, int N, void* stream) {
+template <int PL>
+static int gemm_q_ln_go(const float* a, const void* w_planes, const float* bias, const float* residual,
+                        const float* gamma, const float* beta, float eps, float* out, long long M,
+                        int K, int N, void* stream) {
   if (K % 32 != 0 || K < 64 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_q_ln: K %% 32 == 0, K >= 64 and N == 256 required");
   if (M < kSmallRows && pave_internal_diag_variant() == 0) {
     // few rows: the small-row GEMM (bias + identity in its epilogue), then LayerNorm in place -- two
     // launches of a few microseconds instead of 10 row tiles walking K behind barriers
-    const int st1 = launch_s<1, 4>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K,
+    const int st1 = launch_s<1, 4, PL>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K,
                                    0, 0, N, reinterpret_cast<hipStream_t>(stream));
     if (st1 != PAVE_OK) return st1;
     return pave_bias_add_layernorm_f32(out, nullptr, nullptr, gamma, beta, out, M, N, eps, stream);
   }
-  constexpr int STAGE = QBM * 64 + 3 * 256 * 32;
+  constexpr int STAGE = QBM * 64 + PL * 256 * 32;
   constexpr int smem = QNS * STAGE + 2 * QBM * 2 * 4;
-  auto kern = gemm_q_ln_kernel;
+  auto kern = gemm_q_ln_kernel<PL>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1589,12 +1682,12 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   if (dvl != 13 && (gx >= 512 || dvl == 14) && M * 1024ll < (1ll << 32)) {
     static bool attr_w = false;
     if (!attr_w) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w_ln_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w_ln_kernel<PL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, w_smem<PL>()) != hipSuccess)
         return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w_ln: cannot raise dynamic LDS limit");
       attr_w = true;
     }
-    hipLaunchKernelGGL(gemm_w_ln_kernel, dim3((unsigned)gx), dim3(256), W_SMEM,
+    hipLaunchKernelGGL(gemm_w_ln_kernel<PL>, dim3((unsigned)gx), dim3(256), w_smem<PL>(),
                        reinterpret_cast<hipStream_t>(stream), a, static_cast<const uint16_t*>(w_planes),
                        bias, residual, out, (int)M, K, N, QLn{gamma, beta, eps});
     const hipError_t ew = hipGetLastError();
@@ -1608,10 +1701,17 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
+int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* bias, const float* residual,
+                            const float* gamma, const float* beta, float eps, float* out, long long M,
+                            int K, int N, void* stream, int planes) {
+  if (planes == 1) return gemm_q_ln_go<1>(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
+  if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_q_ln: 3 bf16 planes or 1 fp16 plane");
+  return gemm_q_ln_go<3>(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
+}
 
-template <bool HAS_A, int KIND2, int CN, int RMC = 1>
+template <bool HAS_A, int KIND2, int CN, int RMC = 1, int PL = 3>
 static int launch_chain(const ChainArgs& p, hipStream_t st) {
-  auto kern = bottleneck_chain_kernel<HAS_A, KIND2, CN, RMC>;
+  auto kern = bottleneck_chain_kernel<HAS_A, KIND2, CN, RMC, PL>;
   // (the 256-row 64-column body: ring of 3 x 22 KiB)
   constexpr int smem = RMC == 2 ? (3 * (2 * QBM * 64 + 3 * 64 * 32) > W_SMEM ? 3 * (2 * QBM * 64 + 3 * 64 * 32) : W_SMEM) : W_SMEM;
   static bool attr_set = false;
@@ -1628,11 +1728,12 @@ static int launch_chain(const ChainArgs& p, hipStream_t st) {
   return PAVE_OK;
 }
 
-extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const float* b2, float* c2,
-                                         const void* w3_planes, const float* b3, const float* residual,
-                                         const float* a2, int k2, float* out, const void* w1n_planes,
-                                         const float* b1n, float* c1n, int cn, int N, int H, int W,
-                                         void* stream) {
+template <int PL>
+static int bottleneck_chain_go(const float* c1, const void* w2_planes, const float* b2, float* c2,
+                               const void* w3_planes, const float* b3, const float* residual,
+                               const float* a2, int k2, float* out, const void* w1n_planes,
+                               const float* b1n, float* c1n, int cn, int N, int H, int W,
+                               void* stream) {
   if (!c2 || !w3_planes || !out || (c1 != nullptr) != (w2_planes != nullptr))
     return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: null pointer (c1 and w2_planes: both or neither)");
   // (the 3x3 body addresses the c1 map through a buffer resource: below 4 GiB)
@@ -1653,34 +1754,47 @@ extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define PAVE_CHAIN_GO(HA)                                              \
   if (a2) {                                                            \
-    if (cn == 64) return launch_chain<HA, 4, 64>(p, st);               \
-    if (cn == 128) return launch_chain<HA, 4, 128>(p, st);             \
-    return launch_chain<HA, 4, 0>(p, st);                              \
+    if (cn == 64) return launch_chain<HA, 4, 64, 1, PL>(p, st);               \
+    if (cn == 128) return launch_chain<HA, 4, 128, 1, PL>(p, st);             \
+    return launch_chain<HA, 4, 0, 1, PL>(p, st);                              \
   }                                                                    \
-  if (cn == 64) return launch_chain<HA, 0, 64>(p, st);                 \
-  if (cn == 128) return launch_chain<HA, 0, 128>(p, st);               \
-  return launch_chain<HA, 0, 0>(p, st)
+  if (cn == 64) return launch_chain<HA, 0, 64, 1, PL>(p, st);                 \
+  if (cn == 128) return launch_chain<HA, 0, 128, 1, PL>(p, st);               \
+  return launch_chain<HA, 0, 0, 1, PL>(p, st)
   // from two 256-row tiles per block slot of the chip on: 256-row tiles (the 3x3 and a 64-output conv1 with two
   // row tiles per wave); diag variant 15: never, 16: always
   const int dvc = pave_internal_diag_variant();
   if (c1 && cn > 0 && dvc != 15 && (p.M >= 256 * 1024 || dvc == 16)) {
     if (a2) {
-      if (cn == 64) return launch_chain<true, 4, 64, 2>(p, st);
-      return launch_chain<true, 4, 128, 2>(p, st);
+      if (cn == 64) return launch_chain<true, 4, 64, 2, PL>(p, st);
+      return launch_chain<true, 4, 128, 2, PL>(p, st);
     }
-    if (cn == 64) return launch_chain<true, 0, 64, 2>(p, st);
-    return launch_chain<true, 0, 128, 2>(p, st);
+    if (cn == 64) return launch_chain<true, 0, 64, 2, PL>(p, st);
+    return launch_chain<true, 0, 128, 2, PL>(p, st);
   }
   if (c1) { PAVE_CHAIN_GO(true); }
   PAVE_CHAIN_GO(false);
 #undef PAVE_CHAIN_GO
 }
 
+extern "C" int pave_bottleneck_chain_f32(const float* c1, const void* w2_planes, const float* b2, float* c2,
+                                         const void* w3_planes, const float* b3, const float* residual,
+                                         const float* a2, int k2, float* out, const void* w1n_planes,
+                                         const float* b1n, float* c1n, int cn, int N, int H, int W,
+                                         int nplanes, void* stream) {
+  if (nplanes == PAVE_PLANES_FP16)
+    return bottleneck_chain_go<1>(c1, w2_planes, b2, c2, w3_planes, b3, residual, a2, k2, out, w1n_planes, b1n, c1n,
+                                  cn, N, H, W, stream);
+  if (nplanes != 3) return pave_internal_fail(PAVE_E_ARG, "bottleneck_chain: nplanes must be 3 or PAVE_PLANES_FP16");
+  return bottleneck_chain_go<3>(c1, w2_planes, b2, c2, w3_planes, b3, residual, a2, k2, out, w1n_planes, b1n, c1n,
+                                cn, N, H, W, stream);
+}
+
 // Stem: w_stem = the 11-slab (c, ky, kx' = kx + 1) planes [11][3][64][16]; requires W % 4 == 0 and
 // a 16-byte aligned image base (LDS-DMA chunks); the caller falls back to the first-generation
 // kernel otherwise.
 int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bias, float* y, int N,
-                            int H, int W, int relu, void* stream) {
+                            int H, int W, int relu, void* stream, int planes) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long gx = (long long)N * Ho * ((Wo + SBM - 1) / SBM);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "stem7x7: grid too large");
@@ -1689,9 +1803,14 @@ int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bia
 #endif
   constexpr int R = PAVE_STEM_ROWS;
   const long long g2 = (long long)N * ((Ho + R - 1) / R) * ((Wo + SBM - 1) / SBM);
-  hipLaunchKernelGGL(stem7x7_qr_kernel<R>, dim3((unsigned)g2), dim3(192), StemRows<R>::WIN,
-                     reinterpret_cast<hipStream_t>(stream), x, static_cast<const uint16_t*>(w_stem), bias,
-                     y, H, W, Ho, Wo, relu);
+  if (planes == 1)
+    hipLaunchKernelGGL((stem7x7_qr_kernel<R, 1>), dim3((unsigned)g2), dim3(192), StemRows<R>::WIN,
+                       reinterpret_cast<hipStream_t>(stream), x, static_cast<const uint16_t*>(w_stem), bias,
+                       y, H, W, Ho, Wo, relu);
+  else
+    hipLaunchKernelGGL((stem7x7_qr_kernel<R, 3>), dim3((unsigned)g2), dim3(192), StemRows<R>::WIN,
+                       reinterpret_cast<hipStream_t>(stream), x, static_cast<const uint16_t*>(w_stem), bias,
+                       y, H, W, Ho, Wo, relu);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -624,17 +624,20 @@ int pave_split_bf16x3_f32(const float* x, void* planes, long long n, int nplanes
 static int gemm_split_entry(const float* a, const float* a_bias, const void* w_planes,
                             const float* bias, const float* residual, float* out, long long M,
                             int K, int N, int relu, int nplanes, void* stream, OutSplit os);
+// nplanes of the C ABI -> the LDS-DMA generation's operand planes (3 | 1 = fp16), 0 = not one of its modes
+static inline int q_planes(int nplanes) { return nplanes == 3 ? 3 : (nplanes == PAVE_PLANES_FP16 ? 1 : 0); }
 
 int pave_gemm_bf16x3_encproj_f32(const float* a, const void* w_planes, const float* table,
                                  long long table_rows, const float* value_bias, const float* ref,
                                  const int* levels_hw, float* value, float* samp, long long M, int K,
-                                 void* stream) {
+                                 int nplanes, void* stream) {
   if (!a || !w_planes || !table || !ref || !levels_hw || !value || !samp)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: null pointer");
   if (M <= 0 || M >= (1ll << 31) || table_rows <= 0 || table_rows >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: bad sizes (0 < M, table_rows < 2^31)");
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_encproj: nplanes must be 3 or PAVE_PLANES_FP16");
   return pave_internal_gemm_encproj(a, w_planes, table, table_rows, value_bias, ref, levels_hw, value, samp, M, K,
-                                    stream);
+                                    stream, q_planes(nplanes));
 }
 
 int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_planes,
@@ -668,10 +671,11 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
   // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip) takes K %% 32 == 0 and any
   // N %% 4 == 0 -- the weight planes then carry roundup(N, 64) rows (zero rows beyond N), out / bias /
   // residual have N columns.  The kernels of this file keep the 1- / 2-plane and fp16 modes.
-  if (nplanes == 3 && g_diag_variant != 9 && K % 32 == 0 && K >= 64 && N % 4 == 0 &&
+  if (q_planes(nplanes) && g_diag_variant != 9 && K % 32 == 0 && K >= 64 && N % 4 == 0 &&
       (N % 64 == 0 || !os.out2))
     return pave_internal_gemm_q(a, a_bias, w_planes, bias, residual, os.res_rows, out, os.out2, os.nsplit,
-                                M, K, (N + 63) / 64 * 64, relu, 0, 0, 0, 0, 0, 0, 0, stream, nullptr, N);
+                                M, K, (N + 63) / 64 * 64, relu, 0, 0, 0, 0, 0, 0, 0, stream, nullptr, N, 1, 0,
+                                q_planes(nplanes));
   if (K % 64 != 0 || (N % 128 != 0 && !(N == 64 && nplanes == 3 && !os.out2)))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: K %% 64 == 0 and N %% 128 == 0 (or N == 64 "
                                           "with 3 planes) required");
@@ -716,19 +720,20 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
 
 int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, const void* w_planes,
                              const float* bias, const float* residual, float* out, long long M, int K,
-                             int N, int relu, void* stream) {
+                             int N, int relu, int nplanes, void* stream) {
   if (!a || !a2 || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: null pointer");
   if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: bad sizes (0 < M < 2^31)");
   if (K % 32 != 0 || K < 64 || N % 64 != 0 || K1 <= 0 || K1 >= K || K1 % 16 != 0)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: K %% 32 == 0, N %% 64 == 0, 0 < K1 < K, K1 %% 16 == 0");
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_cat: nplanes must be 3 or PAVE_PLANES_FP16");
   return pave_internal_gemm_q(a, nullptr, w_planes, bias, residual, 0, out, nullptr, 0, M, K, N, relu, 4,
-                              0, 0, (int)K1, 0, 0, 0, stream, a2);
+                              0, 0, (int)K1, 0, 0, 0, stream, a2, 0, 1, 0, q_planes(nplanes));
 }
 
 int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_planes, const float* bias,
                                  float* out, long long M, int K, int N, int group_n, int relu,
-                                 void* stream) {
+                                 int nplanes, void* stream) {
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: null pointer");
   if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0 || group_n <= 0)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: bad sizes (0 < M < 2^31)");
@@ -738,21 +743,24 @@ int pave_gemm_bf16x3_grouped_f32(const float* a, long long lda, const void* w_pl
                                           "groups * K <= lda < 2^23 (a tile's 127 rows x lda x 4 B is a 32-bit lane offset), lda %% 4 == 0");
   // column tiles must not straddle a group: 128-wide tiles need group_n %% 128 == 0
   const int np = (N % 128 == 0 && group_n % 128 == 0) ? N : -N;
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_grouped: nplanes must be 3 or PAVE_PLANES_FP16");
   return pave_internal_gemm_q(a, nullptr, w_planes, bias, nullptr, 0, out, nullptr, 0, M, K, np, relu, 0,
-                              (int)lda, group_n, 0, 0, 0, 0, stream);
+                              (int)lda, group_n, 0, 0, 0, 0, stream, nullptr, 0, 1, 0, q_planes(nplanes));
 }
 
 int pave_gemm_bf16x3_ln_f32(const float* a, const void* w_planes, const float* bias,
                             const float* residual, const float* gamma, const float* beta, float eps,
-                            float* out, long long M, int K, int N, void* stream) {
+                            float* out, long long M, int K, int N, int nplanes, void* stream) {
   if (!a || !w_planes || !out || !gamma || !beta)
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: null pointer");
   if (M <= 0 || K <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: bad sizes (0 < M < 2^31)");
   if (K % 64 != 0 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_bf16x3_ln: K %% 64 == 0 and N == 256 required");
-  if (g_diag_variant != 9)
-    return pave_internal_gemm_q_ln(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_ln: nplanes must be 3 or PAVE_PLANES_FP16");
+  if (g_diag_variant != 9 || nplanes != 3)
+    return pave_internal_gemm_q_ln(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream,
+                                   q_planes(nplanes));
   return launch_gemm<2, 2, false, 3, false, false, true, 4, true>(
       a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, nullptr,
       reinterpret_cast<hipStream_t>(stream), ConvGeom{0, 0, 0, 0, 0, 0}, OutSplit{nullptr, 0, 0},
@@ -776,7 +784,7 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: bad sizes (stride 1 or 2)");
   const bool padded = Cin % 64 != 0 || Cout % 64 != 0;   // zero-padded weight planes: 3-plane DMA kernel only
   if (Cin <= 0 || Cout <= 0 || Cin % 16 != 0 || Cout % 4 != 0 ||
-      ((padded || residual) && (nplanes != 3 || g_diag_variant == 9)))
+      ((padded || residual) && (!q_planes(nplanes) || g_diag_variant == 9)))
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: Cin %% 16 == 0 and Cout %% 4 == 0 (3 planes; the other "
                                           "modes: Cin, Cout %% 64 == 0, no residual) required");
   if ((nplanes < 1 || nplanes > 3) && nplanes != PAVE_PLANES_FP16)
@@ -785,10 +793,10 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
   const long long M = (long long)N * Ho * Wo;
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: tensor too large");
-  if (nplanes == 3 && g_diag_variant != 9)   // K = 9 Cin padded to a multiple of 32, Cout to one of 64
+  if (q_planes(nplanes) && g_diag_variant != 9)   // K = 9 Cin padded to a multiple of 32, Cout to one of 64
     return pave_internal_gemm_q(x, nullptr, w_planes, bias, residual, 0, y, nullptr, 0, M,
                                 (9 * Cin + 31) / 32 * 32, (Cout + 63) / 64 * 64, relu, 1, H, W, Cin, Ho,
-                                Wo, stride, stream, nullptr, Cout);
+                                Wo, stride, stream, nullptr, Cout, 1, 0, q_planes(nplanes));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint16_t* w = static_cast<const uint16_t*>(w_planes);
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};
@@ -823,7 +831,7 @@ long long pave_conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int 
 int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* bias,
                             const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                             int stride, int relu, void* workspace, long long workspace_bytes,
-                            void* stream) {
+                            int nplanes, void* stream) {
   if (!x || !w_planes || !y || !workspace)
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: null pointer");
   const long long need = pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride);
@@ -838,15 +846,17 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
   int parts, per;
   pave_internal_splitk_plan(M, Kp, Np, &parts, &per);
   float* ws = static_cast<float*>(workspace);
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: nplanes must be 3 or PAVE_PLANES_FP16");
   const int rc = pave_internal_gemm_q(x, nullptr, w_planes, nullptr, nullptr, 0, ws, nullptr, 0, M, Kp, Np, 0,
-                                      1, H, W, Cin, Ho, Wo, stride, stream, nullptr, Cout, parts, per);
+                                      1, H, W, Cin, Ho, Wo, stride, stream, nullptr, Cout, parts, per,
+                                      q_planes(nplanes));
   if (rc != PAVE_OK) return rc;
   return pave_internal_splitk_reduce(ws, parts, M, Cout, bias, residual, relu, y, stream);
 }
 
 int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                    int N, int H, int W, int Cin, int Cout, int stride, int relu,
-                                   void* stream) {
+                                   int nplanes, void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: null pointer");
   if (N <= 0 || H <= 0 || W <= 0 || stride < 1 || stride > 4)
     return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: bad sizes (1 <= stride <= 4)");
@@ -857,9 +867,11 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
   if (M >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: tensor too large");
   // (the LDS-DMA kernel addresses the strided pixels with 32-bit byte offsets from x)
-  if (g_diag_variant != 9 && (long long)N * H * W * Cin * 4 < (1ll << 32))
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "conv1x1_strided_split: nplanes must be 3 or PAVE_PLANES_FP16");
+  if ((g_diag_variant != 9 || nplanes != 3) && (long long)N * H * W * Cin * 4 < (1ll << 32))
     return pave_internal_gemm_q(x, nullptr, w_planes, bias, nullptr, 0, y, nullptr, 0, M, Cin, Cout, relu,
-                                3, H, W, Cin, Ho, Wo, stride, stream);
+                                3, H, W, Cin, Ho, Wo, stride, stream, nullptr, 0, 1, 0, q_planes(nplanes));
+  if (nplanes != 3) return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv1x1_strided_split: fp16 operands need a map below 4 GiB");
   const ConvGeom g{H, W, Cin, Ho, Wo, stride};
   return launch_gemm<2, 2, false, 3, false, 0, true>(x, static_cast<const uint16_t*>(w_planes), bias,
                                                      nullptr, y, M, Cin, Cout, relu, nullptr,
@@ -867,7 +879,7 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
 }
 
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                                  int N, int H, int W, int Cout, int relu, void* stream) {
+                                  int N, int H, int W, int Cout, int relu, int nplanes, void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: null pointer");
   if (N <= 0 || H <= 0 || W < 8) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: bad sizes (W >= 8)");
   if (Cout != 64)
@@ -879,9 +891,12 @@ int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const fl
   // w_planes holds two layouts of the same weights (ops.split_stem7x7_weight): 12 slabs
   // (c, ky, kx | pad) for the kernel of this file, then 11 slabs (c, ky, kx + 1) for the LDS-window
   // kernel of pave_gemm_dma.hip, which needs 16-byte aligned image rows
-  if (g_diag_variant != 9 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-    return pave_internal_stem7x7_q(x, static_cast<const uint16_t*>(w_planes) + 12 * 3 * 64 * 16, bias, y,
-                                   N, H, W, relu, stream);
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: nplanes must be 3 or PAVE_PLANES_FP16");
+  if ((g_diag_variant != 9 || nplanes != 3) && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    return pave_internal_stem7x7_q(x, static_cast<const uint16_t*>(w_planes) + 12 * q_planes(nplanes) * 64 * 16, bias, y,
+                                   N, H, W, relu, stream, q_planes(nplanes));
+  if (nplanes != 3)
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: fp16 operands need W %% 4 == 0 and a 16-byte aligned image");
   const ConvGeom g{H, W, 3, Ho, Wo, 2};
   return launch_gemm<2, 1, false, 3, false, 2, true>(x, static_cast<const uint16_t*>(w_planes), bias,
                                                      nullptr, y, M, 192, Cout, relu, nullptr,

@@ -203,7 +203,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         logits Linears read the layer input ONCE, as one N = 640 GEMM whose epilogue adds the
         per-token table [b_v | pos W_cat^T + b_cat] (row m -> token m % S) and writes value and
         projections as two dense matrices.  No `query + query_pos` pass, no second read of q."""
-        from .bricks import _split_weight, get_gemm_mode
+        from .bricks import _split_weight, fused_mode, get_gemm_mode
         bs, S, C = q.shape
         w_all, w_cat, b_cat = self._merged_proj()
         nv = self.value_proj.out_features
@@ -223,7 +223,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         ref = reference_points.reshape(1, bs * S, self.num_levels, 2)
         if not ref.is_contiguous():
             ref = ref.contiguous()
-        if get_gemm_mode() == 'bf16x3' and self.prepare_in_gemm and nv == 256 and w_all.shape[0] == 640:
+        if fused_mode() and self.prepare_in_gemm and nv == 256 and w_all.shape[0] == 640:
             # the sampler's softmax / location arithmetic runs in this GEMM's epilogue (its waves are
             # ~25 % VALU-active, the sampler is VALU-bound): same code, same bits (pave_enc_math.h)
             v, samp = ops.gemm_bf16x3_encproj(q.reshape(bs * S, C), _split_weight(w_all), table, ref,
@@ -665,10 +665,11 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
         ref = reference_points.reshape(T, N * num_query, L, 2)
         if _fused_ok(self, q, v) and L == 4 and P == 4:
             hit = self.__dict__.get('_pave_unit_clip')   # (the head passes one cached index tensor)
-            if hit is None or hit[0] is not clip_index or hit[1] != num_query:
-                hit = (clip_index, num_query, clip_index.to(torch.int32).repeat_interleave(num_query))
+            ukey = SourceKey((clip_index,), num_query)   # (identity AND version: an index rewritten in place)
+            if hit is None or hit[0] != ukey:
+                hit = (ukey, clip_index.to(torch.int32).repeat_interleave(num_query))
                 self.__dict__['_pave_unit_clip'] = hit
-            unit_clip = hit[2]
+            unit_clip = hit[1]
             out = ops.deform_attn_grid_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
                 proj, ref if ref.is_contiguous() else ref.contiguous(), T=T, n_clips=n_clips,

@@ -37,21 +37,21 @@ SIGNATURES = {
     'pave_gemm_bf16x3_ex_f32': [_vp] * 5 + [ctypes.c_longlong, _vp, _vp, _c_int, ctypes.c_longlong]
                                + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_cat_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,
-                                 _c_int, _vp],
+                                 _c_int, _c_int, _vp],
     'pave_gemm_bf16x3_grouped_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,
-                                     _c_int, _c_int, _vp],
-    'pave_gemm_bf16x3_ln_f32': [_vp] * 6 + [ctypes.c_float, _vp, ctypes.c_longlong, _c_int, _c_int, _vp],
+                                     _c_int, _c_int, _c_int, _vp],
+    'pave_gemm_bf16x3_ln_f32': [_vp] * 6 + [ctypes.c_float, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp],
     'pave_groupnorm_nhwc_f32': [_vp] * 4 + [ctypes.c_longlong] + [_c_int] * 4 + [ctypes.c_float, _vp,
                                 _c_int, _vp, _vp],
     'pave_ref_update_f32': [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_float, _vp],
-    'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 5 + [_vp],
-    'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
+    'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 6 + [_vp],
+    'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
-    'pave_bottleneck_chain_f32': [_vp] * 8 + [_c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp],
-    'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _vp],
+    'pave_bottleneck_chain_f32': [_vp] * 8 + [_c_int, _vp, _vp, _vp, _vp] + [_c_int] * 5 + [_vp],
+    'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _c_int, _vp],
     'pave_gemm_bf16x3_encproj_f32': [_vp, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp,
-                                     ctypes.c_longlong, _c_int, _vp],
+                                     ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_conv3x3s2_c3_nchw_f32': [_vp] * 4 + [_c_int] * 4 + [_vp],
     'pave_mha_core_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_topk_rows_f32': [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
@@ -64,7 +64,7 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 16  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 17  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

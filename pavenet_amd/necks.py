@@ -58,7 +58,7 @@ class ChannelMapper(BaseModule):
         GEMM through the hand-written split-operand kernel, when the GEMM mode and the shape take
         it (bricks.split_gemm_ok / split_conv_weight); None otherwise (library convolution)."""
         from . import ops
-        from .bricks import (get_gemm_mode, linear_rows, small_split_ok, split_conv_weight,
+        from .bricks import (fused_mode, get_gemm_mode, linear_rows, small_split_ok, split_conv_weight,
                              split_gemm_ok)
         if conv.groups != 1 or conv.dilation != (1, 1) or conv.bias is not None \
                 or torch.is_grad_enabled():
@@ -76,7 +76,7 @@ class ChannelMapper(BaseModule):
                 conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
             s_ = conv.stride[0]
             if n * ((h - 1) // s_ + 1) * ((w - 1) // s_ + 1) < 16384 and \
-                    (get_gemm_mode() != 'bf16x3' or 9 * c < 8192):
+                    (not fused_mode() or 9 * c < 8192):
                 # too few 128-row tiles to fill 256 CUs: the library's split-K wins (the 3-plane
                 # kernel has its own split-K form from K = 8192 on: ops.conv3x3_split)
                 return None

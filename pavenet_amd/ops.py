@@ -73,6 +73,28 @@ def _dev(t, name, dtype=None):
     return t
 
 
+PLANES_FP16 = 16   # include/pave_hip.h PAVE_PLANES_FP16: one plane of fp16 operands
+
+
+def _planes(w_planes, name='w_planes', fp16=False, only=None):
+    """Checks a split-weight operand and returns the C ABI's `nplanes` for it: int16 tensors hold
+    shape[1] bf16 planes, float16 tensors ONE plane of fp16 operands (split_weight_bf16x3(..., PLANES_FP16));
+    `fp16=True` with an int16 single plane = the same bits under the old dtype.  only: allowed values."""
+    _dev(w_planes, name)
+    _require(w_planes.dtype in (torch.int16, torch.float16), f'{name} must be int16 (bf16 planes) or float16 (fp16 plane)')
+    _require(w_planes.dim() == 4 and w_planes.shape[3] == 16, f'{name}: [K/16, planes, N, 16] (split_weight_bf16x3)')
+    if w_planes.dtype == torch.float16 or fp16:
+        _require(w_planes.shape[1] == 1, f'{name}: fp16 operands are a single plane')
+        n = PLANES_FP16
+    else:
+        n = int(w_planes.shape[1])
+    _require(only is None or n in only, f'{name}: this entry point takes 3 bf16 planes or one fp16 plane')
+    return n
+
+
+_Q_PLANES = (3, PLANES_FP16)   # the modes of the LDS-DMA generation (every fused form)
+
+
 def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                            sampling_locations, attention_weights, im2col_step=64):
     """[R1] value [bs,S,M,D], shapes [L,2] i64, lsi [L] i64, loc [bs,Lq,M,L,P,2],
@@ -425,10 +447,10 @@ def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None):
     lib = native.load()
     for t, nm in ((a, 'a'), (table, 'table'), (ref, 'ref')):
         _dev(t, nm, torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
+    npl = _planes(w_planes, only=_Q_PLANES)
     M, K = a.shape
-    _require(w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[2] == 640
-             and w_planes.shape[0] * 16 == K, 'gemm_bf16x3_encproj: w_planes [K/16, 3, 640, 16]')
+    _require(w_planes.shape[2] == 640 and w_planes.shape[0] * 16 == K,
+             'gemm_bf16x3_encproj: w_planes [K/16, planes, 640, 16]')
     _require(table.dim() == 2 and table.shape[1] == 640 and ref.numel() == M * 8,
              'gemm_bf16x3_encproj: table [rows, 640], ref [M, 4, 2]')
     _require(len(levels_hw) == 4, 'gemm_bf16x3_encproj: four (h, w) levels')
@@ -445,7 +467,7 @@ def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None):
                                               value_bias.data_ptr() if value_bias is not None else None,
                                               ref.data_ptr(),
                                               ctypes.cast(hw_arr, ctypes.c_void_p), value.data_ptr(),
-                                              samp.data_ptr(), M, K, _stream_ptr())
+                                              samp.data_ptr(), M, K, npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_encproj')
     return value, samp
 
@@ -573,9 +595,6 @@ def bias_relu_maxpool_nhwc(x, bias):
     return y.permute(0, 3, 1, 2)
 
 
-PLANES_FP16 = 16   # include/pave_hip.h PAVE_PLANES_FP16: one plane of fp16 operands
-
-
 def split_bf16x3(x, planes=3):
     """fp32 tensor -> int16 tensor [planes, *x.shape] of bf16 bit patterns: truncation terms, the
     last rounded to nearest (planes = 3: x == p0 + p1 + p2 exactly).  planes = PLANES_FP16: one
@@ -589,7 +608,7 @@ def split_bf16x3(x, planes=3):
         st = lib.pave_split_bf16x3_f32(x.data_ptr(), out.data_ptr(), x.numel(), planes,
                                        _stream_ptr())
     native.check(st, 'split_bf16x3')
-    return out
+    return out.view(torch.float16) if planes == PLANES_FP16 else out
 
 
 def split_weight_bf16x3(weight, planes=3, pad=False):
@@ -622,20 +641,18 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     (split_weight_bf16x3(..., pad=True)); out / bias / residual then have n_out columns."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
-    _require(not fp16 or w_planes.shape[1] == 1, 'gemm_bf16x3: fp16 takes a single plane')
-    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
-             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+    npl = _planes(w_planes, fp16=fp16)
+    _require(a.dim() == 2 and w_planes.shape[1] in (1, 2, 3) and w_planes.shape[0] * 16 == a.shape[1],
              'gemm_bf16x3: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
     N = w_planes.shape[2]
     if n_out is not None and n_out != N:
-        _require(w_planes.shape[1] == 3 and n_out % 4 == 0 and (n_out + 63) // 64 * 64 == N,
-                 'gemm_bf16x3: n_out % 4 == 0 with 3 planes padded to roundup(n_out, 64) rows')
+        _require(npl in _Q_PLANES and n_out % 4 == 0 and (n_out + 63) // 64 * 64 == N,
+                 'gemm_bf16x3: n_out % 4 == 0 with 3 planes / fp16 padded to roundup(n_out, 64) rows')
         N = int(n_out)
     else:
-        _require(N % 128 == 0 or (N % 64 == 0 and w_planes.shape[1] == 3),
-                 'gemm_bf16x3: N % 128 == 0 (or N % 64 == 0 with 3 planes)')
+        _require(N % 128 == 0 or (N % 64 == 0 and npl in _Q_PLANES),
+                 'gemm_bf16x3: N % 128 == 0 (or N % 64 == 0 with 3 planes / fp16)')
     for t, nm, n in ((bias, 'bias', N), (a_bias, 'a_bias', K)):
         if t is not None:
             _dev(t, nm, torch.float32)
@@ -651,8 +668,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
-                                      ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)),
-                                      PLANES_FP16 if fp16 else int(w_planes.shape[1]),
+                                      ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)), npl,
                                       _stream_ptr())
     native.check(st, 'gemm_bf16x3')
     return out
@@ -666,13 +682,12 @@ def gemm_bf16x3_cat(a, a2, w_planes, bias=None, residual=None, relu=False, out=N
     lib = native.load()
     _dev(a, 'a', torch.float32)
     _dev(a2, 'a2', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
+    npl = _planes(w_planes, only=_Q_PLANES)
     _require(a.dim() == 2 and a2.dim() == 2 and a.shape[0] == a2.shape[0],
              'gemm_bf16x3_cat: a [M, K1], a2 [M, K2]')
     M, K1 = a.shape
     K = K1 + a2.shape[1]
-    _require(w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[3] == 16
-             and w_planes.shape[0] * 16 == K, 'gemm_bf16x3_cat: w_planes [(K1+K2)/16, 3, N, 16]')
+    _require(w_planes.shape[0] * 16 == K, 'gemm_bf16x3_cat: w_planes [(K1+K2)/16, 3, N, 16]')
     N = w_planes.shape[2]
     _require(K % 32 == 0 and N % 64 == 0 and K1 % 16 == 0, 'gemm_bf16x3_cat: K % 32, N % 64, K1 % 16')
     if bias is not None:
@@ -690,7 +705,7 @@ def gemm_bf16x3_cat(a, a2, w_planes, bias=None, residual=None, relu=False, out=N
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'cat', f'k1={K1}')):
         st = lib.pave_gemm_bf16x3_cat_f32(a.data_ptr(), K1, a2.data_ptr(), w_planes.data_ptr(),
                                           ptr(bias), ptr(residual), out.data_ptr(), M, K, N,
-                                          int(bool(relu)), _stream_ptr())
+                                          int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_cat')
     return out
 
@@ -701,9 +716,8 @@ def gemm_bf16x3_grouped(a, w_planes, bias, group_n, relu=False):
     out[:, i*group_n:(i+1)*group_n] = act(a_i @ W_i^T + bias_i).  One launch for G Linears."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
-    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3 and w_planes.shape[3] == 16,
-             'gemm_bf16x3_grouped: a [M, G*K], w_planes [K/16, 3, N, 16]')
+    npl = _planes(w_planes, only=_Q_PLANES)
+    _require(a.dim() == 2, 'gemm_bf16x3_grouped: a [M, G*K], w_planes [K/16, 3, N, 16]')
     M, lda = a.shape
     K, N = w_planes.shape[0] * 16, w_planes.shape[2]
     G = N // int(group_n)
@@ -716,7 +730,7 @@ def gemm_bf16x3_grouped(a, w_planes, bias, group_n, relu=False):
         st = lib.pave_gemm_bf16x3_grouped_f32(a.data_ptr(), lda, w_planes.data_ptr(),
                                               bias.data_ptr() if bias is not None else None,
                                               out.data_ptr(), M, K, N, int(group_n), int(bool(relu)),
-                                              _stream_ptr())
+                                              npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_grouped')
     return out
 
@@ -729,10 +743,9 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
     _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv1x1_strided_split: fp32 4-D')
     _require(x.is_contiguous(memory_format=torch.channels_last),
              'conv1x1_strided_split: channels_last input')
-    _dev(w_planes, 'w_planes', torch.int16)
+    npl = _planes(w_planes, only=_Q_PLANES)
     N, Cin, H, W = x.shape
-    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == Cin and w_planes.shape[1] == 3
-             and w_planes.shape[3] == 16, 'conv1x1_strided_split: w_planes [Cin/16, 3, Cout, 16]')
+    _require(w_planes.shape[0] * 16 == Cin, 'conv1x1_strided_split: w_planes [Cin/16, 3, Cout, 16]')
     Cout = w_planes.shape[2]
     if bias is not None:
         _dev(bias, 'bias', torch.float32)
@@ -742,7 +755,7 @@ def conv1x1_strided_split(x, w_planes, bias=None, stride=2, relu=False):
     with torch.cuda.device(x.device), _Timed('conv1x1_strided', 2 * N * Ho * Wo * Cin * Cout, (N * Ho * Wo, Cin, Cout, f's{stride}')):
         st = lib.pave_conv1x1_strided_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
-            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), _stream_ptr())
+            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'conv1x1_strided_split')
     return y.permute(0, 3, 1, 2)
 
@@ -770,19 +783,21 @@ def conv3x3s2_c3_nchw(x, w_taps, bias=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def split_stem7x7_weight(weight):
+def split_stem7x7_weight(weight, planes=3):
     """Stem weight [64, 3, 7, 7] -> operand of conv7x7s2_nchw_split, int16 [23, 3, 64, 16]: the 3
     bf16 planes in two K layouts (include/pave_hip.h): 12 slabs of (c, ky, kx | pad) (K = 192)
-    followed by 11 slabs of (c, ky, kx + 1) with a zero 22nd row (K = 176)."""
+    followed by 11 slabs of (c, ky, kx + 1) with a zero 22nd row (K = 176).  planes = PLANES_FP16:
+    float16 [23, 1, 64, 16], one plane of fp16 operands in the same two layouts."""
     _require(tuple(weight.shape[1:]) == (3, 7, 7), 'split_stem7x7_weight: weight [Cout, 3, 7, 7]')
+    _require(planes in _Q_PLANES, 'split_stem7x7_weight: 3 bf16 planes or PLANES_FP16')
     co = weight.shape[0]
     w = torch.zeros((co, 24, 8), dtype=torch.float32, device=weight.device)
     w[:, :21, :7] = weight.reshape(co, 21, 7)
-    a = split_weight_bf16x3(w.reshape(co, 192).contiguous(), 3)
+    a = split_weight_bf16x3(w.reshape(co, 192).contiguous(), planes)
     w2 = torch.zeros((co, 22, 8), dtype=torch.float32, device=weight.device)
     w2[:, :21, 1:] = weight.reshape(co, 21, 7)
-    pl = split_bf16x3(w2.reshape(co, 176).contiguous(), 3)              # [3, co, 176]
-    b = pl.view(3, co, 11, 16).permute(2, 0, 1, 3).contiguous()
+    pl = split_bf16x3(w2.reshape(co, 176).contiguous(), planes)          # [planes, co, 176]
+    b = pl.view(pl.shape[0], co, 11, 16).permute(2, 0, 1, 3).contiguous()
     return torch.cat([a, b], 0)
 
 
@@ -791,10 +806,9 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
     3-plane split kernel -> [N, 64, Ho, Wo] channels_last."""
     lib = native.load()
     _dev(x, 'x', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
+    npl = _planes(w_planes, only=_Q_PLANES)
     _require(x.dim() == 4 and x.shape[1] == 3, 'conv7x7s2_nchw_split: x [N, 3, H, W] (NCHW, dense)')
-    _require(w_planes.dim() == 4 and tuple(w_planes.shape[:2]) == (23, 3) and w_planes.shape[3] == 16,
-             'conv7x7s2_nchw_split: w_planes from split_stem7x7_weight')
+    _require(w_planes.shape[0] == 23, 'conv7x7s2_nchw_split: w_planes from split_stem7x7_weight')
     N, _, H, W = x.shape
     Cout = w_planes.shape[2]
     if bias is not None:
@@ -805,7 +819,7 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
     with torch.cuda.device(x.device), _Timed('conv7x7_stem', 2 * N * Ho * Wo * Cout * 147, (N * Ho * Wo, 147, Cout)):
         st = lib.pave_conv7x7s2_nchw_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
-            y.data_ptr(), N, H, W, Cout, int(bool(relu)), _stream_ptr())
+            y.data_ptr(), N, H, W, Cout, int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'conv7x7s2_nchw_split')
     return y.permute(0, 3, 1, 2)
 
@@ -878,10 +892,9 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     as `out`."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
-    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] == 3
-             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
-             'gemm_bf16x3_ln: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3, 3 planes)')
+    npl = _planes(w_planes, only=_Q_PLANES)
+    _require(a.dim() == 2 and w_planes.shape[0] * 16 == a.shape[1],
+             'gemm_bf16x3_ln: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3, 3 planes or fp16)')
     M, K = a.shape
     N = w_planes.shape[2]
     _require(N == 256, 'gemm_bf16x3_ln: N == 256')
@@ -902,7 +915,7 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3_ln', M), 2 * M * K * N, (M, K, N, 'ln', 'res' if residual is not None else '')):
         st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
                                          gamma.data_ptr(), beta.data_ptr(), float(eps),
-                                         out.data_ptr(), M, K, N, _stream_ptr())
+                                         out.data_ptr(), M, K, N, npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_ln')
     return out
 
@@ -914,10 +927,8 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     matrices -> out [M, n_split], out2 [M, N - n_split] (n_split = 0: one output, out2 = None)."""
     lib = native.load()
     _dev(a, 'a', torch.float32)
-    _dev(w_planes, 'w_planes', torch.int16)
-    _require(not fp16 or w_planes.shape[1] == 1, 'gemm_bf16x3_ex: fp16 takes a single plane')
-    _require(a.dim() == 2 and w_planes.dim() == 4 and w_planes.shape[1] in (1, 2, 3)
-             and w_planes.shape[3] == 16 and w_planes.shape[0] * 16 == a.shape[1],
+    npl = _planes(w_planes, fp16=fp16)
+    _require(a.dim() == 2 and w_planes.shape[1] in (1, 2, 3) and w_planes.shape[0] * 16 == a.shape[1],
              'gemm_bf16x3_ex: a [M,K], w_planes [K/16,3,N,16] (split_weight_bf16x3)')
     M, K = a.shape
     N = w_planes.shape[2]
@@ -942,9 +953,7 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'ex', f'rows{rr}', f'split{n_split}')):
         st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                          ptr(residual), rr, out.data_ptr(), ptr(out2), n_split,
-                                         M, K, N, int(bool(relu)),
-                                         PLANES_FP16 if fp16 else int(w_planes.shape[1]),
-                                         _stream_ptr())
+                                         M, K, N, int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_ex')
     return out, out2
 
@@ -1036,7 +1045,7 @@ def split_conv3x3_weight(weight, planes=3):
     cout, cin = weight.shape[:2]
     # 3 planes: rows / columns zero-padded to Cout % 64 == 0, 9 Cin % 32 == 0 (HRNet's 48 / 96 channels)
     return split_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous(), planes,
-                               pad=planes == 3)
+                               pad=planes in _Q_PLANES)
 
 
 def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w1n_planes=None,
@@ -1058,7 +1067,7 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
     _require((w2_planes is None) == tail_only, 'bottleneck_chain: c1 and w2_planes go together')
     N, _, H, W = src.shape
     M = N * H * W
-    _dev(w3_planes, 'w3_planes', torch.int16)
+    npl = _planes(w3_planes, 'w3_planes', only=_Q_PLANES)
     k2 = 0
     if a2 is not None:
         _require(residual is None and a2.is_cuda and a2.dtype == torch.float32 and a2.dim() == 4
@@ -1067,9 +1076,9 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
                  'bottleneck_chain: a2 [N, k2, H, W] channels_last, no residual')
         k2 = a2.shape[1]
     if not tail_only:
-        _dev(w2_planes, 'w2_planes', torch.int16)
-        _require(tuple(w2_planes.shape) == (36, 3, 64, 16), 'bottleneck_chain: w2_planes [36, 3, 64, 16]')
-    _require(tuple(w3_planes.shape) == ((64 + k2) // 16, 3, 256, 16),
+        _require(_planes(w2_planes, 'w2_planes') == npl, 'bottleneck_chain: one operand mode for all weights')
+        _require(tuple(w2_planes.shape) == (36, w3_planes.shape[1], 64, 16), 'bottleneck_chain: w2_planes [36, 3, 64, 16]')
+    _require(tuple(w3_planes.shape) == ((64 + k2) // 16, w3_planes.shape[1], 256, 16),
              'bottleneck_chain: w3_planes [(64 + k2)/16, 3, 256, 16]')
     if residual is not None:
         _require(residual.is_cuda and residual.dtype == torch.float32
@@ -1078,9 +1087,9 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
                  'bottleneck_chain: residual [N, 256, H, W] channels_last')
     cn = 0
     if w1n_planes is not None:
-        _dev(w1n_planes, 'w1n_planes', torch.int16)
+        _require(_planes(w1n_planes, 'w1n_planes') == npl, 'bottleneck_chain: one operand mode for all weights')
         cn = w1n_planes.shape[2]
-        _require(tuple(w1n_planes.shape) == (16, 3, cn, 16) and cn in (64, 128),
+        _require(tuple(w1n_planes.shape) == (16, w3_planes.shape[1], cn, 16) and cn in (64, 128),
                  'bottleneck_chain: w1n_planes [16, 3, 64 | 128, 16]')
     for b, n in ((b2, 64), (b3, 256), (b1n, cn)):
         if b is not None:
@@ -1102,7 +1111,7 @@ def bottleneck_chain(c1, w2_planes, b2, w3_planes, b3, residual=None, a2=None, w
         st = lib.pave_bottleneck_chain_f32(
             ptr(c1), ptr(w2_planes), ptr(b2), c2.data_ptr(), w3_planes.data_ptr(), ptr(b3),
             ptr(residual), ptr(a2), k2, out.data_ptr(), ptr(w1n_planes), ptr(b1n), ptr(c1n), cn,
-            N, H, W, _stream_ptr())
+            N, H, W, npl, _stream_ptr())
     native.check(st, 'bottleneck_chain')
     return out, (c1n.permute(0, 3, 1, 2) if cn else None)
 
@@ -1116,12 +1125,10 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False, resi
     lib = native.load()
     _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, 'conv3x3_split: fp32 4-D')
     _require(x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_split: channels_last input')
-    _dev(w_planes, 'w_planes', torch.int16)
+    npl = _planes(w_planes, fp16=fp16)
     N, Cin, H, W = x.shape
-    kp = 9 * Cin if w_planes.shape[1] != 3 else (9 * Cin + 31) // 32 * 32
-    _require(w_planes.dim() == 4 and w_planes.shape[0] * 16 == kp and w_planes.shape[3] == 16,
-             'conv3x3_split: w_planes [9*Cin/16, P, Cout, 16] (split_conv3x3_weight)')
-    _require(not fp16 or w_planes.shape[1] == 1, 'conv3x3_split: fp16 takes a single plane')
+    kp = 9 * Cin if npl not in _Q_PLANES else (9 * Cin + 31) // 32 * 32
+    _require(w_planes.shape[0] * 16 == kp, 'conv3x3_split: w_planes [9*Cin/16, P, Cout, 16] (split_conv3x3_weight)')
     Cout = int(cout) if cout is not None else w_planes.shape[2]
     _require((Cout + 63) // 64 * 64 == w_planes.shape[2], 'conv3x3_split: cout does not match the planes')
     if bias is not None:
@@ -1138,23 +1145,22 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False, resi
     # workgroups, ordered sum in a second launch); the workspace comes from torch's stream-aware
     # caching allocator
     ws_bytes = lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, int(stride)) \
-        if w_planes.shape[1] == 3 and not fp16 else 0
+        if npl in _Q_PLANES else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin,
-                                                 (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride} split-K')):
+                                                 (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride} split-K', 'res' if residual is not None else '')):
             st = lib.pave_conv3x3_splitk_f32(
                 x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
                 residual.data_ptr() if residual is not None else None,
                 y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), ws.data_ptr(), ws_bytes,
-                _stream_ptr())
+                npl, _stream_ptr())
         native.check(st, 'conv3x3_splitk')
         return y.permute(0, 3, 1, 2)
-    with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin, (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}')):
+    with torch.cuda.device(x.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin, (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}', 'res' if residual is not None else '')):
         st = lib.pave_conv3x3_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
             residual.data_ptr() if residual is not None else None,
-            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)),
-            PLANES_FP16 if fp16 else int(w_planes.shape[1]), _stream_ptr())
+            y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'conv3x3_split')
     return y.permute(0, 3, 1, 2)

@@ -91,10 +91,11 @@ def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
     lead = x.shape[:-1]
     rows = x.reshape(-1, x.shape[-1])
     R = rows.shape[0]
-    from .bricks import _GEMM, get_gemm_mode
+    from .bricks import _GEMM, fused_mode, get_gemm_mode
+    mode_planes = lambda: 3     # noqa: E731  (per-frame branch MLPs on a few hundred query rows: always exact)
     dims = [l[0].weight.shape for l in lins]                      # [(out, in)] per layer
     # (T Linears per launch: worth it from a few thousand frame-rows on; tests force min_rows = 1)
-    if (get_gemm_mode() == 'bf16x3' and R * T >= min(_GEMM['min_rows'], 4096) and rows.is_contiguous()
+    if (fused_mode() and R * T >= min(_GEMM['min_rows'], 4096) and rows.is_contiguous()
             and dims[0][1] % 64 == 0 and (T * dims[0][0]) % 64 == 0
             and all(d[1] % 64 == 0 for d in dims[1:])      # split_weight_bf16x3 (un-padded): K % 64 == 0
             and all(d[0] % 64 == 0 for d in dims[1:-1]) and dims[-1][0] % 2 == 0):
@@ -102,9 +103,11 @@ def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
         # launch per following layer (group t = frame t's Linear on its own column block)
         from . import ops
         gp = m0.__dict__.get('_pave_grouped')
-        if gp is None or gp[0] != key:
+        gmode = get_gemm_mode()
+        if gp is None or gp[0] != key or gp[3] != gmode:
             with torch.no_grad():
-                planes = [ops.split_weight_bf16x3(torch.cat([l.weight for l in lins[0]], 0).contiguous())]
+                planes = [ops.split_weight_bf16x3(torch.cat([l.weight for l in lins[0]], 0).contiguous(),
+                                                  mode_planes())]
                 biases = [b1]
                 for li, layer in enumerate(lins[1:]):
                     o = layer[0].weight.shape[0]
@@ -114,11 +117,11 @@ def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
                     for t, l in enumerate(layer):
                         wcat[t, :o] = l.weight
                         bcat[t, :o] = l.bias
-                    planes.append(ops.split_weight_bf16x3(wcat.flatten(0, 1).contiguous()))
+                    planes.append(ops.split_weight_bf16x3(wcat.flatten(0, 1).contiguous(), mode_planes()))
                     biases.append(bcat.flatten().contiguous())
-            gp = (key, planes, biases)
+            gp = (key, planes, biases, gmode)
             m0.__dict__['_pave_grouped'] = gp
-        _, planes, biases = gp
+        _, planes, biases, _ = gp
         y = ops.gemm_bf16x3(rows, planes[0], biases[0], None, relu=True)          # [R, T*h]
         for li in range(1, len(lins)):
             last = li + 1 == len(lins)

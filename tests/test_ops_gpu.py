@@ -1360,6 +1360,137 @@ def test_gemm_bf16_split_reduced_planes(planes, rel):
         assert torch.equal(p.view(torch.float16), w.to(torch.float16))
 
 
+@pytest.mark.parametrize('form', ['rows', 'rows_small', 'rows_n48', 'ex', 'ln_wide', 'ln_8wave', 'ln_small', 'cat',
+                                  'grouped', 'strided', 'conv3x3', 'conv3x3_c48_res', 'conv3x3_splitk', 'stem',
+                                  'chain', 'encproj'])
+def test_fp16_operand_mode_on_every_fused_form(form):
+    """BASELINE configs[4]'s "fp16 MFMA projections" on the LDS-DMA kernel generation (nplanes =
+    PAVE_PLANES_FP16): ONE plane of fp16 weights, the fp32 activation rows rounded to fp16 at operand fetch,
+    fp32 accumulation -- i.e. the EXACT product of the fp16-rounded operands up to fp32 summation error, for
+    every form the exact 3-plane mode has (tile / wide / small-row GEMMs, two outputs + row table, LayerNorm
+    epilogue in its three forms, two row sources, grouped columns, strided pixels, 3x3 incl. padded 48-channel
+    planes + identity and the split-K form, the 7x7 stem, the layer1 chain, the encoder projection with the
+    sampler arithmetic).  Plain rows / `ex` / 3x3 are also bit-identical to the first-generation fp16 kernels."""
+    from pavenet_amd import native, ops
+    F16 = ops.PLANES_FP16
+    g = torch.Generator().manual_seed(len(form) * 7 + 1)
+    h = lambda t: t.half().double()                                   # noqa: E731  (what the kernel multiplies)
+    rnd = lambda *sh, sc=1.0: torch.randn(*sh, generator=g) * sc       # noqa: E731
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)   # noqa: E731
+
+    def close(got, exp, tol=2e-5):
+        exp = exp.double()
+        err = float((got.double().cpu() - exp).abs().max() / exp.abs().max().clamp_min(1e-6))
+        assert err < tol, (form, err)
+
+    if form in ('rows', 'rows_small', 'rows_n48'):
+        M, K, N = {'rows': (9000, 256, 384), 'rows_small': (300, 1024, 256), 'rows_n48': (20000, 96, 48)}[form]
+        a, w, b, r = rnd(M, K), rnd(N, K, sc=K ** -0.5), rnd(N), rnd(M, N)
+        wp = ops.split_weight_bf16x3(w.cuda(), F16, pad=True)
+        assert wp.dtype == torch.float16 and wp.shape[1] == 1
+        got = ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), r.cuda(), relu=True, n_out=N)
+        close(got, torch.relu(h(a) @ h(w).t() + b.double() + r.double()))
+        if form == 'rows':
+            with native.diag_build(9):      # first-generation fp16 kernel: same conversion, same order
+                old = ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), r.cuda(), relu=True).clone()
+            assert torch.equal(got, old)
+            # wrong mode refused: a float16 plane where only 3 bf16 planes or fp16 are valid is fine, int16 x1 is not
+            with pytest.raises(RuntimeError):
+                ops.gemm_bf16x3_ln(a.cuda(), ops.split_weight_bf16x3(w[:256].cuda(), 1), None, None, b[:256].cuda(),
+                                   b[:256].cuda(), 1e-5)
+    elif form == 'ex':
+        M, K, N, rows = 9000, 256, 640, 125
+        a, w, tab = rnd(M, K), rnd(N, K, sc=K ** -0.5), rnd(rows, N)
+        wp = ops.split_weight_bf16x3(w.cuda(), F16)
+        o1, o2 = ops.gemm_bf16x3_ex(a.cuda(), wp, None, tab.cuda(), residual_rows=rows, n_split=256)
+        close(torch.cat([o1, o2], 1), h(a) @ h(w).t() + tab.double()[torch.arange(M) % rows])
+        with native.diag_build(9):
+            p1, p2 = ops.gemm_bf16x3_ex(a.cuda(), wp, None, tab.cuda(), residual_rows=rows, n_split=256)
+            p1, p2 = p1.clone(), p2.clone()
+        assert torch.equal(o1, p1) and torch.equal(o2, p2)
+    elif form.startswith('ln'):
+        M, K = (300, 1024) if form == 'ln_small' else (3000, 256)
+        a, w, b, r, ga, be = rnd(M, K), rnd(256, K, sc=K ** -0.5), rnd(256), rnd(M, 256), rnd(256) + 1.0, rnd(256)
+        wp = ops.split_weight_bf16x3(w.cuda(), F16)
+        args = (a.cuda(), wp, b.cuda(), r.cuda(), ga.cuda(), be.cuda(), 1e-5)
+        if form == 'ln_small':
+            got = ops.gemm_bf16x3_ln(*args)
+        else:
+            with native.diag_build(14 if form == 'ln_wide' else 13):
+                got = ops.gemm_bf16x3_ln(*args).clone()
+        exp = torch.nn.functional.layer_norm(h(a) @ h(w).t() + b.double() + r.double(), (256,), ga.double(),
+                                             be.double(), 1e-5)
+        close(got, exp, 3e-5)
+    elif form == 'cat':
+        M, K1, K2, N = 9000, 64, 64, 256
+        a, a2, w, b = rnd(M, K1).relu(), rnd(M, K2).relu(), rnd(N, K1 + K2, sc=0.1), rnd(N)
+        got = ops.gemm_bf16x3_cat(a.cuda(), a2.cuda(), ops.split_weight_bf16x3(w.cuda(), F16), b.cuda(), relu=True)
+        close(got, torch.relu(torch.cat([h(a), h(a2)], 1) @ h(w).t() + b.double()))
+    elif form == 'grouped':
+        M, K, G, gn = 1200, 128, 3, 64
+        a, w, b = rnd(M, G * K), rnd(G * gn, K, sc=0.1), rnd(G * gn)
+        got = ops.gemm_bf16x3_grouped(a.cuda(), ops.split_weight_bf16x3(w.cuda(), F16), b.cuda(), gn, relu=True)
+        exp = torch.cat([h(a[:, i * K:(i + 1) * K]) @ h(w[i * gn:(i + 1) * gn]).t() for i in range(G)], 1) + b.double()
+        close(got, torch.relu(exp))
+    elif form == 'strided':
+        x, w, b = rnd(2, 64, 31, 45), rnd(128, 64, sc=0.1), rnd(128)
+        got = ops.conv1x1_strided_split(cl(x), ops.split_weight_bf16x3(w.cuda(), F16), b.cuda(), stride=2, relu=True)
+        exp = torch.relu(torch.nn.functional.conv2d(h(x), h(w)[:, :, None, None], b.double(), stride=2))
+        close(got, exp)
+    elif form in ('conv3x3', 'conv3x3_c48_res', 'conv3x3_splitk'):
+        n, H, W, Cin, Cout, st = {'conv3x3': (2, 33, 47, 64, 128, 2), 'conv3x3_c48_res': (2, 40, 56, 48, 48, 1),
+                                  'conv3x3_splitk': (1, 26, 42, 1024, 256, 2)}[form]
+        x, w, b = rnd(n, Cin, H, W), rnd(Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5), rnd(Cout)
+        res = rnd(n, Cout, (H - 1) // st + 1, (W - 1) // st + 1) if form == 'conv3x3_c48_res' else None
+        wp = ops.split_conv3x3_weight(w.cuda(), F16)
+        got = ops.conv3x3_split(cl(x), wp, b.cuda(), stride=st, relu=True, cout=Cout,
+                                residual=cl(res) if res is not None else None)
+        exp = torch.nn.functional.conv2d(h(x), h(w), b.double(), stride=st, padding=1)
+        close(got, torch.relu(exp + (res.double() if res is not None else 0)))
+        if form == 'conv3x3':
+            with native.diag_build(9):
+                old = ops.conv3x3_split(cl(x), wp, b.cuda(), stride=st, relu=True).clone()
+            assert torch.equal(got, old)
+    elif form == 'stem':
+        x, w, b = rnd(2, 3, 64, 96), rnd(64, 3, 7, 7, sc=0.08), rnd(64)
+        wp = ops.split_stem7x7_weight(w.cuda(), F16)
+        assert wp.dtype == torch.float16 and tuple(wp.shape) == (23, 1, 64, 16)
+        got = ops.conv7x7s2_nchw_split(x.cuda(), wp, b.cuda(), relu=True)
+        close(got, torch.relu(torch.nn.functional.conv2d(h(x), h(w), b.double(), stride=2, padding=3)))
+        with pytest.raises(RuntimeError):     # odd width: no fp16 form of the per-lane window kernel
+            ops.conv7x7s2_nchw_split(x[..., :95].contiguous().cuda(), wp, b.cuda())
+    elif form == 'chain':
+        n, H, W = 2, 19, 27
+        c1, xin = cl(rnd(n, 64, H, W).relu()), cl(rnd(n, 256, H, W))
+        w2p, b2 = ops.split_conv3x3_weight(rnd(64, 64, 3, 3, sc=0.05).cuda(), F16), rnd(64, sc=0.1).cuda()
+        w3p, b3 = ops.split_weight_bf16x3(rnd(256, 64, sc=0.08).cuda(), F16), rnd(256, sc=0.1).cuda()
+        w1p, b1 = ops.split_weight_bf16x3(rnd(64, 256, sc=0.05).cuda(), F16), rnd(64, sc=0.1).cuda()
+        c2 = ops.conv3x3_split(c1, w2p, b2, relu=True)
+        exp_out = ops.gemm_bf16x3(c2.permute(0, 2, 3, 1).reshape(-1, 64), w3p, b3,
+                                  xin.permute(0, 2, 3, 1).reshape(-1, 256), relu=True)
+        exp_c1n = ops.gemm_bf16x3(exp_out, w1p, b1, relu=True)
+        for v in (15, 16):      # 128- and 256-row tiles of the chain launch
+            with native.diag_build(v):
+                out, c1n = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=xin, w1n_planes=w1p, b1n=b1)
+                torch.cuda.synchronize()
+            assert torch.equal(out.permute(0, 2, 3, 1).reshape(-1, 256), exp_out)
+            assert torch.equal(c1n.permute(0, 2, 3, 1).reshape(-1, 64), exp_c1n)
+    else:   # encproj: the sampler arithmetic in the epilogue = the sampler's own, on the fp16 products
+        levels, F_ = [(16, 24), (8, 12), (4, 6), (2, 3)], 3
+        S = sum(a_ * b_ for a_, b_ in levels)
+        M = F_ * S
+        a, w, tab = rnd(M, 256).cuda(), (rnd(640, 256) * 0.05).cuda(), (rnd(S, 640) * 0.1).cuda()
+        wp = ops.split_weight_bf16x3(w, F16)
+        ref = torch.rand(M, 4, 2, generator=g).cuda()
+        v0, proj = ops.gemm_bf16x3_ex(a, wp, None, tab, residual_rows=S, n_split=256)
+        v1, samp = ops.gemm_bf16x3_encproj(a, wp, tab, ref, levels)
+        assert torch.equal(v0, v1)
+        raw = ops.deform_attn_enc_tile(v0.view(F_, S, 8, 32), proj, ref.view(1, M, 4, 2), levels_hw=levels)
+        pre = ops.deform_attn_enc_tile(v1.view(F_, S, 8, 32), samp, None, levels_hw=levels, prepared=True)
+        assert torch.equal(raw, pre)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 64, 64, 1), (1, 20, 9, 128, 128, 1),
                                                    (3, 14, 22, 128, 256, 2), (2, 9, 9, 256, 64, 2),
                                                    (1, 40, 56, 64, 192, 1)])

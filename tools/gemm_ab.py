@@ -65,7 +65,7 @@ def main():
             if ln:
                 return lambda: lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), wp.data_ptr(), bias.data_ptr(),
                                                            r.data_ptr() if res else None, gam.data_ptr(),
-                                                           bet.data_ptr(), 1e-5, out.data_ptr(), M, K, N, st)
+                                                           bet.data_ptr(), 1e-5, out.data_ptr(), M, K, N, 3, st)
             return lambda: lib.pave_gemm_bf16x3_f32(a.data_ptr(), None, wp.data_ptr(), bias.data_ptr(),
                                                     r.data_ptr() if res else None, out.data_ptr(), M, K, N,
                                                     int(relu), 3, st)
