@@ -67,7 +67,10 @@ def parse():
     ap.add_argument('--no-native-side', action='store_true',
                     help='skip the --gemm native side measurement (profiling runs: one mode per trace)')
     ap.add_argument('--cpu-baseline-clips', type=int, default=3,
-                    help='timed oracle clips after one small warm-up (~50 s each on 128 cores)')
+                    help='timed oracle clips after one small warm-up (~20 s each)')
+    ap.add_argument('--cpu-threads', type=int, default=16,
+                    help='torch intra-op threads of the CPU oracle leg (a 1-GPU box is a 16-CPU share of its host; '
+                         "torch's default of half the host's hardware threads runs the oracle ~3 x slower)")
     ap.add_argument('--graph', type=int, default=0,
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
@@ -206,7 +209,12 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     from oracle import pavenet_ref as R
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cfg = dict(num_frames=frames, num_keypoints=15, num_query=300, max_per_img=args.max_per_img)
-    threads = torch.get_num_threads()
+    # torch's intra-op pool defaults to half the HOST's hardware threads (128 on a GPU box, which is a 16-CPU
+    # share of that host): the oracle then runs 2.8 x SLOWER than with 16 - 32 threads (tools/oracle_threads.py,
+    # profiles/r05_oracle_threads.txt), so the baseline is timed on the share it has
+    default_threads = torch.get_num_threads()
+    threads = max(1, min(default_threads, args.cpu_threads))
+    torch.set_num_threads(threads)
     R.SAMPLER = 'torch'
     with torch.no_grad():
         R.videopose_simple_test(sd, dict(cfg, num_frames=1), clip0[:, :1])   # warm-up (thread pools)
@@ -216,6 +224,7 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
             t0 = time.time()
             exp = R.videopose_simple_test(sd, cfg, clip0, taps=taps)
             times.append(time.time() - t0)
+    torch.set_num_threads(default_threads)
     dt = sum(times) / len(times)
     base = dict(value=round(1.0 / dt, 5), unit='clips/s', cores=threads, kind='port',
                 sample=f'{len(times)} timed clips (after a 1-frame warm-up) of T={frames}, '

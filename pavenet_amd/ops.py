@@ -80,15 +80,19 @@ def _planes(w_planes, name='w_planes', fp16=False, only=None):
     """Checks a split-weight operand and returns the C ABI's `nplanes` for it: int16 tensors hold
     shape[1] bf16 planes, float16 tensors ONE plane of fp16 operands (split_weight_bf16x3(..., PLANES_FP16));
     `fp16=True` with an int16 single plane = the same bits under the old dtype.  only: allowed values."""
-    _dev(w_planes, name)
-    _require(w_planes.dtype in (torch.int16, torch.float16), f'{name} must be int16 (bf16 planes) or float16 (fp16 plane)')
-    _require(w_planes.dim() == 4 and w_planes.shape[3] == 16, f'{name}: [K/16, planes, N, 16] (split_weight_bf16x3)')
-    if w_planes.dtype == torch.float16 or fp16:
-        _require(w_planes.shape[1] == 1, f'{name}: fp16 operands are a single plane')
+    # (one combined test on the way every launch takes; the messages are built on failure only)
+    dt = w_planes.dtype if isinstance(w_planes, torch.Tensor) else None
+    if not (dt in (torch.int16, torch.float16) and w_planes.is_cuda and w_planes.is_contiguous()
+            and w_planes.dim() == 4 and w_planes.shape[3] == 16):
+        _dev(w_planes, name)
+        _require(dt in (torch.int16, torch.float16), f'{name} must be int16 (bf16 planes) or float16 (fp16 plane)')
+        _require(False, f'{name}: [K/16, planes, N, 16] (split_weight_bf16x3)')
+    n = w_planes.shape[1]
+    if dt == torch.float16 or fp16:
+        _require(n == 1, f'{name}: fp16 operands are a single plane')
         n = PLANES_FP16
-    else:
-        n = int(w_planes.shape[1])
-    _require(only is None or n in only, f'{name}: this entry point takes 3 bf16 planes or one fp16 plane')
+    if only is not None and n not in only:
+        _require(False, f'{name}: this entry point takes 3 bf16 planes or one fp16 plane')
     return n
 
 
