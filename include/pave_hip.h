@@ -218,6 +218,17 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
  *                       C % 4 == 0, C <= 1024 (the 'attn/ffn -> + identity -> norm' step of
  *                       mmcv BaseTransformerLayer.forward, bricks/transformer.py:1316-1353).
  */
+/*
+ * x[rows[i], 0:C] = values[0:C] (values == NULL: zeros) for i < n_rows; x [total_rows, ld] row-major, `rows`
+ * int32 indices on the DEVICE (an index outside [0, total_rows) is skipped, never dereferenced).
+ * The padding mask of the reference on a projected value matrix -- masked tokens are 0 when the mask follows
+ * value_proj (third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:369-371) and value_proj.bias when it
+ * precedes it (opera/models/utils/transformer.py:1706-1711, multi_scale_deform_attn.py:1454-1458) -- applied
+ * to the listed rows only instead of a masked_fill pass over the whole memory (an 800 x 1333 image in an
+ * 800 x 1344 batch masks ~1 % of the tokens).
+ */
+int pave_fill_rows_f32(float* x, long long ld, long long total_rows, const int* rows, long long n_rows,
+                       const float* values, int C, void* stream);
 int pave_bias_act_rows_f32(const float* x, const float* bias, const float* res, float* y,
                            long long rows, int C, int relu, void* stream);
 /*

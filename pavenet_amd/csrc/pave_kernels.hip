@@ -588,6 +588,24 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const FuseSrc src, float*
   }
 }
 
+// x[rows[i], :] = values (or zeros) for the listed rows only: the reference's padding-mask semantics on a
+// projected value matrix without a pass over the whole matrix (a padded 800 x 1333 image masks ~1 % of the tokens)
+__global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ x, const long long ld,
+                                                        const int* __restrict__ rows, const long long n4,
+                                                        const int c4, const long long total_rows,
+                                                        const float* __restrict__ values) {
+  const float4* v4 = reinterpret_cast<const float4*>(values);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4);
+    const long long row = rows[r];
+    if (row < 0 || row >= total_rows) continue;     // (an index outside the matrix is never dereferenced)
+    const float4 v = values ? v4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(x + row * ld + 4 * c) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void bias_act_rows_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ res,
@@ -1657,6 +1675,22 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
   const size_t shmem = (size_t)N * (2 * sizeof(int) + sizeof(float));
   hipLaunchKernelGGL(oks_nms_kernel, dim3(n_clips), dim3(256), shmem, st, kpts, scores, sigmas,
                      thresh, keep, order, N, K);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_fill_rows_f32(float* x, long long ld, long long total_rows, const int* rows, long long n_rows,
+                       const float* values, int C, void* stream) {
+  if (!x || (!rows && n_rows > 0)) return fail(PAVE_E_ARG, "fill_rows: null pointer");
+  if (n_rows < 0 || total_rows <= 0 || C <= 0 || (C & 3) || ld < C || (ld & 3))
+    return fail(PAVE_E_ARG, "fill_rows: C and ld must be positive multiples of 4, ld >= C");
+  if (n_rows == 0) return PAVE_OK;
+  const long long n4 = n_rows * (C >> 2);
+  long long nb = (n4 + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, ld, rows, n4, C >> 2, total_rows, values);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -79,12 +79,43 @@ def _proj(linear, x):
     return linear(x)
 
 
+def masked_row_index(mask):
+    """int32 indices of the True entries of a (cached) padding mask, flattened row-major -- built ONCE per mask
+    tensor (one device read-back when a padded batch shape is first seen) and kept on the tensor that owns the
+    storage; the masks themselves are cached per batch shape by the head."""
+    base = mask._base if mask._base is not None else mask
+    key = SourceKey((base,), (tuple(mask.shape), tuple(mask.stride()), mask.storage_offset()))
+    slots = base.__dict__.setdefault('_pave_mask_rows', [])
+    for k, idx in slots:
+        if k == key:
+            return idx
+    with torch.no_grad():
+        idx = mask.reshape(-1).nonzero().flatten().to(torch.int32)
+    if len(slots) > 8:
+        del slots[:]
+    slots.append((key, idx))
+    return idx
+
+
 def project_values_hoisted(attns, value_bf, key_padding_mask=None):
     """value_proj of several decoder layers over the same (constant) memory, as the modules'
     own `project_value` would give them: [B*T, S, 8, 32] per layer.  In the split GEMM modes two
-    layers share one launch (N = 512, two dense outputs), so the memory is read once per pair."""
+    layers share one launch (N = 512, two dense outputs), so the memory is read once per pair.
+    With a padding mask (both T-frame attentions mask the memory BEFORE value_proj, OT:1706-1711 /
+    MO:1454-1458: a masked token's value is value_proj.bias) the launches are the un-masked ones and
+    the masked rows -- ~1 % of the tokens -- are overwritten with the layer's bias afterwards
+    (pave_fill_rows_f32), instead of a masked_fill copy of the memory per layer."""
     from .bricks import _split_weight, get_gemm_mode, split_gemm_ok
     x = value_bf
+    fill = None
+    if key_padding_mask is not None and x.is_cuda and x.is_contiguous() and len(attns) >= 2 \
+            and not torch.is_grad_enabled() and key_padding_mask.dtype == torch.bool \
+            and all(type(a).project_value in (MulFramesMultiScaleDeformablePoseAttention.project_value,
+                                              MulFramesMultiScaleDeformableAttention.project_value)
+                    and a.value_proj.bias is not None for a in attns) \
+            and split_gemm_ok(x.reshape(-1, x.shape[-1]), attns[0].value_proj.weight):
+        fill = masked_row_index(key_padding_mask)
+        key_padding_mask = None
     if key_padding_mask is not None or not (x.is_cuda and x.is_contiguous()) or len(attns) < 2:
         return [a.project_value(value_bf, key_padding_mask) for a in attns]
     rows = x.reshape(-1, x.shape[-1])
@@ -107,10 +138,15 @@ def project_values_hoisted(attns, value_bf, key_padding_mask=None):
             v1, v2 = ops.gemm_bf16x3_ex(rows, _split_weight(a._pair_w), a._pair_b, n_split=nv,
                                         fp16=get_gemm_mode() == 'fp16')
             for m, v in ((a, v1), (b, v2)):
+                if fill is not None:
+                    ops.fill_rows_(v, fill, m.value_proj.bias.detach())
                 outs.append(v.view(-1, x.shape[-2], m.num_heads, nv // m.num_heads))
             i += 2
         else:
-            outs.append(a.project_value(value_bf, None))
+            v = a.project_value(value_bf, None)
+            if fill is not None:
+                ops.fill_rows_(v.view(-1, v.shape[-2] * v.shape[-1]), fill, a.value_proj.bias.detach())
+            outs.append(v)
             i += 1
     return outs
 
@@ -239,6 +275,48 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                                        levels_hw=tile_levels, window_shift=self._tile_shift())
         return out.view(bs, S, self.embed_dims)
 
+    def _forward_merged_groups(self, q, pos_bf, mask, reference_points, tile_levels, groups):
+        """`_forward_merged` for a PADDED batch: the positional encoding and the padding pattern are
+        the same for the frames of a run (`groups`: (first frame, count); the T frames of a clip share one
+        valid size, HEAD:429-445), so each run is ONE launch of the merged projection GEMM with the run's own
+        epilogue table, writing its row slice of the batch's value / prepared-projection matrices; the value
+        rows of masked tokens are zeroed afterwards (the mask FOLLOWS value_proj here, MO:369-371;
+        pave_fill_rows_f32 on the ~1 % masked rows) and ONE sampler launch serves the whole batch.  The
+        reference points carry the per-frame valid ratios (transformer.get_reference_points)."""
+        from .bricks import _split_weight
+        bs, S, C = q.shape
+        w_all, w_cat, b_cat = self._merged_proj()
+        nv = self.value_proj.out_features
+        src = pos_bf._base if pos_bf._base is not None else pos_bf
+        tabs = self.__dict__.setdefault('_pave_group_tables', {})
+        value = torch.empty((bs * S, nv), dtype=torch.float32, device=q.device)
+        samp = torch.empty((bs * S, w_all.shape[0] - nv), dtype=torch.float32, device=q.device)
+        ref = reference_points.reshape(bs * S, self.num_levels, 2)
+        if not ref.is_contiguous():
+            ref = ref.contiguous()
+        rows = q.reshape(bs * S, C)
+        wp = _split_weight(w_all)
+        vb = self.value_proj.bias.detach()
+        for f0, n in groups:
+            pos_row = pos_bf[f0]
+            tkey = SourceKey([src, self.value_proj.bias, w_cat, b_cat],
+                             (tuple(pos_row.shape), pos_row.storage_offset(), tuple(pos_row.stride()), S))
+            hit = tabs.get(f0)
+            if hit is None or hit[0] != tkey:
+                table = torch.empty((S, w_all.shape[0]), dtype=torch.float32, device=q.device)
+                table[:, :nv] = self.value_proj.bias
+                torch.addmm(b_cat, pos_row, w_cat.t(), out=table[:, nv:])
+                if len(tabs) > 64:
+                    tabs.clear()
+                hit = tabs[f0] = (tkey, table)
+            r0, r1 = f0 * S, (f0 + n) * S
+            ops.gemm_bf16x3_encproj(rows[r0:r1], wp, hit[1], ref[r0:r1], tile_levels, value_bias=vb,
+                                    out=(value[r0:r1], samp[r0:r1]))
+        ops.fill_rows_(value, masked_row_index(mask), None)
+        out = ops.deform_attn_enc_tile(value.view(bs, S, self.num_heads, -1), samp, None,
+                                       levels_hw=tile_levels, window_shift=self._tile_shift(), prepared=True)
+        return out.view(bs, S, self.embed_dims)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, post_norm=None, query_plus_pos=None, **kwargs):
@@ -248,6 +326,26 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
         if identity is None:
             identity = query
         tile_levels = kwargs.get('tile_levels')
+        groups = kwargs.get('frame_groups')
+        if (groups is not None and self_value and query_pos is not None and query_plus_pos is None
+                and not self.batch_first and key_padding_mask is not None and tile_levels is not None
+                and kwargs.get('memory_clip_index') is None and reference_points.shape[-1] == 2
+                and self.num_levels == 4 and self.num_points == 4 and query_pos.dim() == 3
+                and query_pos.shape == query.shape and key_padding_mask.dtype == torch.bool
+                and self.prepare_in_gemm and not torch.is_grad_enabled()):
+            from .bricks import fused_mode, split_gemm_ok
+            q = batch_first(query)
+            pos_bf = batch_first(query_pos)
+            if (fused_mode() and _fused_ok(self, q) and self.value_proj.out_features == 256
+                    and self.value_proj.bias is not None and pos_bf.stride(2) == 1 and q.is_contiguous()
+                    and all(split_gemm_ok(q[f0:f0 + n].reshape(-1, q.shape[-1]), self.sampling_offsets.weight)
+                            for f0, n in groups)):
+                out = self._forward_merged_groups(q, pos_bf, key_padding_mask, reference_points,
+                                                  tile_levels, groups)
+                idt = batch_first(identity)
+                out = linear_residual_norm(out, self.output_proj, idt, post_norm,
+                                           inplace=kwargs.get('inplace_residual', False) is True)
+                return seq_first_view(out)
         if (self_value and query_pos is not None and query_plus_pos is None and not self.batch_first
                 and key_padding_mask is None and tile_levels is not None
                 and kwargs.get('memory_clip_index') is None and reference_points.shape[-1] == 2

@@ -113,6 +113,13 @@ def _clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
 
+class MaskList(list):
+    """The per-level padding masks of a batch, with what the host knows about them: `frame_groups` = runs
+    (first frame, count) of consecutive frames sharing one valid size (padded batches only) -- lets the encoder
+    take its merged-projection path per run without reading the masks back from the device."""
+    frame_groups = None
+
+
 @HEADS.register_module()
 class VideoPoseHeadMulFrames(BaseModule):
 
@@ -238,6 +245,16 @@ class VideoPoseHeadMulFrames(BaseModule):
                 pos.append(self.positional_encoding(m))
             if len(self._consts) > 8:
                 self._consts.clear()
+            masks = MaskList(masks)
+            if has_padding:
+                # runs of consecutive frames with one valid size (the T frames of a clip always; neighbouring
+                # clips of equal size merge): one positional table / padding pattern per run
+                runs, f0 = [], 0
+                for i in range(1, n + 1):
+                    if i == n or shapes[i] != shapes[f0]:
+                        runs.append((f0, i - f0))
+                        f0 = i
+                masks.frame_groups = tuple(runs)
             self._consts[key] = (masks, pos)
         masks, pos = self._consts[key]
         return masks, pos, has_padding

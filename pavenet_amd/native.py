@@ -23,6 +23,7 @@ SIGNATURES = {
     'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp, _vp],
     'pave_fuse_sum_nhwc_f32': [_vp, _c_int] * 4 + [_vp] + [_c_int] * 5 + [_vp],
     'pave_bias_act_rows_f32': [_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, _vp],
+    'pave_fill_rows_f32': [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _c_int, _vp],
     'pave_bias_add_layernorm_f32': [_vp] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _vp],
     'pave_bias_add_layernorm_pos_f32': [_vp] * 7 + [ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int,
                                         ctypes.c_float, _vp],

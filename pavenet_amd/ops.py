@@ -390,6 +390,24 @@ def bias_act_rows_(x, bias=None, res=None, relu=True):
     return x
 
 
+def fill_rows_(x, rows, values=None):
+    """x[rows] = values (zeros when None), in place: x [R, C] fp32 (a row-strided view is fine), rows int32
+    indices on the device, values [C] -- pave_fill_rows_f32."""
+    lib = native.load()
+    _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1,
+             'fill_rows_: x [R, C] fp32 on the device, unit column stride')
+    _dev(rows, 'rows', torch.int32)
+    if values is not None:
+        _dev(values, 'values', torch.float32)
+        _require(values.numel() == x.shape[1], 'fill_rows_: values [C]')
+    with torch.cuda.device(x.device):
+        st = lib.pave_fill_rows_f32(x.data_ptr(), x.stride(0), x.shape[0], rows.data_ptr(), rows.numel(),
+                                    values.data_ptr() if values is not None else None, x.shape[1],
+                                    _stream_ptr())
+    native.check(st, 'fill_rows_')
+    return x
+
+
 def bias_add_layernorm(x, bias, res, gamma, beta, eps=1e-5, pos=None):
     """LayerNorm(x + bias + res) over the last dim; x / res dense row-major [..., C].
     With pos ([P, C] rows, P dividing the row count pattern r % P): returns (y, y + pos) from the
@@ -441,7 +459,7 @@ def enc_tile_window_shift(offset_bias):
     return tuple(int(v) for v in m.flatten().tolist())
 
 
-def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None):
+def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None, out=None):
     """The encoder layer's merged N = 640 projection with the sampler's softmax / location
     arithmetic in the GEMM epilogue (pave_gemm_bf16x3_encproj_f32): a [M, K], w_planes = 3-plane
     split of the [640, K] weight, table [rows, 640] (row m adds table[m % rows]), ref [M, 4, 2]
@@ -463,8 +481,14 @@ def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None):
         _require(value_bias.numel() == 256 and value_bias.is_contiguous(), 'gemm_bf16x3_encproj: value_bias [256]')
     import ctypes
     hw_arr = (ctypes.c_int * 8)(*[int(v) for hw in levels_hw for v in hw])
-    value = torch.empty((M, 256), dtype=torch.float32, device=a.device)
-    samp = torch.empty((M, 384), dtype=torch.float32, device=a.device)
+    if out is not None:     # (value [M, 256], samp [M, 384]) given: row slices of larger dense matrices
+        value, samp = out
+        _dev(value, 'out value', torch.float32)
+        _dev(samp, 'out samp', torch.float32)
+        _require(tuple(value.shape) == (M, 256) and tuple(samp.shape) == (M, 384), 'gemm_bf16x3_encproj: out shapes')
+    else:
+        value = torch.empty((M, 256), dtype=torch.float32, device=a.device)
+        samp = torch.empty((M, 384), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device), _Timed('gemm_bf16x3', 2 * M * K * 640, (M, K, 640, 'encproj')):
         st = lib.pave_gemm_bf16x3_encproj_f32(a.data_ptr(), w_planes.data_ptr(), table.data_ptr(),
                                               table.shape[0],

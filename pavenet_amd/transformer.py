@@ -580,6 +580,10 @@ class VideoPoseTransformerMulFrames(Transformer):
         extra = {}
         if self.enc_lds_tile and feat_flatten.is_cuda and geom.tile_levels() is not None:
             extra['tile_levels'] = geom.tile_levels()
+            groups = getattr(mlvl_masks, 'frame_groups', None)
+            if attn_mask is not None and groups is not None and sum(n for _, n in groups) == bs:
+                # padded batch: runs of frames with one positional table / padding pattern each
+                extra['frame_groups'] = groups
         elif self.xcd_unit_order and feat_flatten.is_cuda:
             extra['unit_order'] = geom.unit_order(bs, dev)
         # every encoder layer input is a temporary owned by this function, so the residual

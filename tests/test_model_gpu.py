@@ -22,6 +22,7 @@ _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_w
              'test_deterministic_mode_is_bit_reproducible_and_matches_default',
              'test_hipgraph_replay_equals_eager', 'test_bench_batch_full_size_t7_b4_vs_oracle',
              'test_hrnet_w48_full_size_t7_vs_oracle', 'test_t15_full_size_unsharded_vs_oracle',
+             'test_t15_full_size_fp16_vs_oracle', 'test_padded_batch_full_size_vs_oracle',
              'test_neck_eval_with_grad_keeps_the_differentiable_path')
 
 
@@ -747,7 +748,7 @@ def test_full_size_800x1344_vs_reference_golden(golden_dir):
 _ORACLE_RUNS = {}   # (T, backbone) -> the oracle's result on clip 0 (one CPU run shared by the tests of a shape)
 
 
-def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=1e-3):
+def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=1e-3, img_shapes=None):
     """bench.py's batch of a BASELINE configuration at 800 x 1344 (bench weights, headline GEMM mode
     'bf16x3', shipped GEMM selections): clip 0 against ONE run of the CPU oracle -- key points within
     1e-3 px with the oracle's two top-k selections pinned, equal OKS-NMS keep sets, and the FREE run
@@ -771,23 +772,26 @@ def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=
     g = torch.Generator(device='cuda').manual_seed(seed)
     img = torch.randn(B, T, 3, H, W, device='cuda', generator=g)
     img[0].copy_(clip0[0])
-    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))
-             for _ in range(B)]
+    # img_shapes: per-clip valid sizes (h, w) inside the H x W batch -- a PADDED batch (HEAD:429-445)
+    shapes = [tuple(s) + (3,) for s in img_shapes] if img_shapes is not None else [(H, W, 3)] * B
+    metas = [dict(batch_input_shape=(H, W), img_shape=shapes[i], scale_factor=(1., 1., 1., 1.))
+             for i in range(B)]
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     cfg = dict(num_frames=T, num_keypoints=K, num_query=300, max_per_img=N)
     if backbone == 'hrnet_w48':
         cfg['backbone'] = 'hrnet'
-    if (T, backbone) not in _ORACLE_RUNS:
+    okey = (T, backbone, shapes[0])
+    if okey not in _ORACLE_RUNS:
         taps = {}
         old = R.SAMPLER
         R.SAMPLER = 'torch'
         try:
             with torch.no_grad():
-                eb, el, ek = R.videopose_simple_test(sd, cfg, clip0, taps=taps)
+                eb, el, ek = R.videopose_simple_test(sd, cfg, clip0, img_shape=shapes[0], taps=taps)
         finally:
             R.SAMPLER = old
-        _ORACLE_RUNS[(T, backbone)] = (eb, el, ek, {k: taps[k] for k in ('topk_idx', 'score_topk_idx')})
-    eb, el, ek, taps = _ORACLE_RUNS[(T, backbone)]
+        _ORACLE_RUNS[okey] = (eb, el, ek, {k: taps[k] for k in ('topk_idx', 'score_topk_idx')})
+    eb, el, ek, taps = _ORACLE_RUNS[okey]
     bricks.set_gemm_mode(gemm)
     tuning.use_tuned_gemms()
     try:
@@ -835,6 +839,17 @@ def test_t15_full_size_unsharded_vs_oracle():
     """The BASELINE configs[4] shape at FULL size, un-sharded, exact arithmetic: R-50, T = 15, one
     800 x 1344 clip (15-frame T-frame attention kernels, 15 x 22 323-token memory)."""
     _full_size_vs_oracle(15, 1)
+
+
+def test_padded_batch_full_size_vs_oracle():
+    """A PADDED batch at full size on the encoder's fast path: two clips of T = 3 in an 800 x 1344 batch with
+    valid sizes 750 x 1333 and 800 x 1333 (the reference's test pipeline pads to a multiple of 32,
+    configs/_base_/datasets/coco_keypoint.py:79; masks per clip from img_shape, HEAD:429-445) -- two runs of
+    frames with their own positional table, padding pattern and valid ratios through the merged projection
+    GEMM + one sampler launch, value rows of masked tokens zeroed (MO:369-371), the decoders' masked memory
+    (OT:1706-1711, MO:1454-1458) as bias rows.  Clip 0 against the oracle: <= 1e-3 px with the selections
+    pinned, equal keep set, the free run reproducing every oracle pose."""
+    _full_size_vs_oracle(3, 2, img_shapes=[(750, 1333), (800, 1333)])
 
 
 def test_t15_full_size_fp16_vs_oracle():

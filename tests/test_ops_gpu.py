@@ -1181,6 +1181,25 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
     assert torch.isfinite(outs[0]).all()
 
 
+def test_fill_rows_sets_listed_rows_only():
+    """pave_fill_rows_f32: the listed rows take the vector (or zeros), every other row is untouched, a row
+    index outside the matrix is skipped; row-strided views work (the value half of a wider matrix)."""
+    from pavenet_amd.ops import fill_rows_
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1000, 512, generator=g).cuda()
+    rows = torch.tensor([0, 7, 999, 500, 1000, -1, 7], dtype=torch.int32).cuda()
+    vals = torch.randn(256, generator=g).cuda()
+    exp = x.clone()
+    exp[[0, 7, 999, 500], :256] = vals
+    fill_rows_(x[:, :256], rows, vals)
+    assert torch.equal(x, exp)
+    exp[[0, 7, 999, 500], 256:] = 0
+    fill_rows_(x[:, 256:], rows, None)
+    assert torch.equal(x, exp)
+    fill_rows_(x, rows[:0], None)      # an empty list: nothing to do
+    assert torch.equal(x, exp)
+
+
 def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
     """pave_enc_deform_attn_tile_f32 called directly (ctypes): prepared input with the wide-window variant
     (5: the non-prepared kernel would read the null `ref`), (6) and bits above the 3-bit mask must come back
