@@ -88,10 +88,11 @@ int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_
  *              frame_table[c*T + t] instead of c*T + t -- `value` is then a per-frame cache
  *              [n_cached_frames, S, 8, 32] shared by overlapping clips (streaming windows of a video,
  *              opera/datasets/posetrack_video_pose.py:578-623: no per-window copy / re-projection).
- *              PRECONDITION: 0 <= frame_table[i] < n_cached_frames -- the entries are slab indices read
- *              on the device and are NOT range-checked (the number of cached slabs is not an argument);
- *              the caller that builds the table owns the check (pavenet_amd/streaming.py does it on the
- *              host list the table is made from, FrameSlabs.covers)
+ *              n_slabs = n_cached_frames (> 0 with a table; 0 or n_clips*T without): the entries are slab
+ *              indices read on the device; every slab index is CLAMPED into [0, n_slabs) there, so a bad
+ *              table reads a wrong frame of `value`, never memory outside it (a correct result still needs
+ *              0 <= frame_table[i] < n_slabs: pavenet_amd/streaming.py checks the host list the table is
+ *              made from, FrameSlabs.covers)
  *   out        [n_units, 256]
  *   stat_max, stat_sum  [n_units, 8] or NULL: per-head max logit and sum(exp(logit-max)) over the
  *              frames this call saw (for merging frame-sharded partial results)
@@ -108,13 +109,13 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
                                     int T, int S, int L, int P, int proj_stride,
-                                    const int32_t* frame_table, void* stream);
+                                    const int32_t* frame_table, int n_slabs, void* stream);
 
 int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start, const float* proj,
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
-                                    int K, int proj_stride, const int32_t* frame_table,
+                                    int K, int proj_stride, const int32_t* frame_table, int n_slabs,
                                     void* stream);
 
 /*
@@ -530,6 +531,15 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
  */
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int relu, int nplanes, void* stream);
+
+/*
+ * Exact merge of G partial attention rows of a frame-sharded T-frame attention (pavenet_amd/dist.py; SURVEY
+ * 8e: "all-gather of pose-query logits"): parts [G, U, C + 2 H] = per rank the softmax-weighted row over its
+ * frames (normalised by its own sum) followed by the per-head max logit and sum(exp(logit - max)) the fused
+ * kernels emit (stat_max, stat_sum) -> out [U, C], the row of ONE softmax over all ranks' logits.  A rank
+ * with sum = 0 (no frames) drops out.  C / H channels per head (a multiple of 4).
+ */
+int pave_merge_softmax_partials_f32(const float* parts, float* out, int G, int U, int C, int H, void* stream);
 
 /* x[n] fp32 -> planes[nplanes][n] bf16: truncation terms, the last rounded to nearest even
  * (nplanes = 3: x = p0 + p1 + p2 exactly). */

@@ -545,3 +545,54 @@ extern "C" int pave_ref_update_frames_f32(const float* y, const float* ref, floa
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
+
+// pave_merge_softmax_partials_f32
+// The frame-sharded T-frame attentions (BASELINE configs[4]: frame t on rank t % G) leave on every rank the
+// all-gathered [G, U, C + 2 H] buffer of per-rank partial rows (normalised by the rank's OWN sum) followed by the
+// per-head (max logit, sum exp) of the rank's frames; the exact row of a softmax over all ranks' logits is
+//   w_g = ssum_g exp(smax_g - max_g smax_g),   out = sum_g rows_g w_g / sum_g w_g
+// (a rank with ssum = 0 -- no frames -- drops out, its row is not read).  One launch instead of the ~10
+// elementwise launches of the torch formulation on the latency-bound decoder tail.
+namespace {
+__global__ __launch_bounds__(256) void merge_softmax_partials_kernel(const float* __restrict__ parts,
+                                                                      float* __restrict__ out, const int G,
+                                                                      const int U, const int C, const int H) {
+  const int c4n = C >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)U * c4n) return;
+  const int u = (int)(i / c4n), c = (int)(i - (long long)u * c4n) * 4;
+  const int h = c / (C / H);
+  const int ld = C + 2 * H;
+  float m = -INFINITY;
+  for (int g = 0; g < G; ++g) {
+    const float* row = parts + ((long long)g * U + u) * ld;
+    if (row[C + H + h] > 0.f) m = fmaxf(m, row[C + h]);
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float wsum = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float* row = parts + ((long long)g * U + u) * ld;
+    const float s = row[C + H + h];
+    if (!(s > 0.f)) continue;
+    const float w = s * expf(row[C + h] - m);
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    acc.x = fmaf(v.x, w, acc.x), acc.y = fmaf(v.y, w, acc.y), acc.z = fmaf(v.z, w, acc.z), acc.w = fmaf(v.w, w, acc.w);
+    wsum += w;
+  }
+  const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+  *reinterpret_cast<float4*>(out + (long long)u * C + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+}  // namespace
+
+extern "C" int pave_merge_softmax_partials_f32(const float* parts, float* out, int G, int U, int C, int H,
+                                               void* stream) {
+  if (!parts || !out) return pave_internal_fail(PAVE_E_ARG, "merge_softmax_partials: null pointer");
+  if (G <= 0 || U <= 0 || C <= 0 || H <= 0 || C % H != 0 || (C / H) % 4 != 0 || (2 * H) % 4 != 0)
+    return pave_internal_fail(PAVE_E_ARG, "merge_softmax_partials: C / H channels per head, a multiple of 4; H even");
+  const long long n = (long long)U * (C >> 2);
+  hipLaunchKernelGGL(merge_softmax_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), parts, out, G, U, C, H);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}

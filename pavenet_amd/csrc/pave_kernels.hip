@@ -238,6 +238,7 @@ struct FusedParams {
   int S;
   int L;
   int P;  // points per level (GRID: 4; POSE: K)
+  int n_slabs;  // frame slabs behind `value`: every slab index is clamped into [0, n_slabs)
   int proj_stride;
   int n_blocks_logical;
 };
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParam
     const int lp0 = (MODE == kGrid) ? 0 : lvl * P;
     const float* lg = logit_row + (t * kHeads + h) * LP + lp0;
     const float* of = off_row + ((long long)(t * kHeads + h) * LP + lp0) * 2;
-    const int slab = p.frame_table ? p.frame_table[clip * T + t] : clip * T + t;
+    // (clamped: a frame table / unit_clip entry outside the value tensor reads a wrong slab, never
+    // memory outside it)
+    const int slab = min(max(p.frame_table ? p.frame_table[clip * T + t] : clip * T + t, 0), p.n_slabs - 1);
     const char* frame = reinterpret_cast<const char*>(p.value) +
                         (long long)slab * p.S * rowbytes + j * 16;
 
@@ -1577,9 +1580,12 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
                                     int T, int S, int L, int P, int proj_stride,
-                                    const int32_t* frame_table, void* stream) {
+                                    const int32_t* frame_table, int n_slabs, void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_grid_fused: null pointer");
+  if (frame_table ? n_slabs <= 0 : (n_slabs != 0 && n_slabs != n_clips * T))
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: n_slabs = the frame slabs behind value (> 0 with a frame table; "
+                            "0 or n_clips * T without)");
   if (n_units <= 0 || T <= 0 || S <= 0 || n_clips <= 0 || units_per_clip <= 0)
     return fail(PAVE_E_ARG, "deform_attn_grid_fused: sizes must be positive");
   if (L != 4 || P != 4)
@@ -1601,6 +1607,7 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
   p.unit_clip = unit_clip;
   p.order = order;
   p.frame_table = frame_table;
+  p.n_slabs = frame_table ? n_slabs : n_clips * T;
   p.out = out;
   p.stat_max = stat_max;
   p.stat_sum = stat_sum;
@@ -1627,10 +1634,13 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     const int64_t* level_start, const float* proj,
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
-                                    int K, int proj_stride, const int32_t* frame_table,
+                                    int K, int proj_stride, const int32_t* frame_table, int n_slabs,
                                     void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_pose_fused: null pointer");
+  if (frame_table ? n_slabs <= 0 : (n_slabs != 0 && n_slabs != n_clips * T))
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: n_slabs = the frame slabs behind value (> 0 with a frame table; "
+                            "0 or n_clips * T without)");
   if (n_clips <= 0 || Q <= 0 || T <= 0 || S <= 0 || K <= 0)
     return fail(PAVE_E_ARG, "deform_attn_pose_fused: sizes must be positive");
   if (L < 1 || L > 4) return fail(PAVE_E_ARG, "deform_attn_pose_fused: 1 <= L <= 4 levels");
@@ -1650,6 +1660,7 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
   p.unit_clip = nullptr;
   p.order = nullptr;
   p.frame_table = frame_table;
+  p.n_slabs = frame_table ? n_slabs : n_clips * T;
   p.out = out;
   p.stat_max = stat_max;
   p.stat_sum = stat_sum;

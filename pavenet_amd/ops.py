@@ -220,8 +220,8 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_grid_fused: value must be [frames, S, 8, 32]')
     if frame_table is not None:   # value = per-frame cache, slab of (clip, t) = frame_table[clip*T + t]
-        # (entries must be < value.shape[0]: checked where the table is built, streaming.decode --
-        # a device-side check here would be a host sync per launch)
+        # (entries must be < value.shape[0]: checked where the table is built, streaming.decode; the
+        # kernel clamps every slab index into the value tensor, so a bad table cannot fault)
         _dev(frame_table, 'frame_table', torch.int32)
         _require(frame_table.numel() == n_clips * T, 'deform_attn_grid_fused: frame_table [n_clips*T]')
     else:
@@ -253,7 +253,7 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, n_units, int(units_per_clip),
             int(n_clips), int(T), S, L, 4, proj.stride(0),
-            frame_table.data_ptr() if frame_table is not None else None, _stream_ptr())
+            frame_table.data_ptr() if frame_table is not None else None, int(value.shape[0]), _stream_ptr())
     native.check(st, 'deform_attn_grid_fused')
     if return_stats:
         return out, smax, ssum
@@ -307,7 +307,7 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, int(n_clips), Q, int(T), S, L, K,
             proj.stride(0), frame_table.data_ptr() if frame_table is not None else None,
-            _stream_ptr())
+            int(value.shape[0]), _stream_ptr())
     native.check(st, 'deform_attn_pose_fused')
     if return_stats:
         return out, smax, ssum
@@ -984,6 +984,21 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
                                          M, K, N, int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_ex')
     return out, out2
+
+
+def merge_softmax_partials(parts, C, H):
+    """parts [G, U, C + 2 H] (all-gathered partial rows | per-head max | per-head sum-exp) -> [U, C]: the
+    exact full-softmax row (pave_merge_softmax_partials_f32), one launch."""
+    lib = native.load()
+    _dev(parts, 'parts', torch.float32)
+    _require(parts.dim() == 3 and parts.shape[2] == C + 2 * H, 'merge_softmax_partials: parts [G, U, C + 2 H]')
+    G, U = parts.shape[0], parts.shape[1]
+    out = torch.empty((U, C), dtype=torch.float32, device=parts.device)
+    with torch.cuda.device(parts.device):
+        st = lib.pave_merge_softmax_partials_f32(parts.data_ptr(), out.data_ptr(), G, U, int(C), int(H),
+                                                 _stream_ptr())
+    native.check(st, 'merge_softmax_partials')
+    return out
 
 
 def mha_core(qkv, n_seq, seq_len, num_heads):

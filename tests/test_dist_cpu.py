@@ -84,6 +84,71 @@ def test_world_size_2_gloo(tmp_path):
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
+def _worker8(rank, world, port, tmp):
+    """World size 8, the driver's first multi-rank shape: BASELINE configs[4]'s T = 15 over 8 ranks gives
+    2, 2, 2, 2, 2, 2, 2, 1 frames per rank with the centre frame (7) on rank 7 -- the one rank that owns a
+    single frame; every collective of the frame-sharded forward and the clip-parallel result exchange with
+    those shapes."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pavenet_amd import dist as pd
+        T, U, H, P, D = 15, 6, 8, 60, 32
+        shard = pd.FrameShard(T, rank, world)
+        assert shard.local == [t for t in range(T) if t % 8 == rank]
+        assert shard.n_local == (1 if rank == 7 else 2)
+        assert shard.center == 7 and shard.center_owner == 7
+        assert shard.owns_center() == (rank == 7)
+        if rank == 7:
+            assert shard.local_index_of_center() == 0
+        # the proposals of the centre frame: broadcast from the single-frame rank
+        sel = torch.arange(300, dtype=torch.float32) * (1.0 if rank == 7 else -1.0)
+        pd.broadcast_from(sel, shard.center_owner)
+        assert torch.equal(sel, torch.arange(300, dtype=torch.float32))
+        # the T-frame attention: every rank's partial row over ITS frames, one all-gather, exact merge
+        gs = torch.Generator().manual_seed(11)       # the same logits / values on every rank
+        logits = torch.randn(U, T, H, P, generator=gs) * 4
+        logits[1, 7] += 70.0                         # the single-frame rank's frame dominates one query
+        logits[2, 0] += 70.0
+        vals = torch.randn(U, T, H, P, D, generator=gs)
+        row, m, s = _partial(logits, vals, shard.local)
+        merged = pd.all_gather_merge(row, m, s)
+        full, _, _ = _partial(logits, vals, list(range(T)))
+        np.testing.assert_allclose(merged.numpy(), full.numpy(), rtol=2e-5, atol=2e-5)
+        # five such layers in a row (3 pose-decoder + 2 joint-decoder layers), different unit counts
+        for units in (300, 300, 300, 20 * 15, 20 * 15):
+            r_ = torch.randn(units, H * D, generator=gs)
+            m_ = torch.randn(units, H, generator=gs)
+            s_ = torch.rand(units, H, generator=gs) + 0.1
+            out = pd.all_gather_merge(r_, m_, s_)      # (identical inputs on every rank: the merge of equals)
+            np.testing.assert_allclose(out.numpy(), r_.numpy(), rtol=1e-5, atol=1e-6)
+        # clip-parallel result exchange, 4 clips per rank, 20 poses, 15 key points (the bench's shapes)
+        B, N, K = 4, 20, 15
+        g = torch.Generator().manual_seed(500 + rank)
+        res = dict(bboxes=torch.randn(B, N, 5, generator=g), kpts=torch.randn(B, N, K, 3, generator=g),
+                   keep=(torch.rand(B, N, generator=g) > 0.5).int())
+        allr = pd.all_gather_results(res)
+        assert allr.shape == (8, B, N * (5 + 3 * K + 1))
+        for r in range(8):
+            gr = torch.Generator().manual_seed(500 + r)
+            assert torch.equal(pd.unpack_results(allr[r], N, K)['bboxes'], torch.randn(B, N, 5, generator=gr))
+        # T = 7 on 8 ranks: refused on every rank before any collective is entered
+        with pytest.raises(AssertionError):
+            pd.FrameShard(7, rank, world)
+        dist.barrier()
+        open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_t15_layout(tmp_path):
+    """No rank count other than 2 had executed before the driver's 8-GPU run: the collectives of both shard
+    modes at world size 8 (gloo, CPU), with the T = 15 frame layout of BASELINE configs[4]."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
 def test_merge_is_exact_for_any_split():
     from pavenet_amd import dist as pd
     T, U, H, P, D = 7, 4, 8, 15, 32

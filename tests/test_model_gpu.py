@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_within_half_pixel',
              'test_forward_is_the_same_from_the_first_call_and_reads_no_stale_memory',
              'test_frame_sharded_two_ranks', 'test_t15_frame_sharded_vs_oracle',
+             'test_frame_sharded_center_frame_on_a_single_frame_rank_vs_oracle',
              'test_bench_multi_rank_code_path_on_one_gpu', 'test_split_caches_follow_reloaded_weights',
              'test_derived_operand_caches_follow_reloaded_weights',
              'test_oks_nms_kernel_vs_oracle', 'test_oks_nms_kernel_survives_nan_and_inf',
@@ -380,6 +381,15 @@ def test_t15_frame_sharded_vs_oracle(gemm, tol_px, nproc):
     softmax rows merged by all-gather, projections in fp32 or with fp16 MFMA operands -- against
     the ORACLE's un-sharded fp32 run (fp32: 1e-2 px; fp16 projections: 0.5 px)."""
     assert 'sharded == oracle: True' in _run_sharded_worker([15, gemm, tol_px], nproc)
+
+
+def test_frame_sharded_center_frame_on_a_single_frame_rank_vs_oracle():
+    """The shape of the driver's 8-GPU run of BASELINE configs[4] (T = 15 over 8 ranks: 2, ..., 2, 1 frames, the
+    centre frame on the LAST rank, the only one that owns a single frame) at the largest world the box's
+    process guard allows on one GPU: T = 9 over 5 ranks = 2, 2, 2, 2, 1 frames, centre frame 4 on rank 4 --
+    proposals broadcast from the single-frame rank, five all-gather merges -- against the oracle's un-sharded
+    run (the world-size-8 collectives themselves run on gloo / CPU in tests/test_dist_cpu.py)."""
+    assert 'sharded == oracle: True' in _run_sharded_worker([9, 'native', 1e-2], 5)
 
 
 @pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'opera.PETRHead'),
@@ -842,14 +852,14 @@ def test_t15_full_size_unsharded_vs_oracle():
 
 
 def test_padded_batch_full_size_vs_oracle():
-    """A PADDED batch at full size on the encoder's fast path: two clips of T = 3 in an 800 x 1344 batch with
-    valid sizes 750 x 1333 and 800 x 1333 (the reference's test pipeline pads to a multiple of 32,
+    """A PADDED batch at full size on the encoder's fast path: two clips of T = 7 in an 800 x 1344 batch with
+    valid sizes 800 x 1333 and 750 x 1333 (the reference's test pipeline pads to a multiple of 32,
     configs/_base_/datasets/coco_keypoint.py:79; masks per clip from img_shape, HEAD:429-445) -- two runs of
     frames with their own positional table, padding pattern and valid ratios through the merged projection
     GEMM + one sampler launch, value rows of masked tokens zeroed (MO:369-371), the decoders' masked memory
     (OT:1706-1711, MO:1454-1458) as bias rows.  Clip 0 against the oracle: <= 1e-3 px with the selections
     pinned, equal keep set, the free run reproducing every oracle pose."""
-    _full_size_vs_oracle(3, 2, img_shapes=[(750, 1333), (800, 1333)])
+    _full_size_vs_oracle(7, 2, img_shapes=[(800, 1333), (750, 1333)])
 
 
 def test_t15_full_size_fp16_vs_oracle():

@@ -256,6 +256,58 @@ def test_softmax_is_stabilised():
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_frame_table_entries_outside_the_value_cache_cannot_fault():
+    """The fused T-frame kernels address `value` through a frame table of slab indices read on the device
+    (streaming: per-frame caches shared by overlapping windows).  The C entry takes the number of slabs and the
+    kernels clamp every index into it: a table with entries far outside the cache gives exactly what the
+    clamped table gives -- a wrong frame, never an access outside the tensor (advisor finding, round 3)."""
+    from pavenet_amd.ops import deform_attn_grid_fused, deform_attn_pose_fused
+    shapes, lsi, sd, ld = _levels(LEVELS)
+    S = int(shapes.prod(1).sum())
+    T, U, n_cached = 3, 8, 5
+    value = _t(seeded_array('ft.value', (n_cached, S, 8, 32))).cuda()
+    proj = _t(seeded_array('ft.proj', (U, T * 8 * 16 * 3))).cuda()
+    ref = (_t(seeded_array('ft.ref', (T, U, 4, 2), 0.2)) + 0.5).cuda()
+    bad = torch.tensor([4, 2 ** 30, -7], dtype=torch.int32).cuda()
+    ok = torch.tensor([4, n_cached - 1, 0], dtype=torch.int32).cuda()
+    kw = dict(T=T, n_clips=1, units_per_clip=U)
+    a = deform_attn_grid_fused(value, sd, ld, proj, ref, frame_table=bad, **kw)
+    b = deform_attn_grid_fused(value, sd, ld, proj, ref, frame_table=ok, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    K = 15
+    pproj = _t(seeded_array('ft.pproj', (U, T * 8 * 4 * K * 3))).cuda()
+    pref = (_t(seeded_array('ft.pref', (1, T * U, 4, 2 * K), 0.2)) + 0.5).cuda()
+    pk = dict(T=T, n_clips=1, num_query=U, num_keypoints=K)
+    a = deform_attn_pose_fused(value, sd, ld, pproj, pref, frame_table=bad, **pk)
+    b = deform_attn_pose_fused(value, sd, ld, pproj, pref, frame_table=ok, **pk)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_merge_softmax_partials_kernel_vs_host_formulation():
+    """pave_merge_softmax_partials_f32 (the frame-sharded attentions' exact softmax merge as one launch) against
+    pavenet_amd.dist.merge_softmax_partials in fp64: dominated ranks, a rank without frames (sum = 0, max = -inf,
+    garbage row) and G = 1 ... 8."""
+    from pavenet_amd import dist as pd
+    from pavenet_amd.ops import merge_softmax_partials
+    g = torch.Generator().manual_seed(9)
+    for G in (1, 2, 5, 8):
+        U, C, H = 300, 256, 8
+        rows = torch.randn(G, U, C, generator=g)
+        smax = torch.randn(G, U, H, generator=g) * 10
+        ssum = torch.rand(G, U, H, generator=g) * 50 + 0.01
+        if G > 2:
+            smax[1] += 80.0                       # one rank dominates
+            ssum[2] = 0.0                         # a rank that owns no frame: dropped, its row not read
+            smax[2] = float('-inf')
+            rows[2] = float('nan')
+        parts = torch.cat([rows, smax, ssum], 2).cuda()
+        got = merge_softmax_partials(parts, C, H).cpu()
+        exp = pd.merge_softmax_partials(torch.nan_to_num(rows).double(), smax.double(), ssum.double(), H)
+        np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_full_size_linearity():
     """At BASELINE's full size (S = 22 323, 800x1344) the oracle is too slow to run whole:
     check size-independent properties instead -- linearity in value, a constant map sampled
