@@ -74,6 +74,11 @@ def parse():
     ap.add_argument('--graph', type=int, default=0,
                     help='replay the forward as one hipGraph (opt-in: pays off for small batches; '
                          'the 28-frame headline batch is GPU-bound without it)')
+    ap.add_argument('--tail-graph', type=int, default=1,
+                    help='replay everything behind the encoder (proposals, decoders, post-processing: ~170 '
+                         'launch-bound dispatches) as ONE hipGraph; backbone / neck / encoder stay eager and '
+                         'keep their per-launch events (pavenet_amd.graph.TailGraphedForward; single stream, '
+                         'clip-parallel only; falls back to eager if the capture fails its self-check)')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='steps in flight: P > 1 runs consecutive steps (independent batches) on P HIP '
                          'streams, so the launch-bound decoder / post-processing tail of step i overlaps '
@@ -303,10 +308,26 @@ def secondary_workloads(args, dev, budget_s=90.0):
         g = torch.Generator(device=dev).manual_seed(4321)
         img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
         host = None
+        tail, tail_note = None, 'off'
+        if args.tail_graph:
+            from pavenet_amd import GRAPH_REPLAY_SAFE
+            from pavenet_amd.graph import TailGraphedForward
+            try:
+                if GRAPH_REPLAY_SAFE:
+                    tail = TailGraphedForward(model, img, metas)
+                    with torch.no_grad():
+                        a_, b_ = model.forward_device(img, metas), tail(img)
+                        torch.cuda.synchronize()
+                    if all(torch.equal(a_[k], b_[k]) for k in ('bboxes', 'kpts', 'keep')):
+                        tail_note = 'on'
+                    else:
+                        tail, tail_note = None, 'off: the replay differed from the eager forward'
+            except Exception as e:
+                tail, tail_note = None, f'off: capture failed ({type(e).__name__}: {e})'[:200]
 
         def step():
             nonlocal host
-            res = model.forward_device(img, metas)
+            res = tail(img) if tail is not None else model.forward_device(img, metas)
             packed = torch.cat([res['bboxes'].flatten(1), res['kpts'].flatten(1), res['keep'].float()], dim=1)
             if host is None:
                 host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
@@ -337,7 +358,7 @@ def secondary_workloads(args, dev, budget_s=90.0):
         fl = sum(f for _, _, _, f in ev)
         nbytes = sum(algorithmic_bytes_gemm_launch(e_[0], sh) for e_, sh in zip(ev, shapes))
         peak = MFMA_PEAK[gemm]
-        rec = dict(workload=label, steps=steps, warmup=warmup,
+        rec = dict(workload=label, steps=steps, warmup=warmup, tail_graph=tail_note,
                    ms_per_step=round(dt / steps * 1e3, 3), clips_per_s=round(B * steps / dt, 3),
                    split_class_tflops=round(fl / tt / 1e12, 1) if tt > 0 else None,
                    split_class_ms_per_step=round(tt / ev_steps * 1e3, 3),
@@ -356,6 +377,7 @@ def secondary_workloads(args, dev, budget_s=90.0):
             rec.update(bound='mfma', peak_tflops=round(peak, 1),
                        frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None)
         out.append(rec)
+        tail = None
         del img
     model = None
     torch.cuda.empty_cache()
@@ -456,8 +478,30 @@ def main():
     if args.graph:
         from pavenet_amd.graph import GraphedForward
         graphed = GraphedForward(model, img, metas)
+    tail_graph, tail_note = None, None
+    if args.tail_graph and not args.graph and shard is None and args.pipeline == 1 and not frame_sharded:
+        from pavenet_amd import GRAPH_REPLAY_SAFE
+        from pavenet_amd.graph import TailGraphedForward
+        if not GRAPH_REPLAY_SAFE:
+            tail_note = 'off: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not set before HIP started'
+        else:
+            try:
+                tail_graph = TailGraphedForward(model, img, metas)
+                # self-check on the timed batch: the replay must give what the eager forward gives
+                with torch.no_grad():
+                    ref_res = model.forward_device(img, metas)
+                    got_res = tail_graph(img)
+                    torch.cuda.synchronize()
+                same = all(torch.equal(ref_res[k], got_res[k]) for k in ('bboxes', 'kpts', 'keep'))
+                if not same:
+                    tail_graph, tail_note = None, 'off: the replay differed from the eager forward'
+                else:
+                    tail_note = 'on: proposals / decoders / post-processing replayed as one hipGraph per step'
+            except Exception as e:      # a capture problem must not cost the run
+                tail_graph, tail_note = None, f'off: capture failed ({type(e).__name__}: {e})'[:200]
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(2, args.pipeline))]
+    TAIL_ON = [True]     # (the two-batches-in-flight side run is eager: one capture serves one stream)
 
     host_bufs = {}
 
@@ -475,6 +519,8 @@ def main():
     def step(slot=-1):
         if graphed is not None:
             res = graphed(img)
+        elif tail_graph is not None and TAIL_ON[0]:
+            res = tail_graph(img)
         elif shard is not None:
             res = model.forward_device(img, metas, frame_shard=shard)
         else:
@@ -555,7 +601,9 @@ def main():
     if args.gemm != 'native' and graphed is None and not args.no_native_side and world == 1:
         # the same workload on the vendor fp32-MFMA kernels, printed beside the headline
         set_gemm_mode('native')
+        TAIL_ON[0] = False          # (the captured tail holds the headline mode's kernels)
         native_dt, _, _ = timed(False)
+        TAIL_ON[0] = True
         set_gemm_mode(args.gemm)
     dt, events, last = timed(True)
     last = last.clone()     # (the pinned result buffer is reused by later runs)
@@ -564,7 +612,9 @@ def main():
     if args.pipeline == 1 and world == 1 and graphed is None and not args.no_native_side:
         # the same K steps with two batches in flight (two HIP streams): throughput of a serving loop;
         # reported beside the headline, whose kernels run alone (clean per-kernel event times)
+        TAIL_ON[0] = False
         pipe_dt, _, _ = timed(False, 2)
+        TAIL_ON[0] = True
     timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl, _ in events]
     shaped_ev = [(tag, s.elapsed_time(e) * 1e-3, fl, sh) for tag, s, e, fl, sh in events]
     enc = [(tag, t) for tag, t, _ in timed_ev if tag in ('enc_tile', 'enc_grid_T1')]
@@ -675,7 +725,7 @@ def main():
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
                                 parallelism=unit_note, gemm=args.gemm,
-                                gemm_select=args.gemm_select,
+                                gemm_select=args.gemm_select, tail_graph=tail_note,
                                 detections_last_step=int(last[..., -N:].sum().item())),
                     backend=backend, ranks_seen=ranks_seen, devices=devices,
                     roofline=roofline_mfma if roofline_mfma is not None else roofline,

@@ -57,3 +57,66 @@ class GraphedForward:
         self.static_in.copy_(img, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class TailGraphedForward:
+    """Eager backbone / neck / encoder + ONE hipGraph for everything behind the encoder.
+
+    ``g = TailGraphedForward(model, example_img, img_metas); res = g(img)``.
+
+    The step has two regimes: up to the end of the encoder it is ~80 large launches (GPU-bound: the host runs
+    ahead), behind it ~170 dependent launches of 4 - 150 us on a few hundred query rows -- two-stage proposals,
+    top-k, the three pose-decoder and two joint-decoder layers, post-processing, OKS-NMS -- where the 14 - 20 us
+    a launch costs through the Python wrappers is most of the wall time.  That tail (the reference's
+    OT:21340-21456 + forward_refine + HEAD:1371-1505) is captured once per input shape and replayed; its one
+    input is the encoder memory, copied into the capture's static buffer (the eager half allocates its own),
+    its outputs are the head's fixed-shape result tensors (static buffers: clone what must survive the next call).
+    The eager half keeps its per-launch HIP events (bench.py's roofline), the tail has none inside the graph.
+    Frame-sharded multi-GPU forwards are not captured (collectives inside the tail)."""
+
+    def __init__(self, model, example_img, img_metas, rescale=False, warmup=2, **head_kwargs):
+        assert example_img.is_cuda
+        from . import ops
+        self.model, self.img_metas, self.rescale, self.head_kwargs = model, img_metas, rescale, head_kwargs
+        assert 'frame_shard' not in head_kwargs, 'TailGraphedForward: not for frame-sharded forwards'
+        saved, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None  # no event records inside a capture
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(warmup):      # builds every cache of both halves
+                    memory, ctx = self._encode(example_img)
+                    self._tail(memory, ctx)
+                # strides kept: the tail's views (frame-major permutes) expect the encoder's own layout
+                self.static_memory = memory.clone(memory_format=torch.preserve_format)
+                self.ctx = ctx
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.static_out = self._tail(self.static_memory, self.ctx)
+        finally:
+            ops.KERNEL_EVENTS = saved
+
+    def _encode(self, img):
+        head = self.model.bbox_head
+        feat = self.model.extract_feat(img)
+        masks, pos, has_padding = head.make_masks(feat, self.img_metas)
+        memory, mask_flatten, valid_ratios, geom = head.transformer.encode_frames(feat, masks, pos, has_padding)
+        return memory, (masks, pos, has_padding, mask_flatten, valid_ratios, geom)
+
+    def _tail(self, memory, ctx):
+        masks, pos, has_padding, mask_flatten, valid_ratios, geom = ctx
+        head = self.model.bbox_head
+        kw = dict(self.head_kwargs)
+        kw.setdefault('last_level_only', True)
+        outs = head(None, self.img_metas, precomputed=(masks, pos, has_padding,
+                                                        (memory, mask_flatten, valid_ratios, geom)), **kw)
+        return head.get_bboxes(outs, self.img_metas, rescale=self.rescale)
+
+    @torch.no_grad()
+    def __call__(self, img):
+        memory, _ = self._encode(img)          # eager (the masks / encodings of `ctx` are per-shape constants)
+        self.static_memory.copy_(memory)
+        self.graph.replay()
+        return self.static_out

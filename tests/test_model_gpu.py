@@ -21,7 +21,8 @@ _OWN_MODE = ('test_split_gemm_mode_matches_native', 'test_fp16_projection_mode_w
              'test_derived_operand_caches_follow_reloaded_weights',
              'test_oks_nms_kernel_vs_oracle', 'test_oks_nms_kernel_survives_nan_and_inf',
              'test_deterministic_mode_is_bit_reproducible_and_matches_default',
-             'test_hipgraph_replay_equals_eager', 'test_bench_batch_full_size_t7_b4_vs_oracle',
+             'test_hipgraph_replay_equals_eager', 'test_tail_hipgraph_replay_equals_eager',
+             'test_bench_batch_full_size_t7_b4_vs_oracle',
              'test_hrnet_w48_full_size_t7_vs_oracle', 'test_t15_full_size_unsharded_vs_oracle',
              'test_t15_full_size_fp16_vs_oracle', 'test_padded_batch_full_size_vs_oracle',
              'test_neck_eval_with_grad_keeps_the_differentiable_path')
@@ -386,10 +387,11 @@ def test_t15_frame_sharded_vs_oracle(gemm, tol_px, nproc):
 def test_frame_sharded_center_frame_on_a_single_frame_rank_vs_oracle():
     """The shape of the driver's 8-GPU run of BASELINE configs[4] (T = 15 over 8 ranks: 2, ..., 2, 1 frames, the
     centre frame on the LAST rank, the only one that owns a single frame) at the largest world the box's
-    process guard allows on one GPU: T = 9 over 5 ranks = 2, 2, 2, 2, 1 frames, centre frame 4 on rank 4 --
-    proposals broadcast from the single-frame rank, five all-gather merges -- against the oracle's un-sharded
-    run (the world-size-8 collectives themselves run on gloo / CPU in tests/test_dist_cpu.py)."""
-    assert 'sharded == oracle: True' in _run_sharded_worker([9, 'native', 1e-2], 5)
+    process guard allows on one GPU (6 processes with the device open: this one, the launcher and 4 ranks):
+    T = 7 over 4 ranks = 2, 2, 2, 1 frames, centre frame 3 on rank 3 -- proposals broadcast from the
+    single-frame rank, five all-gather merges -- against the oracle's un-sharded run (the world-size-8
+    collectives themselves run on gloo / CPU in tests/test_dist_cpu.py)."""
+    assert 'sharded == oracle: True' in _run_sharded_worker([7, 'native', 1e-2], 4)
 
 
 @pytest.mark.parametrize('name,K,head', [('e2e_petr_r50', 17, 'opera.PETRHead'),
@@ -546,6 +548,34 @@ def test_hipgraph_replay_equals_eager():
         for k in ('bboxes', 'kpts', 'keep'):
             _close(got[k].float().cpu().numpy(),
                                        exp[k].float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_tail_hipgraph_replay_equals_eager():
+    """pavenet_amd.graph.TailGraphedForward: backbone / neck / encoder eager, everything behind the encoder
+    (proposals, top-k, both decoders, post-processing, OKS-NMS) replayed as one hipGraph -- the same values as
+    the eager forward, for new inputs too, on a padded two-clip batch (per-clip masks, valid ratios and the
+    masked-row fills are inside the capture) and in the headline GEMM mode."""
+    from pavenet_amd import bricks
+    from pavenet_amd.graph import TailGraphedForward
+    m = _build(3, 12)
+    metas = [dict(batch_input_shape=(128, 160), img_shape=(120, 150, 3), scale_factor=(1., 1., 1., 1.)),
+             dict(batch_input_shape=(128, 160), img_shape=(128, 141, 3), scale_factor=(1., 1., 1., 1.))]
+    a = _t(seeded_array('tailgraph.a', (2, 3, 3, 128, 160))).cuda()
+    b = _t(seeded_array('tailgraph.b', (2, 3, 3, 128, 160))).cuda()
+    bricks.set_gemm_mode('bf16x3')
+    old_rows = bricks._GEMM['min_rows']
+    bricks._GEMM['min_rows'] = 1
+    try:
+        with torch.no_grad():
+            g = TailGraphedForward(m, a, metas)
+            for img in (a, b, a):
+                got = {k: v.clone() for k, v in g(img).items()}
+                exp = m.forward_device(img, metas)
+                for k in ('bboxes', 'kpts', 'keep'):
+                    assert torch.equal(got[k], exp[k]), k      # (the split kernels are run-to-run reproducible)
+    finally:
+        bricks._GEMM['min_rows'] = old_rows
+        bricks.set_gemm_mode('native')
 
 
 def test_swin_l_t3_vs_reference_golden(golden_dir):
