@@ -264,7 +264,7 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     return base, parity
 
 
-def secondary_workloads(args, dev, budget_s=90.0):
+def secondary_workloads(args, dev, budget_s=100.0):
     """The other BASELINE configurations on the driver's clock (`extra` of the JSON line): short
     single-stream runs -- 3 warm-up + 10 timed steps each, results copied to the host per step as in
     the headline, the split-GEMM class timed by HIP events over the last 3 steps -- of configs[1]
@@ -284,12 +284,14 @@ def secondary_workloads(args, dev, budget_s=90.0):
             ('configs[1]', 'r50', 3, 1, 'bf16x3', None),
             ('configs[3] on one GPU', 'hrnet_w48', 7, 4, 'bf16x3', None),
             ('configs[4] shape on one GPU', 'r50', 15, 1, 'bf16x3', None),
-            ('configs[4] shape on one GPU, fp16-operand projections', 'r50', 15, 1, 'fp16', None)]
+            ('configs[4] shape on one GPU, fp16-operand projections', 'r50', 15, 1, 'fp16', None),
+            # the reference's flagship backbone (configs/videopose/2025-2-7/2025_2_7_swin_num_frames_3_posetrack17.py)
+            ('Swin-L T=3 (the reference\'s 2025-2-7 config)', 'swin_l', 3, 1, 'bf16x3', None)]
     out, t_begin, model, key = [], time.perf_counter(), None, None
     steps, warmup, ev_steps = 10, 3, 3
     for name, backbone, T, B, gemm, shapes in todo:
-        label = (f'{name}: PAVE-Net {"R-50" if backbone == "r50" else "HRNet-w48"} T={T}, batch={B} clips, '
-                 f'{args.height}x{args.width}, gemm={gemm}')
+        bname = {'r50': 'R-50', 'hrnet_w48': 'HRNet-w48', 'swin_l': 'Swin-L'}[backbone]
+        label = f'{name}: PAVE-Net {bname} T={T}, batch={B} clips, {args.height}x{args.width}, gemm={gemm}'
         if time.perf_counter() - t_begin > budget_s:
             out.append(dict(workload=label, skipped=f'secondary budget of {budget_s:.0f} s used up'))
             continue
@@ -299,6 +301,9 @@ def secondary_workloads(args, dev, budget_s=90.0):
             mcfg = videopose_r50_cfg(num_frames=T, max_per_img=args.max_per_img)
             if backbone == 'hrnet_w48':
                 mcfg = with_hrnet_w48(mcfg)
+            elif backbone == 'swin_l':
+                from pavenet_amd.models import with_swin_l
+                mcfg = with_swin_l(mcfg, num_frames=T)
             model = init_random_weights(build_model(mcfg), seed=0).to(dev).eval()
             key = (backbone, T)
         set_gemm_mode(gemm)

@@ -216,7 +216,7 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
  *                       bias, residual-add and ReLU kernels behind conv / Linear
  *                       (mmdet resnet.py Bottleneck.forward, mmcv FFN).
  *   bias_add_layernorm: y[r,:] = LayerNorm(x[r,:] + bias + res[r,:]) * gamma + beta,
- *                       C % 4 == 0, C <= 1024 (the 'attn/ffn -> + identity -> norm' step of
+ *                       C % 4 == 0, C <= 3072 (the 'attn/ffn -> + identity -> norm' step of
  *                       mmcv BaseTransformerLayer.forward, bricks/transformer.py:1316-1353).
  */
 /*
@@ -348,7 +348,9 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
  *                plain fp16 operands (BASELINE config 5's "fp16 MFMA projections") -- always
  *                with fp32 accumulation and fp32 in/out.
  *   out[M, N] = act(A'[M, K] * W[N, K]^T + bias[N] + residual[M, N]),
- *   A' = a_bias ? relu(a + a_bias[K]) : a
+ *   A' = a_bias ? relu(a + a_bias[K]) : a;  act: relu = 0 none | 1 ReLU | 2 exact GELU x Phi(x) (nn.GELU, the
+ *   activation of the Swin block's FFN, third_party/mmdetection/mmdet/models/backbones/swin.py:330-341;
+ *   3 planes / fp16 only)
  * = nn.Linear (mmcv FFN / projections, bricks/transformer.py:1046-1120) with the residual and
  * activation of its caller in the epilogue.  `w_planes` = the weight [N, K] split once by
  * pave_split_bf16x3_f32 into `nplanes` bf16 planes and re-laid slab-major [K/16][nplanes][N][16]
@@ -531,6 +533,23 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
  */
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int relu, int nplanes, void* stream);
+
+/*
+ * The (shifted-)window multi-head self-attention core of a Swin block -- ShiftWindowMSA.forward around
+ * WindowMSA.forward, third_party/mmdetection/mmdet/models/backbones/swin.py:22-126, 128-286 -- on the
+ * UN-partitioned token map (pad to a multiple of the window, roll by -shift, window partition, relative-position
+ * bias, the -100 mask between roll regions, softmax, PV, window reverse, reverse roll and crop are all index
+ * arithmetic inside the kernel; no copy of the map, no mask tensor):
+ *   qkv [B, H, W, 3 C] fp32 = the block's qkv Linear per token (q | k | v, each [heads][32]);
+ *   bias_t [heads, ws^2 (key j), ws^2 (query i)] = relative_position_bias_table[relative_position_index],
+ *     TRANSPOSED per head (lanes = queries read consecutive addresses);
+ *   pad_qkv [3 C] = the qkv Linear's bias: what a zero pad token projects to (the reference pads BEFORE qkv);
+ *   out [B, H, W, C]: the attention output at every real pixel, the input of `proj`.
+ * scale = head_dim^-0.5 (or qk_scale).  Built for window 7, head dim 32 (C == heads * 32): every Swin variant
+ * of the reference's configs.
+ */
+int pave_swin_window_attn_f32(const float* qkv, const float* bias_t, const float* pad_qkv, float* out, int B,
+                              int H, int W, int C, int heads, int window, int shift, float scale, void* stream);
 
 /*
  * Exact merge of G partial attention rows of a frame-sharded T-frame attention (pavenet_amd/dist.py; SURVEY

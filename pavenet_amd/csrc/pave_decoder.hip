@@ -596,3 +596,125 @@ extern "C" int pave_merge_softmax_partials_f32(const float* parts, float* out, i
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
+
+// pave_swin_window_attn_f32
+// The (shifted-)window multi-head self-attention core of a Swin block (ShiftWindowMSA.forward + WindowMSA.forward,
+// third_party/mmdetection/mmdet/models/backbones/swin.py:22-126, 128-286) on the UN-partitioned token map:
+//   qkv [B, H, W, 3 C] = the block's qkv Linear applied per token (a Linear commutes with every permutation of
+//   the rows), out [B, H, W, C] = what `window_reverse` + the reverse roll + the crop return, ready for `proj`.
+// One wave per (window, head): lane i < ws^2 owns query token i of the window.  The reference pads the map to a
+// multiple of the window (zeros BEFORE the qkv Linear: a pad token's q | k | v is the Linear's bias), rolls it by
+// -shift, cuts windows, adds the relative-position bias and -- for shifted windows -- the -100 mask between
+// tokens of different roll regions, and undoes all of it afterwards; here every lane computes the source pixel of
+// its token ((window row * ws + iy + shift) mod H_pad, ...), takes the bias vector for a pad pixel, derives its
+// mask region from the shifted coordinates (swin.py:213-231: three bands per axis) and writes its output row
+// straight to its source pixel -- no pad / roll / partition / reverse copies, no mask tensor.
+// K and V of the head sit in LDS (rows padded to 36 dwords: conflict-free 16-byte stores; the key loop reads one
+// row per step, broadcast to the whole wave); two passes over the ws^2 keys (scores kept in registers):
+// max, then exp / sum / PV.  head dim 32 (every Swin variant), ws^2 <= 64 (window 7: 49 tokens).
+namespace {
+template <int WS>
+__global__ __launch_bounds__(64) void swin_window_attn_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ bias_t, const float* __restrict__ pad_qkv,
+    float* __restrict__ out, const int B, const int H, const int W, const int C, const int heads,
+    const int shift, const float scale) {
+  constexpr int N = WS * WS;
+  __shared__ __attribute__((aligned(16))) float ks[N * kPad];
+  __shared__ __attribute__((aligned(16))) float vs[N * kPad];
+  __shared__ int regs[N];
+  const int lane = threadIdx.x;
+  const int nwx = (W + WS - 1) / WS, nwy = (H + WS - 1) / WS;
+  const int Hp = nwy * WS, Wp = nwx * WS;
+  int bid = blockIdx.x;
+  const int h = bid % heads;
+  bid /= heads;
+  const int wx = bid % nwx;
+  bid /= nwx;
+  const int wy = bid % nwy;
+  const int b = bid / nwy;
+  const bool act = lane < N;
+  const int iy = act ? lane / WS : 0, ix = act ? lane % WS : 0;
+  const int ys = wy * WS + iy, xs = wx * WS + ix;          // coordinates in the rolled, padded map
+  int y = ys + shift, x = xs + shift;                        // source pixel (roll by -shift)
+  if (y >= Hp) y -= Hp;
+  if (x >= Wp) x -= Wp;
+  const bool real = act && y < H && x < W;
+  const float* row = real ? qkv + (((long long)b * H + y) * W + x) * 3 * C : pad_qkv;
+  int reg = 0;
+  if (shift > 0) {
+    const int rh = ys < Hp - WS ? 0 : (ys < Hp - shift ? 1 : 2);
+    const int rw = xs < Wp - WS ? 0 : (xs < Wp - shift ? 1 : 2);
+    reg = rh * 3 + rw;
+  }
+  float q[kD];
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < kD; c += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(row + h * kD + c);
+      q[c] = t.x * scale, q[c + 1] = t.y * scale, q[c + 2] = t.z * scale, q[c + 3] = t.w * scale;
+      *reinterpret_cast<float4*>(ks + lane * kPad + c) = *reinterpret_cast<const float4*>(row + C + h * kD + c);
+      *reinterpret_cast<float4*>(vs + lane * kPad + c) = *reinterpret_cast<const float4*>(row + 2 * C + h * kD + c);
+    }
+    regs[lane] = reg;
+  }
+  __syncthreads();
+  if (!act) return;
+  // pass 1: scores (bias_t [heads][key j][query i]: consecutive lanes read consecutive addresses)
+  const float* bt = bias_t + (long long)h * N * N + lane;
+  float s[N];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < kD; c += 4) {
+      const float4 k4 = *reinterpret_cast<const float4*>(ks + j * kPad + c);
+      d = fmaf(q[c], k4.x, d), d = fmaf(q[c + 1], k4.y, d), d = fmaf(q[c + 2], k4.z, d), d = fmaf(q[c + 3], k4.w, d);
+    }
+    d += bt[j * N];
+    if (shift > 0 && regs[j] != reg) d += -100.f;
+    s[j] = d;
+    m = fmaxf(m, d);
+  }
+  // pass 2: softmax weights and the weighted sum of the values
+  float acc[kD];
+#pragma unroll
+  for (int c = 0; c < kD; ++c) acc[c] = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float p = expf(s[j] - m);
+    l += p;
+#pragma unroll
+    for (int c = 0; c < kD; c += 4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vs + j * kPad + c);
+      acc[c] = fmaf(p, v4.x, acc[c]), acc[c + 1] = fmaf(p, v4.y, acc[c + 1]);
+      acc[c + 2] = fmaf(p, v4.z, acc[c + 2]), acc[c + 3] = fmaf(p, v4.w, acc[c + 3]);
+    }
+  }
+  if (!real) return;                 // a pad token: attended to by its window, never written back (the crop)
+  const float inv = 1.f / l;
+  float* o = out + (((long long)b * H + y) * W + x) * C + h * kD;
+#pragma unroll
+  for (int c = 0; c < kD; c += 4)
+    *reinterpret_cast<float4*>(o + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+}
+}  // namespace
+
+extern "C" int pave_swin_window_attn_f32(const float* qkv, const float* bias_t, const float* pad_qkv, float* out,
+                                         int B, int H, int W, int C, int heads, int window, int shift,
+                                         float scale, void* stream) {
+  if (!qkv || !bias_t || !pad_qkv || !out) return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || C != heads * kD)
+    return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: C == heads * 32 (head dim 32) required");
+  if (window != 7) return pave_internal_fail(PAVE_E_UNSUPPORTED, "swin_window_attn: window size 7 is built");
+  if (shift < 0 || shift >= window) return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: 0 <= shift < window");
+  const long long nb = (long long)B * ((H + window - 1) / window) * ((W + window - 1) / window) * heads;
+  if (nb >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: grid too large");
+  hipLaunchKernelGGL((swin_window_attn_kernel<7>), dim3((unsigned)nb), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), qkv, bias_t, pad_qkv, out, B, H, W, C, heads, shift,
+                     scale);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}

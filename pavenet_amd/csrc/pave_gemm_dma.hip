@@ -152,6 +152,8 @@ __device__ __forceinline__ float half32_sum(float v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
 // max(x, 0) as the single v_max_f32 fmaxf ends in (the compiler puts a canonicalising v_max in front of it)
 __device__ __forceinline__ float relu_max(float x) {
   float y;
@@ -774,12 +776,18 @@ __device__ __forceinline__ void gemm_q_body(
               v[ps].x += rv.x, v[ps].y += rv.y, v[ps].z += rv.z, v[ps].w += rv.w;
             }
           }
-          if (relu) {
+          if (relu == 1) {
             asm volatile("" ::);
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps)
               v[ps].x = relu_max(v[ps].x), v[ps].y = relu_max(v[ps].y), v[ps].z = relu_max(v[ps].z),
               v[ps].w = relu_max(v[ps].w);
+          } else if (relu == 2) {     // exact GELU (nn.GELU: x Phi(x)): the Swin block's FFN activation
+            asm volatile("" ::);
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps)
+              v[ps].x = gelu_erf(v[ps].x), v[ps].y = gelu_erf(v[ps].y), v[ps].z = gelu_erf(v[ps].z),
+              v[ps].w = gelu_erf(v[ps].w);
           }
 #pragma unroll
           for (int ps = 0; ps < NPS; ++ps) {
@@ -1394,7 +1402,8 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
           const int rr = res_rows > 0 ? (int)((unsigned)row % (unsigned)res_rows) : row;
           v += residual[(long long)rr * n_real + col];
         }
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu == 1) v = fmaxf(v, 0.f);
+        else if (relu == 2) v = gelu_erf(v);
         out[(long long)row * n_real + col] = v;
       }
     }
@@ -1487,6 +1496,7 @@ static int gemm_q_dispatch(const float* a, const float* a_bias, const void* w_pl
                            int ksplit, int ks_slabs) {
   const QConv g{H, W, Cin, Ho, Wo, stride,
                 (kind == 1 && Cin > 16) ? (unsigned)(((1ull << 32) + (Cin >> 4) - 1) / (unsigned)(Cin >> 4)) : 0u};
+  if (relu < 0 || relu > 2) return pave_internal_fail(PAVE_E_ARG, "gemm_q: activation 0 (none), 1 (ReLU) or 2 (GELU)");
   const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
   if (narrow) N = -N;
   if (n_real <= 0) n_real = N;

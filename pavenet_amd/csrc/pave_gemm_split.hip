@@ -666,6 +666,8 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
                             const float* bias, const float* residual, float* out, long long M,
                             int K, int N, int relu, int nplanes, void* stream, OutSplit os) {
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
+  if (relu < 0 || relu > 2 || (relu == 2 && (!q_planes(nplanes) || g_diag_variant == 9)))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: relu = 0 | 1 | 2 (2 = exact GELU: 3 planes / fp16 only)");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
   // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip) takes K %% 32 == 0 and any
@@ -780,8 +782,8 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                            int stride, int relu, int nplanes, void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: null pointer");
-  if (N <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2))
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: bad sizes (stride 1 or 2)");
+  if (N <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || (relu != 0 && relu != 1))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_split: bad sizes (stride 1 or 2; relu 0 | 1)");
   const bool padded = Cin % 64 != 0 || Cout % 64 != 0;   // zero-padded weight planes: 3-plane DMA kernel only
   if (Cin <= 0 || Cout <= 0 || Cin % 16 != 0 || Cout % 4 != 0 ||
       ((padded || residual) && (!q_planes(nplanes) || g_diag_variant == 9)))
@@ -832,8 +834,8 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
                             const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                             int stride, int relu, void* workspace, long long workspace_bytes,
                             int nplanes, void* stream) {
-  if (!x || !w_planes || !y || !workspace)
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: null pointer");
+  if (!x || !w_planes || !y || !workspace || (relu != 0 && relu != 1))
+    return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: null pointer (or relu not 0 | 1)");
   const long long need = pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride);
   if (need == 0 || workspace_bytes < need)
     return pave_internal_fail(PAVE_E_ARG, "conv3x3_splitk: shape has no split-K plan (use pave_conv3x3_split_f32) "
@@ -881,7 +883,8 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
                                   int N, int H, int W, int Cout, int relu, int nplanes, void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: null pointer");
-  if (N <= 0 || H <= 0 || W < 8) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: bad sizes (W >= 8)");
+  if (N <= 0 || H <= 0 || W < 8 || (relu != 0 && relu != 1))
+    return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: bad sizes (W >= 8; relu 0 | 1)");
   if (Cout != 64)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: Cout == 64 (the ResNet / HRNet stem)");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;

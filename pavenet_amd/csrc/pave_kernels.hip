@@ -1761,8 +1761,8 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
   if (rows >= (1ll << 31)) return fail(PAVE_E_ARG, "bias_add_layernorm: rows must be < 2^31");
   if ((y_plus != nullptr) != (pos != nullptr) || (pos && pos_rows <= 0))
     return fail(PAVE_E_ARG, "bias_add_layernorm: pos, pos_rows > 0 and y_plus go together");
-  if (rows <= 0 || C <= 0 || (C & 3) || C > 1024)
-    return fail(PAVE_E_ARG, "bias_add_layernorm: C must be a multiple of 4, <= 1024");
+  if (rows <= 0 || C <= 0 || (C & 3) || C > 3072)
+    return fail(PAVE_E_ARG, "bias_add_layernorm: C must be a multiple of 4, <= 3072");
   long long nb = (rows + 3) / 4;
   if (nb > 256 * 16) nb = 256 * 16;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1774,7 +1774,9 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
     case 1: PAVE_LN(1); break;
     case 2: PAVE_LN(2); break;
     case 3: PAVE_LN(3); break;
-    default: PAVE_LN(4); break;
+    case 4: PAVE_LN(4); break;
+    case 5: case 6: PAVE_LN(6); break;      // (Swin-L: 1536-wide rows; its patch-merging norm: 3072)
+    default: PAVE_LN(12); break;
   }
 #undef PAVE_LN
   const hipError_t e = hipGetLastError();

@@ -97,7 +97,7 @@ def masked_row_index(mask):
     return idx
 
 
-def project_values_hoisted(attns, value_bf, key_padding_mask=None):
+def project_values_hoisted(attns, value_bf, key_padding_mask=None, masked_rows=None):
     """value_proj of several decoder layers over the same (constant) memory, as the modules'
     own `project_value` would give them: [B*T, S, 8, 32] per layer.  In the split GEMM modes two
     layers share one launch (N = 512, two dense outputs), so the memory is read once per pair.
@@ -114,7 +114,8 @@ def project_values_hoisted(attns, value_bf, key_padding_mask=None):
                                               MulFramesMultiScaleDeformableAttention.project_value)
                     and a.value_proj.bias is not None for a in attns) \
             and split_gemm_ok(x.reshape(-1, x.shape[-1]), attns[0].value_proj.weight):
-        fill = masked_row_index(key_padding_mask)
+        # (masked_rows: the caller's cached index of the mask's True entries, heads.MaskList.masked_rows)
+        fill = masked_rows if masked_rows is not None else masked_row_index(key_padding_mask)
         key_padding_mask = None
     if key_padding_mask is not None or not (x.is_cuda and x.is_contiguous()) or len(attns) < 2:
         return [a.project_value(value_bf, key_padding_mask) for a in attns]
@@ -275,7 +276,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                                        levels_hw=tile_levels, window_shift=self._tile_shift())
         return out.view(bs, S, self.embed_dims)
 
-    def _forward_merged_groups(self, q, pos_bf, mask, reference_points, tile_levels, groups):
+    def _forward_merged_groups(self, q, pos_bf, mask, reference_points, tile_levels, groups, masked_rows=None):
         """`_forward_merged` for a PADDED batch: the positional encoding and the padding pattern are
         the same for the frames of a run (`groups`: (first frame, count); the T frames of a clip share one
         valid size, HEAD:429-445), so each run is ONE launch of the merged projection GEMM with the run's own
@@ -312,7 +313,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             r0, r1 = f0 * S, (f0 + n) * S
             ops.gemm_bf16x3_encproj(rows[r0:r1], wp, hit[1], ref[r0:r1], tile_levels, value_bias=vb,
                                     out=(value[r0:r1], samp[r0:r1]))
-        ops.fill_rows_(value, masked_row_index(mask), None)
+        ops.fill_rows_(value, masked_rows if masked_rows is not None else masked_row_index(mask), None)
         out = ops.deform_attn_enc_tile(value.view(bs, S, self.num_heads, -1), samp, None,
                                        levels_hw=tile_levels, window_shift=self._tile_shift(), prepared=True)
         return out.view(bs, S, self.embed_dims)
@@ -341,7 +342,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                     and all(split_gemm_ok(q[f0:f0 + n].reshape(-1, q.shape[-1]), self.sampling_offsets.weight)
                             for f0, n in groups)):
                 out = self._forward_merged_groups(q, pos_bf, key_padding_mask, reference_points,
-                                                  tile_levels, groups)
+                                                  tile_levels, groups, kwargs.get('masked_rows'))
                 idt = batch_first(identity)
                 out = linear_residual_norm(out, self.output_proj, idt, post_norm,
                                            inplace=kwargs.get('inplace_residual', False) is True)

@@ -118,6 +118,17 @@ class MaskList(list):
     (first frame, count) of consecutive frames sharing one valid size (padded batches only) -- lets the encoder
     take its merged-projection path per run without reading the masks back from the device."""
     frame_groups = None
+    _rows = None
+
+    def masked_rows(self):
+        """int32 indices of the masked tokens in the flattened [n_frames * S] token order (levels concatenated
+        per frame, as the transformer flattens them): built once per cached mask set -- one device read-back
+        when a padded batch shape is first seen, none afterwards (and none inside a hipGraph capture)."""
+        if self._rows is None:
+            with torch.no_grad():
+                flat = torch.cat([m.flatten(1) for m in self], 1)
+                self._rows = flat.reshape(-1).nonzero().flatten().to(torch.int32)
+        return self._rows
 
 
 @HEADS.register_module()

@@ -59,6 +59,7 @@ SIGNATURES = {
     'pave_gather_frame_poses_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [_vp],
     'pave_pose_finalize_f32': [_vp] * 7 + [_c_int] * 4 + [_vp],
     'pave_ref_update_frames_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [ctypes.c_float, _vp],
+    'pave_swin_window_attn_f32': [_vp] * 4 + [_c_int] * 7 + [ctypes.c_float, _vp],
     'pave_merge_softmax_partials_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }

@@ -661,6 +661,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
                 fp16=False, n_out=None):
     """out[M, N] = act(A' @ W^T + bias + residual), A' = relu(a + a_bias) if a_bias is given, on
     the bf16 matrix cores with both operands split into P = w_planes.shape[1] bf16 terms
+    (relu: False | True | 'gelu' = exact GELU, 3 planes / fp16 only)
     (P = 3: exact split, 6 MFMA products, fp32-level accuracy;  2: 3 products, ~2^-16;
     1: plain bf16 operands, or fp16 operands with fp16=True and a PLANES_FP16 weight), fp32
     accumulate, fp32 in / out.
@@ -696,8 +697,8 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
-                                      ptr(residual), out.data_ptr(), M, K, N, int(bool(relu)), npl,
-                                      _stream_ptr())
+                                      ptr(residual), out.data_ptr(), M, K, N,
+                                      2 if relu == 'gelu' else int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3')
     return out
 
@@ -984,6 +985,28 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
                                          M, K, N, int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3_ex')
     return out, out2
+
+
+def swin_window_attn(qkv, bias_t, pad_qkv, heads, window, shift, scale):
+    """The (shifted-)window attention core of a Swin block on the un-partitioned token map
+    (pave_swin_window_attn_f32): qkv [B, H, W, 3C], bias_t [heads, ws^2, ws^2] (relative-position bias, key-major),
+    pad_qkv [3C] (the qkv Linear's bias) -> [B, H, W, C]."""
+    lib = native.load()
+    for t, nm in ((qkv, 'qkv'), (bias_t, 'bias_t'), (pad_qkv, 'pad_qkv')):
+        _dev(t, nm, torch.float32)
+    _require(qkv.dim() == 4 and qkv.shape[3] % 3 == 0, 'swin_window_attn: qkv [B, H, W, 3C]')
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    n = window * window
+    _require(tuple(bias_t.shape) == (heads, n, n) and pad_qkv.numel() == C3 and C == heads * 32,
+             'swin_window_attn: bias_t [heads, ws^2, ws^2], pad_qkv [3C], head dim 32')
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        st = lib.pave_swin_window_attn_f32(qkv.data_ptr(), bias_t.data_ptr(), pad_qkv.data_ptr(), out.data_ptr(),
+                                           B, H, W, C, int(heads), int(window), int(shift), float(scale),
+                                           _stream_ptr())
+    native.check(st, 'swin_window_attn')
+    return out
 
 
 def merge_softmax_partials(parts, C, H):

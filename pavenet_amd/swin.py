@@ -3,7 +3,13 @@ third_party/mmdetection/mmdet/models/backbones/swin.py (WindowMSA :22-126, Shift
 :128-286, SwinBlock :288-379, SwinBlockSequence :381-465, SwinTransformer :467-768) and
 mmdet/models/utils/transformer.py (AdaptivePadding :56-133, PatchEmbed :136-259, PatchMerging
 :262-387).  Same ctor kwargs and state-dict keys; inference only (DropPath = identity).
-Window attention is a batch of dense (49 x 49) products: rocBLAS batched GEMMs via PyTorch.
+On the device (fp32, no grad, the exact-split or fp16 GEMM mode) the forward runs on this package's kernels
+(`SwinTransformer._forward_device`): every Linear -- patch embedding as a row GEMM over 4 x 4 patches, qkv, proj,
+the FFN (exact GELU in the GEMM epilogue), the patch-merging reduction -- is a launch of the split GEMM with
+bias / identity in its epilogue, LayerNorm is `pave_bias_add_layernorm_f32`, and the (shifted-)window attention
+is ONE kernel on the un-partitioned token map (`pave_swin_window_attn_f32`: pad / roll / partition / mask /
+reverse are index arithmetic) -- no library GEMM, no batched 49 x 49 products.  Elsewhere (CPU, autograd): the
+plain torch formulation below, bit-identical to the reference backbone.
 """
 import math
 
@@ -315,9 +321,109 @@ class SwinTransformer(BaseModule):
                 m.init_weights()
         self._is_init = True
 
+    # ---- the device path: this package's kernels -------------------------------------------------
+    def _device_ok(self, x):
+        from .bricks import fused_mode
+        return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and fused_mode()
+                and not self.use_abs_pos_embed and self.patch_embed.adap_padding is not None
+                and self.patch_embed.projection.kernel_size == self.patch_embed.projection.stride
+                and all(blk.attn.window_size == 7 and blk.attn.w_msa.embed_dims == 32 * blk.attn.w_msa.num_heads
+                        and isinstance(blk.ffn.activate, nn.GELU) and blk.ffn.num_fcs == 2
+                        for st in self.stages for blk in st.blocks))
+
+    @staticmethod
+    def _ln(rows, norm):
+        from . import ops
+        return ops.bias_add_layernorm(rows, None, None, norm.weight, norm.bias, norm.eps)
+
+    @staticmethod
+    def _lin(rows, weight, bias=None, act=False, residual=None):
+        """Linear on rows through the split GEMM (planes zero-padded to N % 64 == 0), bias / GELU / identity in
+        its epilogue."""
+        from . import ops
+        from .bricks import _split_cached
+        wp = _split_cached(weight, 'gemm_pad', lambda planes: ops.split_weight_bf16x3(
+            weight.detach().contiguous(), planes, pad=True))
+        return ops.gemm_bf16x3(rows, wp, bias, residual, relu=act, n_out=weight.shape[0],
+                               out=residual if residual is not None else None)
+
+    def _block_device(self, blk, x, B, H, W):
+        """SwinBlock.forward (swin.py:347-365) on token rows x [B*H*W, C]; x is overwritten (it is a temporary)."""
+        from . import ops
+        from .bricks import SourceKey
+        msa = blk.attn.w_msa
+        y = self._ln(x, blk.norm1)
+        qkv = self._lin(y, msa.qkv.weight, msa.qkv.bias)
+        hit = msa.__dict__.get('_pave_bias_t')
+        key = SourceKey((msa.relative_position_bias_table,))
+        if hit is None or hit[0] != key:
+            n = msa.window_size[0] * msa.window_size[1]
+            with torch.no_grad():      # [heads, key j, query i]: bias[i, j] of the reference, transposed per head
+                bt = msa.relative_position_bias_table[msa.relative_position_index.view(-1)].view(n, n, -1)
+                bt = bt.permute(2, 1, 0).contiguous()
+            hit = msa.__dict__['_pave_bias_t'] = (key, bt)
+        pad = msa.qkv.bias if msa.qkv.bias is not None else torch.zeros(qkv.shape[1], device=x.device)
+        a = ops.swin_window_attn(qkv.view(B, H, W, -1), hit[1], pad.detach(), msa.num_heads, blk.attn.window_size,
+                                 blk.attn.shift_size, msa.scale)
+        x = self._lin(a.view(-1, a.shape[-1]), msa.proj.weight, msa.proj.bias, residual=x)       # + identity
+        y = self._ln(x, blk.norm2)
+        fc1, fc2 = blk.ffn.layers[0][0], blk.ffn.layers[1]
+        h = self._lin(y, fc1.weight, fc1.bias, act='gelu')
+        return self._lin(h, fc2.weight, fc2.bias, residual=x)                                    # + identity
+
+    def _merge_device(self, pm, x, B, H, W):
+        """PatchMerging.forward (mmdet/models/utils/transformer.py:336-387): 2 x 2 neighbourhoods in nn.Unfold's
+        channel order (c, ky, kx), LayerNorm, the bias-free reduction Linear."""
+        C = x.shape[1]
+        m = x.view(B, H, W, C)
+        if H % 2 or W % 2:                                   # 'corner' padding to even sizes
+            m = F.pad(m, (0, 0, 0, W % 2, 0, H % 2))
+        Ho, Wo = m.shape[1] // 2, m.shape[2] // 2
+        rows = m.view(B, Ho, 2, Wo, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B * Ho * Wo, 4 * C)
+        if pm.norm is not None:
+            rows = self._ln(rows, pm.norm)
+        return self._lin(rows, pm.reduction.weight, pm.reduction.bias), Ho, Wo
+
+    def _forward_device(self, x):
+        pe = self.patch_embed
+        x = pe.adap_padding(x)
+        B, Cin, Hi, Wi = x.shape
+        p = pe.projection.kernel_size[0]
+        H, W = Hi // p, Wi // p
+        K = Cin * p * p
+        Kp = max(64, (K + 31) // 32 * 32)
+        # the patch embedding as a row GEMM: one row per p x p patch in the convolution's (c, ky, kx) order,
+        # zero-padded to the kernels' K % 32 == 0
+        rows = x.new_zeros((B * H * W, Kp))
+        rows[:, :K].view(B, H, W, Cin, p, p).copy_(x.view(B, Cin, H, p, W, p).permute(0, 2, 4, 1, 3, 5))
+        w = pe.projection.weight
+        hit = pe.__dict__.get('_pave_w')
+        from .bricks import SourceKey
+        key = SourceKey((w,))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wk = w.new_zeros((w.shape[0], Kp))
+                wk[:, :K] = w.flatten(1)
+            hit = pe.__dict__['_pave_w'] = (key, wk)
+        t = self._lin(rows, hit[1], pe.projection.bias)
+        if pe.norm is not None:
+            t = self._ln(t, pe.norm)
+        outs = []
+        for i, stage in enumerate(self.stages):
+            for blk in stage.blocks:
+                t = self._block_device(blk, t, B, H, W)
+            if i in self.out_indices:
+                o = self._ln(t, getattr(self, f'norm{i}'))
+                outs.append(o.view(B, H, W, -1).permute(0, 3, 1, 2))     # channels_last [B, C, H, W]
+            if stage.downsample:
+                t, H, W = self._merge_device(stage.downsample, t, B, H, W)
+        return tuple(outs)
+
     def forward(self, x):
         if x.dim() == 5:  # swin.py:747-749 (`num_frames` flatten)
             x = x.flatten(0, 1)
+        if self._device_ok(x):
+            return self._forward_device(x)
         x, hw_shape = self.patch_embed(x)
         if self.use_abs_pos_embed:
             x = x + self.absolute_pos_embed

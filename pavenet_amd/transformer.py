@@ -584,6 +584,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             if attn_mask is not None and groups is not None and sum(n for _, n in groups) == bs:
                 # padded batch: runs of frames with one positional table / padding pattern each
                 extra['frame_groups'] = groups
+                extra['masked_rows'] = mlvl_masks.masked_rows()
         elif self.xcd_unit_order and feat_flatten.is_cuda:
             extra['unit_order'] = geom.unit_order(bs, dev)
         # every encoder layer input is a temporary owned by this function, so the residual
@@ -695,7 +696,9 @@ class VideoPoseTransformerMulFrames(Transformer):
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformablePoseAttention)
                 for l in self.decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(
-                [l.attentions[-1] for l in self.decoder.layers], memory, attn_mask)
+                [l.attentions[-1] for l in self.decoder.layers], memory, attn_mask,
+                masked_rows=mlvl_masks.masked_rows() if (attn_mask is not None
+                                                         and hasattr(mlvl_masks, 'masked_rows')) else None)
         inter_states, inter_references = self.decoder(
             query=seq_first_view(query.contiguous()), key=None, value=seq_first_view(memory),
             query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,
@@ -761,7 +764,9 @@ class VideoPoseTransformerMulFrames(Transformer):
                 isinstance(l.attentions[-1], MulFramesMultiScaleDeformableAttention)
                 for l in self.refine_decoder.layers):
             dec_kwargs['values_projected'] = project_values_hoisted(
-                [l.attentions[-1] for l in self.refine_decoder.layers], mem_bt, attn_mask)
+                [l.attentions[-1] for l in self.refine_decoder.layers], mem_bt, attn_mask,
+                masked_rows=mlvl_masks.masked_rows() if (attn_mask is not None
+                                                         and hasattr(mlvl_masks, 'masked_rows')) else None)
         inter_states, inter_references = self.refine_decoder(
             query=seq_first_view(query.contiguous()), key=None, value=memory,
             query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,

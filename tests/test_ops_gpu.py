@@ -215,7 +215,7 @@ def test_grid_fused_T1_unaligned_rows_take_the_per_query_kernel():
     out = torch.empty(U, 256, device='cuda')
     st = lib.pave_deform_attn_grid_fused_f32(
         vd.data_ptr(), sd.data_ptr(), ld.data_ptr(), pd.data_ptr(), rd.data_ptr(), None, None,
-        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride, None,
+        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride, None, 0,
         torch.cuda.current_stream().cuda_stream)
     native.check(st, 'grid_fused (unaligned rows)')
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
@@ -283,6 +283,52 @@ def test_frame_table_entries_outside_the_value_cache_cannot_fault():
     b = deform_attn_pose_fused(value, sd, ld, pproj, pref, frame_table=ok, **pk)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,H,W,heads,shift', [(2, 14, 21, 3, 0), (2, 14, 21, 3, 3), (1, 20, 33, 6, 3),
+                                               (3, 7, 7, 12, 0), (1, 5, 9, 3, 3), (1, 29, 48, 6, 3)])
+def test_swin_window_attention_kernel_vs_reference_formulation(B, H, W, heads, shift):
+    """pave_swin_window_attn_f32 (pad to the window, roll, partition, relative-position bias, the -100 mask
+    between roll regions, softmax, PV, reverse, un-roll and crop as index arithmetic of ONE kernel on the
+    un-partitioned token map) against ShiftWindowMSA / WindowMSA in their torch formulation (the restatement of
+    mmdet/models/backbones/swin.py:22-286 that is bit-identical to the reference on CPU) in fp64: maps that are
+    and are not multiples of the window, maps smaller than a window, shifted and un-shifted blocks."""
+    from pavenet_amd import ops
+    from pavenet_amd.swin import ShiftWindowMSA
+    torch.manual_seed(B * 100 + H + heads + shift)
+    C = 32 * heads
+    m = ShiftWindowMSA(C, heads, 7, shift_size=shift).double()
+    with torch.no_grad():
+        m.w_msa.relative_position_bias_table.normal_(0, 0.5)
+        m.w_msa.qkv.bias.normal_(0, 0.3)
+        m.w_msa.proj.weight.copy_(torch.eye(C, dtype=torch.float64))      # the kernel stops in front of `proj`
+        m.w_msa.proj.bias.zero_()
+    x = torch.randn(B, H * W, C, dtype=torch.float64)
+    with torch.no_grad():
+        exp = m(x, (H, W))
+        qkv = m.w_msa.qkv(x).float().view(B, H, W, 3 * C)
+        n = 49
+        bt = m.w_msa.relative_position_bias_table[m.w_msa.relative_position_index.view(-1)].view(n, n, heads)
+        bt = bt.permute(2, 1, 0).contiguous().float()
+    got = ops.swin_window_attn(qkv.cuda(), bt.cuda(), m.w_msa.qkv.bias.float().cuda(), heads, 7, shift, m.w_msa.scale)
+    np.testing.assert_allclose(got.view(B, H * W, C).cpu().numpy(), exp.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_gemm_gelu_epilogue_and_wide_layernorm_rows():
+    """What the Swin blocks need beside the window kernel: the exact-GELU epilogue of the split GEMM (tile and
+    small-row forms, against fp64 x Phi(x)) and pave_bias_add_layernorm_f32 on 1 536- and 3 072-wide rows."""
+    from pavenet_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for M in (300, 9000):
+        a, w, b = torch.randn(M, 192, generator=g), torch.randn(768, 192, generator=g) * 0.1, torch.randn(768, generator=g)
+        got = ops.gemm_bf16x3(a.cuda(), ops.split_weight_bf16x3(w.cuda()), b.cuda(), relu='gelu')
+        exp = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double())
+        np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-6)
+    for C in (1536, 3072, 1028):
+        x, ga, be = torch.randn(77, C, generator=g) * 3 + 1, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        got = ops.bias_add_layernorm(x.cuda(), None, None, ga.cuda(), be.cuda(), 1e-5)
+        exp = torch.nn.functional.layer_norm(x.double(), (C,), ga.double(), be.double(), 1e-5)
+        np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
 
 
 def test_merge_softmax_partials_kernel_vs_host_formulation():
