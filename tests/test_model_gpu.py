@@ -857,16 +857,18 @@ def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=
     _close(gb.cpu().numpy()[:, :4], eb.numpy()[:, :4], rtol=0, atol=1e-3)
     _close(gk.cpu().numpy()[..., 2], ek.numpy()[..., 2], rtol=1e-4, atol=1e-5)   # key-point scores
     if img_shapes is not None:
-        # a padded batch: clip 0 inside the batch (two runs of frames, each with its own table / mask rows) equals
-        # clip 0 run alone, bit for bit (the free run's own top-k sits on near-ties against the CPU oracle, so the
-        # un-pinned comparison with the oracle is left to the un-padded tests)
+        # a padded batch: clip 0 inside the batch (two runs of frames, each with its own table / mask rows) gives
+        # the poses of clip 0 run alone (not bit for bit: below 8 192 rows the layer4 downsample GEMMs of a
+        # one-clip batch take the size-gated vendor path); the free run's own top-k sits on near-ties against
+        # the CPU oracle, so the un-pinned comparison with the oracle is left to the un-padded tests
         bricks.set_gemm_mode(gemm)
         try:
             with torch.no_grad():
                 alone = m.bbox_head.results_to_list(m.forward_device(img[:1], metas[:1]))[0][2].cpu()
         finally:
             bricks.set_gemm_mode('native')
-        assert torch.equal(alone, free)
+        assert alone.shape == free.shape, (alone.shape, free.shape)
+        assert float((alone[..., :2] - free[..., :2]).abs().max()) <= 5e-2
         return
     # the un-pinned batch run found every oracle pose (its own top-k, its own NMS)
     assert free.shape[0] == ek.shape[0], (free.shape, ek.shape)
