@@ -79,9 +79,10 @@ def parse():
                          'launch-bound dispatches) as ONE hipGraph; backbone / neck / encoder stay eager and '
                          'keep their per-launch events (pavenet_amd.graph.TailGraphedForward; single stream, '
                          'clip-parallel only; falls back to eager if the capture fails its self-check).  Off by '
-                         'default: on the 28-frame headline batch the host has queued the tail long before the GPU '
-                         'reaches it (70.97 ms replayed against 70.82 eager); it pays on latency-shaped workloads '
-                         '-- `extra` reports configs[1] both ways')
+                         'default -- measured, no gain: on the 28-frame headline batch the host has queued the tail '
+                         'long before the GPU reaches it (70.97 ms replayed against 70.82 eager), and on configs[1] the '
+                         'replay of the ~170-node graph is SLOWER than the eager launches (12.14 against 11.29 ms; '
+                         'with it, `extra` times configs[1] both ways)')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='steps in flight: P > 1 runs consecutive steps (independent batches) on P HIP '
                          'streams, so the launch-bound decoder / post-processing tail of step i overlaps '
@@ -318,7 +319,7 @@ def secondary_workloads(args, dev, budget_s=100.0):
         host = None
         tail, tail_note = None, 'off'
         use_tail = [False]
-        if B * T <= 3:      # a latency-shaped workload: also timed with the tail replayed as one hipGraph
+        if args.tail_graph and B * T <= 3:      # a latency-shaped workload, also timed with the tail replayed
             from pavenet_amd import GRAPH_REPLAY_SAFE
             from pavenet_amd.graph import TailGraphedForward
             try:
