@@ -191,7 +191,16 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 // projections", BASELINE configs[4]): ONE plane of fp16 weights in the same slab-major layout, the raw fp32
 // activation rows converted (round to nearest even) where the 3-plane form splits them, one
 // v_mfma_f32_32x32x16_f16 per tile and slab -- every row source, tile form and epilogue of this file as it is.
-template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1, int PL = 3>
+// HT ("half tail", TN = 2, 33 .. 48 real output columns in 64-row weight planes: HRNet-w48's 48-channel branch):
+// the second column tile is only 16 columns wide, so it is not run as zero-padded 32x32x16 products (a quarter of
+// the launch's MFMA cycles multiplying zeros) but as v_mfma_f32_16x16x32_bf16 over PAIRS of K slabs: its A
+// operands (16 rows x 32 k) are built from the two slabs' 32x32x16 operands with v_permlane32_swap +
+// v_permlane16_swap in place (once the main tile's MFMAs of the second slab are issued nobody else needs them;
+// tools/microbench/permlane_swap.hip), its B operand is one 16-byte piece per lane, lanes 0-31 from the first
+// slab's stage, 32-63 from the second's.  6 + 3 MFMA-equivalents per slab instead of 12.  The tail columns
+// accumulate 32 k per instruction: equal to the padded form up to fp32 summation order, not bit for bit.
+template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1, int PL = 3,
+          bool HT = false>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -216,7 +225,9 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int NS = WIDE ? 2 : QNS;                // ring stages
   constexpr int EPI_OFF = 0;                        // per-wave epilogue chunks reuse the ring
   constexpr int STAT_OFF = NS * STAGE;              // LayerNorm row statistics (WN > 1)
-  constexpr int TQ = WIDE ? 2 : TN;                 // column tiles per W fragment set
+  constexpr int TQ = WIDE ? 2 : (HT ? 1 : TN);      // column tiles per W fragment set (HT: the full tile only)
+  static_assert(!HT || (TN == 2 && WN == 1 && RM == 1 && !WIDE && !LNORM && EPI == 0 && PL == 3),
+                "half-tail form: 64-column planes, one row tile per wave, 3 planes");
   static_assert(!WIDE || (TN == 8 && WN == 1 && !ABIAS), "wide form: 32 x 256 per wave");
   constexpr int ABOFF = STAT_OFF + (LNORM ? 2 * QBM * WN * 4 : 0);   // a_bias vector
   static_assert(NA % NWAVE == 0, "A DMA instructions divide evenly over the waves");
@@ -391,9 +402,55 @@ __device__ __forceinline__ void gemm_q_body(
         wf[set][p][j] =
             *reinterpret_cast<const u32x4*>(st + w_rd + (p * BN + (quarter * TQ + j) * 32) * 32);
   };
+  // HT: the 16-column tail's B pieces -- row 32 + (lane & 15) of every plane, k half (lane >> 4) & 1 -- of
+  // the slab in `stage` (every lane reads; which half of the wave keeps them is the caller's business)
+  u32x4 wtA[PL], wtB[PL], wt[PL];   // first slab of the pair | second | merged operand
+  f32x4 acct[2];                    // tail accumulators: rows 0-15, 16-31 (16x16 layout)
+  const int w_rdt = A_STAGE + (32 + (lane & 15)) * 32 + (((((lane >> 4) & 1)) ^ ((lane >> 3) & 1)) * 16);
+  auto read_tail = [&](const int stage, u32x4 (&dst)[PL]) {
+    const unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int p = 0; p < PL; ++p) dst[p] = *reinterpret_cast<const u32x4*>(st + w_rdt + p * BN * 32);
+  };
   auto read_frags = [&](const int stage, const int set) {
     read_raw(stage);
     read_wq(stage, 0, set);
+    if constexpr (HT) {
+      if (set == 0) read_tail(stage, wtA);   // an even slab: the first of its pair
+      else read_tail(stage, wtB);            // the second: lanes 32-63 carry its k blocks
+    }
+  };
+  // (after the first MFMA group of the step: the reads have landed under it)
+  auto merge_tail = [&]() {
+    if constexpr (HT) {
+#pragma unroll
+      for (int p = 0; p < PL; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wt[p][i] = lane < 32 ? wtA[p][i] : wtB[p][i];
+    }
+  };
+  // HT, after the main tile's MFMAs of the pair's second slab: the tail tile's 12 MFMAs of the pair
+  auto tail_pair = [&]() {
+    if constexpr (HT) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int p = 0; p < PL; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // [X0 X1 X2 X3], [Y0 Y1 Y2 Y3] (rows of 16 lanes: k half x row half) -> [X0 X2 Y0 Y2], [X1 X3 Y1 Y3]
+          u32x2 r = __builtin_amdgcn_permlane32_swap(apl[0][0][p][i], apl[1][0][p][i], false, false);
+          r = __builtin_amdgcn_permlane16_swap(r.x, r.y, false, false);
+          apl[0][0][p][i] = r.x, apl[1][0][p][i] = r.y;
+        }
+#pragma unroll
+      for (int o = 2; o >= 0; --o)
+#pragma unroll
+        for (int pa = 0; pa <= o; ++pa)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            acct[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, apl[hh][0][pa]), __builtin_bit_cast(bf16x8, wt[o - pa]), acct[hh], 0, 0, 0);
+    }
   };
   auto split_raw = [&](const int slab, const int set) {
 #pragma unroll
@@ -534,6 +591,7 @@ __device__ __forceinline__ void gemm_q_body(
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      acct[0] = f32x4{0.f, 0.f, 0.f, 0.f}, acct[1] = acct[0];
       PAVE_QWAIT(2 * QMIN);                  // slab 0 has landed everywhere
       read_frags(0, 0);
       split_raw(0, 0);
@@ -551,9 +609,14 @@ __device__ __forceinline__ void gemm_q_body(
     read_frags(((I) + 1) % 3, nxt);                                            \
     __builtin_amdgcn_sched_barrier(0);                                         \
     mma(cur, 2);                                                               \
-    split_raw(sl + 1, nxt);                                                    \
+    if (HT && cur == 0) merge_tail();                                          \
+    if (!(HT && cur == 1)) split_raw(sl + 1, nxt);                             \
     mma(cur, 1);                                                               \
     mma(cur, 0);                                                               \
+    if (HT && cur == 1) {   /* the pair is complete: its tail tile, then the split that overwrites set 0 */ \
+      tail_pair();                                                             \
+      split_raw(sl + 1, nxt);                                                  \
+    }                                                                          \
   }
       int s = 0;
       for (; s + 9 <= nslabs; s += 6) {
@@ -579,6 +642,7 @@ __device__ __forceinline__ void gemm_q_body(
       mma(1, 2);
       mma(1, 1);
       mma(1, 0);
+      tail_pair();
 #undef PAVE_QSTEP
     } else {
       // ---- two slabs in flight
@@ -743,9 +807,16 @@ __device__ __forceinline__ void gemm_q_body(
           g4 = *reinterpret_cast<const float4*>(ln.gamma + ncol);
           be4 = *reinterpret_cast<const float4*>(ln.beta + ncol);
         }
+        if (HT && t == 1) {   // 16x16 layout: col = lane & 15, row = 4 (lane >> 4) + r (+ 16 for the second half)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(hh * 16 + 4 * (lane >> 4) + r) * QCST + (lane & 15)] = acct[hh][r];
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * QCST + lr] = acc[t][r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -917,13 +988,13 @@ __device__ __forceinline__ void gemm_q_body(
 // (64-column tiles, TN = 2: 136 VGPRs and 42 KB of LDS -- three blocks per CU; these launches are
 // issue-bound, not MFMA-bound, and take the extra wave per SIMD)
 // (RM = 2: 256-row blocks, a wave owns two row tiles; ~200 VGPRs and 66 KB of LDS -- two blocks per CU)
-template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3>
+template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3, bool HT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 && RM == 1) ? 3 : 2, (TN == 2 && RM == 1) ? 3 : 2))) void gemm_q_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const float* __restrict__ a_bias, const QConv g, const QOut os, const float* __restrict__ A2) {
-  gemm_q_body<TN, 1, KIND, ABIAS, false, false, 0, RM, PL>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g, os,
-                                                           QLn{nullptr, nullptr, 0.f}, A2);
+  gemm_q_body<TN, 1, KIND, ABIAS, false, false, 0, RM, PL, HT>(A, Wp, bias, residual, out, M, K, N, relu, a_bias, g,
+                                                               os, QLn{nullptr, nullptr, 0.f}, A2);
 }
 // the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
 template <int KIND, int PL = 3>
@@ -1250,7 +1321,7 @@ __global__ __launch_bounds__(192) void stem7x7_qr_kernel(
   }
 }
 
-template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3>
+template <int TN, int KIND, bool ABIAS, int RM = 1, int PL = 3, bool HT = false>
 int launch_q(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
              long long M, int K, int N, int relu, const float* a_bias, hipStream_t st, const QConv g,
              const QOut os, const float* a2 = nullptr, int ksplit = 1) {
@@ -1262,7 +1333,7 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
   const int smem = (QNS * STAGE > EPIB ? QNS * STAGE : EPIB) + (ABIAS ? K * 4 : 0);
   const long long gx = ((M + BM - 1) / BM) * (N / BN);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_q: grid too large");
-  auto kern = gemm_q_kernel<TN, KIND, ABIAS, RM, PL>;
+  auto kern = gemm_q_kernel<TN, KIND, ABIAS, RM, PL, HT>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1596,6 +1667,15 @@ static int gemm_q_dispatch(const float* a, const float* a_bias, const void* w_pl
       (os.res_rows == 0 || os.res_rows >= 64) && (long long)N * 1024 < (1ll << 31)) {
     if (kind == 1) return launch_q<2, 1, false, 2, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
     return launch_q<2, 0, false, 2, PL>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
+  }
+  // 33 .. 48 real outputs in 64-row planes (HRNet-w48's 48-channel 3x3 branch, 154 launches of a T = 7 x 4 step):
+  // the 16-column tail on v_mfma_f32_16x16x32_bf16 over slab pairs instead of zero-padded 32x32x16 products
+  // (HT above).  The 3x3 form only: it takes the tile kernels at every size, so a clip's values do not depend on
+  // the batch it is in.  (diag variant 17: never -- the padded form, for A/B and the tolerance test)
+  if constexpr (PL == 3) {
+    if (N == 64 && n_real > 32 && n_real <= 48 && kind == 1 && !big3 && !a_bias && !out2 && ksplit == 1 &&
+        dv != 17 && dv != 15 && dv != 16)   // (15 / 16: the A/B of the padded one- / two-row-tile forms)
+      return launch_q<2, 1, false, 1, 3, true>(a, w, bias, residual, out, M, K, N, relu, a_bias, st, g, os);
   }
   if (N % 64 == 0) { PAVE_QGO(2); }
 #undef PAVE_QGO

@@ -1319,6 +1319,45 @@ def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
     assert bool((out == 3.0).all())
 
 
+@pytest.mark.parametrize('n,H,W,Cin,Cout,res,relu', [(2, 40, 56, 48, 48, True, True), (1, 33, 21, 48, 48, False, False),
+                                                      (3, 9, 11, 64, 36, True, False), (2, 19, 27, 16, 40, False, True),
+                                                      (1, 7, 5, 96, 44, True, True), (1, 1, 1, 48, 48, False, False)])
+def test_conv3x3_half_tail_form_vs_padded_form_and_fp64(n, H, W, Cin, Cout, res, relu):
+    """33 .. 48 output channels of a 3x3 convolution (HRNet-w48's 48-channel branch): the columns behind the first
+    32 run as v_mfma_f32_16x16x32_bf16 over PAIRS of K slabs (A operands re-laid with v_permlane32/16_swap, B pieces
+    of both slabs' stages in one register) instead of zero-padded 32x32x16 products.  Against the padded form (diag
+    variant 17): the first 32 channels bit for bit, the tail to fp32 summation order; against fp64; odd slab
+    counts (K = 9 Cin padded to a multiple of 32), ragged tiles, borders, identity + ReLU, a NaN pixel."""
+    from pavenet_amd import native, ops
+    g = torch.Generator().manual_seed(n * 1000 + H * 10 + Cout)
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(n, Cout, H, W, generator=g) if res else None
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)   # noqa: E731
+    wp = ops.split_conv3x3_weight(w.cuda())
+    run = lambda xx: ops.conv3x3_split(cl(xx), wp, b.cuda(), relu=relu, residual=cl(r) if res else None, cout=Cout)  # noqa: E731
+    got = run(x)
+    with native.diag_build(17):
+        pad = run(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :32], pad[:, :32])
+    np.testing.assert_allclose(got[:, 32:].cpu().numpy(), pad[:, 32:].cpu().numpy(), rtol=2e-6, atol=2e-6)
+    exp = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        exp = exp + r.double()
+    if relu:
+        exp = exp.relu()
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    if H > 2:
+        xn = x.clone()
+        xn[0, 1, 1, 1] = float('nan')
+        gn = run(xn)
+        bad = torch.isnan(gn[0]).any(0)
+        assert bad[:3, :3].all() and int(bad.sum()) == min(3, H) * min(3, W)   # exactly the windows holding the pixel
+        assert not torch.isnan(gn[1:]).any()
+
+
 @pytest.mark.parametrize('seed', range(10))
 def test_gemm_two_row_tiles_per_wave_form_is_bit_identical(seed):
     """The 64- / 96-column tile forms with TWO row tiles per wave (256-row blocks, every W fragment read once
