@@ -979,7 +979,8 @@ def test_conv3x3_buffer_addressed_form_equals_flat_form(N, H, W, Cin, Cout, stri
     b = torch.randn(Cout, generator=g).cuda()
     with native.diag_build(5):
         flat = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout).clone()
-    buf = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout)
+    with native.diag_build(17):     # (17: no half-tail form for 33 .. 48 outputs -- the flat form has none)
+        buf = conv3x3_split(xd, wp, b, stride=stride, relu=False, cout=Cout).clone()
     torch.cuda.synchronize()
     assert torch.equal(torch.isnan(buf), torch.isnan(flat))
     assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(flat))
@@ -1320,7 +1321,7 @@ def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
 
 
 @pytest.mark.parametrize('n,H,W,Cin,Cout,res,relu', [(2, 40, 56, 48, 48, True, True), (1, 33, 21, 48, 48, False, False),
-                                                      (3, 9, 11, 64, 36, True, False), (2, 19, 27, 16, 40, False, True),
+                                                      (3, 9, 11, 64, 36, True, False), (2, 19, 27, 16, 40, False, False),
                                                       (1, 7, 5, 96, 44, True, True), (1, 1, 1, 48, 48, False, False)])
 def test_conv3x3_half_tail_form_vs_padded_form_and_fp64(n, H, W, Cin, Cout, res, relu):
     """33 .. 48 output channels of a 3x3 convolution (HRNet-w48's 48-channel branch): the columns behind the first
@@ -1349,7 +1350,7 @@ def test_conv3x3_half_tail_form_vs_padded_form_and_fp64(n, H, W, Cin, Cout, res,
     if relu:
         exp = exp.relu()
     np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
-    if H > 2:
+    if H > 2 and not relu:      # (max(0, NaN) = 0: with the ReLU epilogue a NaN does not survive, in either form)
         xn = x.clone()
         xn[0, 1, 1, 1] = float('nan')
         gn = run(xn)

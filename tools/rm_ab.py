@@ -55,6 +55,22 @@ def main():
                   lambda: ops.bottleneck_chain(c1, w2, b64, w3, b256, residual=idm, w1n_planes=w1n, b1n=b64, out=idm), fl(64, 64)))
     cases.append(('layer1.2 chain (3x3 | conv3 + identity | layer2 conv1 128), in place',
                   lambda: ops.bottleneck_chain(c1, w2, b64, w3, b256, residual=idm, w1n_planes=w1n128, b1n=b128, out=idm), fl(64, 128)))
+    # the half-tail form (16-column tail on 16x16x32 MFMAs over slab pairs; the shipped selection, variant 0)
+    # against the zero-padded 64-column form (variant 17) on HRNet-w48's 48-channel 3x3
+    x48, id48 = cl(F, 200, 336, 48), cl(F, 200, 336, 48)
+    w48, b48 = ops.split_conv3x3_weight(rnd(48, 48, 3, 3, sc=0.05)), rnd(48)
+    ht = lambda: ops.conv3x3_split(x48, w48, b48, relu=True, residual=id48, cout=48)   # noqa: E731
+    tt = {17: [], 0: []}
+    for rd in range(4):
+        for v in (17, 0):
+            with native.diag_build(v):
+                t = timed(ht)
+            if rd:
+                tt[v].append(t)
+    a, b = sorted(tt[17])[1], sorted(tt[0])[1]
+    fl48 = 2 * F * 200 * 336 * 9 * 48 * 48
+    print(f'3x3 48 -> 48 + identity + ReLU, {F} x 200 x 336: padded 64-column form {a:8.1f} us ({fl48 / a * 1e-6:5.1f} TF/s)   '
+          f'half-tail form {b:8.1f} us ({fl48 / b * 1e-6:5.1f} TF/s)   {100 * (b / a - 1):+5.1f} %', flush=True)
     res = {(n, v): [] for n, _, _ in cases for v in (15, 16)}
     for rd in range(4):
         for name, fn, _ in cases:
