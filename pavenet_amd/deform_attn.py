@@ -79,6 +79,9 @@ def _proj(linear, x):
     return linear(x)
 
 
+PADDED_FAST_PATH = True   # A/B switch (tools/debug_padded.py): False = the masked_fill / separate-GEMM formulation
+
+
 def masked_row_index(mask):
     """int32 indices of the True entries of a (cached) padding mask, flattened row-major -- built ONCE per mask
     tensor (one device read-back when a padded batch shape is first seen) and kept on the tensor that owns the
@@ -108,7 +111,7 @@ def project_values_hoisted(attns, value_bf, key_padding_mask=None, masked_rows=N
     from .bricks import _split_weight, get_gemm_mode, split_gemm_ok
     x = value_bf
     fill = None
-    if key_padding_mask is not None and x.is_cuda and x.is_contiguous() and len(attns) >= 2 \
+    if PADDED_FAST_PATH and key_padding_mask is not None and x.is_cuda and x.is_contiguous() and len(attns) >= 2 \
             and not torch.is_grad_enabled() and key_padding_mask.dtype == torch.bool \
             and all(type(a).project_value in (MulFramesMultiScaleDeformablePoseAttention.project_value,
                                               MulFramesMultiScaleDeformableAttention.project_value)
@@ -328,7 +331,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             identity = query
         tile_levels = kwargs.get('tile_levels')
         groups = kwargs.get('frame_groups')
-        if (groups is not None and self_value and query_pos is not None and query_plus_pos is None
+        if (PADDED_FAST_PATH and groups is not None and self_value and query_pos is not None and query_plus_pos is None
                 and not self.batch_first and key_padding_mask is not None and tile_levels is not None
                 and kwargs.get('memory_clip_index') is None and reference_points.shape[-1] == 2
                 and self.num_levels == 4 and self.num_points == 4 and query_pos.dim() == 3

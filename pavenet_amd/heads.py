@@ -56,6 +56,11 @@ class Linear_with_norm(nn.Module):  # noqa: N801  (reference class name, HEAD:16
         self.bias = bias
         self.norm = norm
         self.linear = nn.Linear(in_channel, out_channel, bias)
+        self.constructor_init()
+
+    def constructor_init(self):
+        """The reference's constructor-time initialisation (HEAD:1611: xavier_uniform, gain 0.01), which
+        `init_weights` never redoes: re-applied by weights.init_random_weights after it re-draws the defaults."""
         nn.init.xavier_uniform_(self.linear.weight, gain=0.01)
 
     def forward(self, x):

@@ -18,6 +18,11 @@ def init_random_weights(model, seed=0):
         if callable(reset) and not list(mod.children()) or isinstance(mod, torch.nn.MultiheadAttention):
             if callable(reset):
                 reset()
+    # ... and put back what a module's CONSTRUCTOR set beyond the defaults (init_weights does not redo it:
+    # heads.Linear_with_norm's xavier_uniform with gain 0.01 on the sigma / RLE branches -- advisor finding, round 4)
+    for mod in model.modules():
+        if callable(getattr(mod, 'constructor_init', None)):
+            mod.constructor_init()
     for m in (model.backbone, model.neck, model.bbox_head):
         if m is not None:
             m.init_weights()
