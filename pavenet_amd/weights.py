@@ -18,11 +18,15 @@ def init_random_weights(model, seed=0):
         if callable(reset) and not list(mod.children()) or isinstance(mod, torch.nn.MultiheadAttention):
             if callable(reset):
                 reset()
-    # ... and put back what a module's CONSTRUCTOR set beyond the defaults (init_weights does not redo it:
-    # heads.Linear_with_norm's xavier_uniform with gain 0.01 on the sigma / RLE branches -- advisor finding, round 4)
-    for mod in model.modules():
-        if callable(getattr(mod, 'constructor_init', None)):
-            mod.constructor_init()
+    # NOT re-applied on purpose: heads.Linear_with_norm's constructor-time xavier_uniform(gain = 0.01) on the last
+    # layer of the sigma / RLE branches (HEAD:1611; `init_weights` never redoes it, so the reset above leaves the
+    # default Linear init there -- advisor finding, round 4).  Tried in round 5 (`constructor_init()` after the
+    # reset): every sigma then sits at ~0.5, the twenty best poses of a random-weight clip become near copies of
+    # each other and OKS-NMS keeps ONE (bench parity: oracle_poses 1) -- the full-size parity tests need >= 5
+    # surviving poses to mean anything.  The recipe of rounds 1-4 stays; what it costs: the RLE rescale
+    # kpt p^5 / (p^5 + 1e-10) is ill-conditioned for some poses (p^5 ~ 1e-10), so rounding-level differences
+    # between two batch compositions show as up to ~0.4 px in FINAL key points while the decoder states agree to
+    # 1e-4 (tests compare across batch compositions on the decoder states, against the oracle on one composition).
     for m in (model.backbone, model.neck, model.bbox_head):
         if m is not None:
             m.init_weights()

@@ -23,13 +23,20 @@ from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 WANT = ('copy_', 'clone', 'add', 'add_', 'relu', 'clamp_min', 'clamp_min_', 'cat', 'mul', 'sigmoid',
         '_to_copy', 'index', 'gather', 'expand_copy', 'repeat', 'stack')
+# `python tools/copy_census.py all`: every aten op that launches something (all but the view / metadata ops)
+ALL = len(sys.argv) > 1 and sys.argv[1] == 'all'
+VIEWS = ('view', 'reshape', '_unsafe_view', 'permute', 'expand', 'slice', 'select', 'as_strided', 'unsqueeze',
+         'squeeze', 'transpose', 't', 'detach', 'alias', 'empty', 'empty_like', 'empty_strided', 'unflatten', 'flatten',
+         'split', 'split_with_sizes', 'unbind', 'chunk', 'narrow', 'view_as', '_reshape_alias', 'lift_fresh', 'unfold',
+         'diagonal', 'movedim', 'new_empty', 'new_empty_strided', 'is_same_size', 'sym_size', 'sym_stride', 'stride',
+         'size', 'dim', 'numel', 'is_contiguous', 'storage_offset', 'new_zeros_like', '_local_scalar_dense')
 cnt = collections.Counter()
 
 
 class Census(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.__name__.split('.')[0]
-        if name in WANT:
+        if (ALL and name not in VIEWS) or name in WANT:
             fr = [f for f in traceback.extract_stack() if 'pavenet_amd/' in f.filename]
             if fr:
                 f = fr[-1]
