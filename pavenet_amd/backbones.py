@@ -320,14 +320,19 @@ class ResNet(BaseModule):
         c2 = blk.conv2
         w3, b3 = f[(name, bi, 'conv3')]
         w3_kn = f.get((name, bi, 'conv3_kn'))
-        split3 = blk.downsample is None and split_gemm_ok(rows, w3.flatten(1))
-        if split3:
-            w3_kn = None  # the split GEMM takes the tail (same prologue / epilogue) for K >= 256
         taps = f.get((name, bi, 'conv2_taps')) if self.deterministic_conv3x3 else None
         wsplit = None
         if c2.dilation[0] == 1 and c2.padding[0] == 1 and c2.stride[0] == c2.stride[1] \
                 and not torch.is_grad_enabled():
             wsplit = split_conv_weight(w2)     # split / 16-bit GEMM modes: same kernel family
+        from .bricks import fused_mode, small_split_ok
+        # (below min_rows too when the 3x3 runs on the split kernel -- its epilogue applies bn2 + relu, so the tail
+        # needs no A-side prologue: the same kernels for a one-clip batch as for a large one)
+        split3 = blk.downsample is None and (
+            split_gemm_ok(rows, w3.flatten(1))
+            or (wsplit is not None and fused_mode() and small_split_ok(rows, w3.flatten(1))))
+        if split3:
+            w3_kn = None  # the split GEMM takes the tail (same prologue / epilogue) for K >= 256
         if wsplit is not None:
             from .bricks import get_gemm_mode
             y = ops.conv3x3_split(y, wsplit, b2, stride=c2.stride[0], relu=True,
@@ -347,16 +352,19 @@ class ResNet(BaseModule):
             wd, bd = f[(name, bi, 'ds')]
             s = blk.downsample[0].stride[0]
             tail = f.get((name, bi, 'tail_ds_kn'))
-            from .bricks import _GEMM, _split_weight, fused_mode
+            from .bricks import _GEMM, _split_weight, fused_mode, small_split_ok
+            # (any number of rows: below min_rows -- layer4 of a one-clip batch -- these were vendor GEMMs until
+            # round 5, so a clip's values depended on the batch it came in and a library kernel was on the path)
+            w3_split = b2 is None and (split_gemm_ok(yrows, w3.flatten(1)) or small_split_ok(yrows, w3.flatten(1)))
             if (s > 1 and tail is None and fused_mode() and not torch.is_grad_enabled()
                     and wd.shape[0] % 128 == 0 and wd.shape[1] % 64 == 0
-                    and yrows.shape[0] >= _GEMM['min_rows']
-                    and (w3_kn is not None or split_gemm_ok(yrows, w3.flatten(1)))):
+                    and (yrows.shape[0] >= _GEMM['min_rows'] or w3_split)
+                    and (w3_kn is not None or w3_split or split_gemm_ok(yrows, w3.flatten(1)))):
                 # stride-2 downsample: the GEMM reads the strided pixels itself (no slice copy)
                 idt = ops.conv1x1_strided_split(x, _split_weight(wd.flatten(1)),
                                                 self._ds_bias(f, name, bi), stride=s)
                 idt, _ = self._as_rows(idt)
-                if split_gemm_ok(yrows, w3.flatten(1)):
+                if w3_split or split_gemm_ok(yrows, w3.flatten(1)):
                     out = linear_rows(yrows, w3.flatten(1), None, relu=True, residual=idt,
                                       inplace_residual=True, a_bias=b2)
                 else:
@@ -367,7 +375,7 @@ class ResNet(BaseModule):
             xrows, _ = self._as_rows(xs)
             from .bricks import _split_cached
             if tail is not None and b2 is None and fused_mode() \
-                    and not torch.is_grad_enabled() and yrows.shape[0] >= _GEMM['min_rows'] \
+                    and not torch.is_grad_enabled() \
                     and tail[0].shape[0] % 32 == 0 and tail[0].shape[1] % 64 == 0 \
                     and yrows.shape[1] % 16 == 0:
                 # relu([y | x] @ [W3 | Wd]^T + b3 + bd) on the split kernel: two A sources, one
