@@ -1536,8 +1536,12 @@ void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks
   // Few tiles and a very long K (K >= 8192: the ChannelMapper's 3x3 on C5).  ALWAYS 8 parts: the
   // summation order of an output must not depend on the batch size (a clip's values are the same
   // alone and inside a batch, as long as the batch stays under the tile threshold).
-  if (tiles >= 200 || nsl < 512 || pave_internal_diag_variant() == 6) return;
-  int per = ((nsl + 7) / 8 + 1) & ~1;
+  if (tiles >= 200 || nsl < 128 || pave_internal_diag_variant() == 6) return;
+  // 2 048 <= K < 8 192 (the ChannelMapper's extra level behind HRNet-w48: 3x3 / stride 2 on 384 channels,
+  // K = 3 456): 4 parts -- a fixed count per K range, for the same reason
+  const int want = nsl < 512 ? 4 : 8;
+  if (nsl < 512 && tiles >= 64) return;
+  int per = ((nsl + want - 1) / want + 1) & ~1;
   int parts;
   for (;; per += 2) {   // the last part keeps >= 4 slabs (nsl and per are even: its size is even)
     parts = (nsl + per - 1) / per;

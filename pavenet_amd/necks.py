@@ -76,9 +76,9 @@ class ChannelMapper(BaseModule):
                 conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2):
             s_ = conv.stride[0]
             if n * ((h - 1) // s_ + 1) * ((w - 1) // s_ + 1) < 16384 and \
-                    (not fused_mode() or 9 * c < 8192):
-                # too few 128-row tiles to fill 256 CUs: the library's split-K wins (the 3-plane
-                # kernel has its own split-K form from K = 8192 on: ops.conv3x3_split)
+                    (not fused_mode() or 9 * c < 2048):
+                # too few 128-row tiles to fill 256 CUs: the library's split-K wins (the 3-plane / fp16
+                # kernel has its own split-K form from K = 2048 on: ops.conv3x3_split)
                 return None
             wsplit = split_conv_weight(conv.weight)
             if wsplit is None:
