@@ -897,7 +897,8 @@ def test_conv3x3_split_padded_channels_with_residual_vs_fp64(N, H, W, Cin, Cout,
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 25, 42, 2048, 256, 2), (1, 13, 21, 1024, 128, 1),
-                                                   (3, 9, 11, 944, 100, 1), (1, 14, 14, 1040, 64, 2)])
+                                                   (3, 9, 11, 944, 100, 1), (1, 14, 14, 1040, 64, 2),
+                                                   (2, 25, 42, 384, 256, 2)])
 def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     """The split-K form of the 3-plane 3x3 convolution (few output pixels, long K: the
     ChannelMapper's extra level, channel_mapper.py:84-97): the plan must exist for these shapes,
@@ -908,10 +909,13 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
     lib = native.load()
     M = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
-    # (always 8 parts: the summation order does not depend on the batch size)
-    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == 8 * M * Cout * 4
-    assert lib.pave_conv3x3_splitk_workspace_bytes(4 * N, H, W, Cin, Cout, stride) in (0, 8 * 4 * M * Cout * 4)
-    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, 256, Cout, stride) == 0    # K = 2304: one pass
+    # (a fixed number of parts per K range -- 8 from K = 8 192 on, 4 for 2 048 <= K < 8 192 (the neck's extra level
+    # behind HRNet-w48: K = 3 456) --: the summation order does not depend on the batch size)
+    parts = 8 if 9 * Cin >= 8192 else 4
+    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == parts * M * Cout * 4
+    assert lib.pave_conv3x3_splitk_workspace_bytes(4 * N, H, W, Cin, Cout, stride) in (0, parts * 4 * M * Cout * 4)
+    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, 256, Cout, stride) == 4 * M * Cout * 4   # K = 2 304
+    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, 128, Cout, stride) == 0    # K = 1 152: one pass
     g = torch.Generator().manual_seed(Cin * Cout + H)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin**0.5)
