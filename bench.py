@@ -189,7 +189,9 @@ def algorithmic_bytes_gemm_launch(tag, shape):
         return 4 * M * (64 + (k2 if k2 else 256) + 256 + cn)
     if tag == 'conv7x7_stem':
         return M * (4 * 3 + 64) * 4
-    a = M * K * 4
+    a = M * K * (2 if 'a16' in notes else 4)       # (fp16 mode: an fp16 activation in / out of the launch)
+    if 'o16' in notes:
+        return a + M * N * 2
     for n in notes:
         if n.startswith('3x3 s'):
             s_ = int(n[5])

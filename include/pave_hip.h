@@ -371,6 +371,21 @@ int pave_gemm_bf16x3_f32(const float* a, const float* a_bias, const void* w_plan
                          int N, int relu, int nplanes, void* stream);
 
 /*
+ * fp16 operand mode with fp16 ACTIVATIONS around a launch (BASELINE configs[4]; wide tile forms, N %% 256 == 0):
+ * a tensor that is only ever a GEMM operand -- the hidden activation between the two Linears of an FFN
+ * (third_party/mmcv/mmcv/cnn/bricks/transformer.py:1046-1120) -- is stored as the fp16 values the next launch's
+ * MFMA consumes anyway: the same results as fp32 storage (the consumer would round it to fp16 at operand fetch),
+ * half the bytes on an HBM-bound chain.
+ *   a [M, K] fp32, or fp16 when a_is_f16;  w_plane = ONE fp16 plane [K/16][1][N][16] (PAVE_PLANES_FP16);
+ *   gamma == NULL:  out[M, N] = act(a W^T + bias), fp32 or (out_is_f16) fp16;  relu as pave_gemm_bf16x3_f32;
+ *   gamma != NULL:  out[M, 256] = LayerNorm(a W^T + bias + residual) * gamma + beta, fp32 (N == 256; residual fp32,
+ *                   may be NULL or alias out).
+ */
+int pave_gemm_fp16_act_f32(const void* a, int a_is_f16, const void* w_plane, const float* bias,
+                           const float* residual, const float* gamma, const float* beta, float eps, void* out,
+                           int out_is_f16, long long M, int K, int N, int relu, void* stream);
+
+/*
  * Same GEMM with two epilogue options (the encoder layer's `value_proj | sampling_offsets |
  * attention_weights` Linears of third_party/mmcv/mmcv/ops/multi_scale_deform_attn.py:355-379 run
  * as ONE launch over the layer input):

@@ -114,6 +114,7 @@ def _fusable(*tensors):
 # measured SLOWER on the bench workload (the extra 640 MB store costs more than the broadcast add
 # it saves) and superseded by folding the positional term into the merged projection GEMM
 # (deform_attn._forward_merged), so it is off (set the attribute for an A/B run).
+FP16_ACTIVATIONS = True  # 'fp16' mode: the FFN hidden stored as fp16 between its two launches (A/B switch)
 FUSE_QUERY_POS = False   # A/B switch (tools/ab_switch.py sets the attribute; never read from the environment)
 _GEMM = {'mode': 'bf16x3', 'min_rows': 8192, 'ln_fused': True, 'small': True}
 
@@ -529,7 +530,24 @@ class FFN(BaseModule):
         if self._fast_ok(x):
             xb, ib = batch_first(x), batch_first(identity)
             fc1, fc2 = self.layers[0][0], self.layers[1]
-            h = linear_rows(xb.reshape(-1, xb.shape[-1]), fc1.weight, fc1.bias, relu=True)
+            x2 = xb.reshape(-1, xb.shape[-1])
+            if (_GEMM['mode'] == 'fp16' and FP16_ACTIVATIONS and x2.shape[0] >= 65536 and x2.is_contiguous()
+                    and ib.is_contiguous() and post_norm is not None and fc2.out_features == 256
+                    and fc1.out_features % 256 == 0 and fc1.in_features % 32 == 0 and fc1.in_features >= 64
+                    and tuple(post_norm.normalized_shape) == (256,) and post_norm.weight is not None
+                    and post_norm.bias is not None and not torch.is_grad_enabled()
+                    and not (carry is not None and carry.get('emit'))):
+                # fp16 mode: the hidden activation only ever feeds fc2's MFMA, which rounds it to fp16 at operand
+                # fetch -- stored AS fp16 it is the same values at half the bytes of the two launches that are
+                # bound by them (fc1 writes 4 x the layer input, fc2 reads it back)
+                from . import ops
+                h16 = ops.gemm_fp16_act(x2, _split_weight(fc1.weight), fc1.bias, relu=True, out_half=True)
+                idt2 = ib.reshape(-1, 256)
+                out = ops.gemm_fp16_act(h16, _split_weight(fc2.weight), fc2.bias, residual=idt2,
+                                        ln=(post_norm.weight, post_norm.bias, post_norm.eps),
+                                        out=idt2 if inplace_residual else None)
+                return seq_first_view(out.view(ib.shape))
+            h = linear_rows(x2, fc1.weight, fc1.bias, relu=True)
             pos_rows = None
             if carry is not None and carry.get('emit') and post_norm is not None \
                     and query_pos is not None and query_pos.dtype == torch.float32:

@@ -199,8 +199,11 @@ __device__ const uint4 g_zero_chunk[4] = {};   // source of out-of-image taps (z
 // tools/microbench/permlane_swap.hip), its B operand is one 16-byte piece per lane, lanes 0-31 from the first
 // slab's stage, 32-63 from the second's.  6 + 3 MFMA-equivalents per slab instead of 12.  The tail columns
 // accumulate 32 k per instruction: equal to the padded form up to fp32 summation order, not bit for bit.
+// IO (fp16 mode, plain rows): bit 0 = the A rows are fp16 in memory (a tensor that is only ever a GEMM operand --
+// the FFN hidden -- kept as what the MFMA consumes: half the bytes, no conversion, the same values), bit 1 = the
+// output is stored as fp16 (bias + ReLU in fp32 first).
 template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1, int PL = 3,
-          bool HT = false>
+          bool HT = false, int IO = 0>
 __device__ __forceinline__ void gemm_q_body(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
@@ -211,7 +214,10 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
   constexpr int BM = QBM * RM;               // rows per block
-  constexpr int A_STAGE = BM * 64;           // raw fp32: BM rows x 64 B
+  constexpr bool AH = (IO & 1) != 0, OH = (IO & 2) != 0;
+  static_assert(!AH || (PL == 1 && KIND == 0 && !ABIAS && RM == 1), "fp16 A rows: fp16 operand mode, plain rows");
+  static_assert(!OH || (PL == 1 && !LNORM && EPI == 0 && !HT && RM == 1), "fp16 output: plain epilogue");
+  constexpr int A_STAGE = AH ? BM * 32 : BM * 64;   // raw fp32: BM rows x 64 B (fp16 rows: 32 B)
   static_assert(RM == 1 || (RM == 2 && WN == 1 && !WIDE && !LNORM && EPI == 0), "two row tiles per wave: narrow form");
   static_assert(PL == 3 || PL == 1, "operand planes: 3 (bf16 split) or 1 (fp16)");
   constexpr int W_STAGE = PL * BN * 32;      // PL planes x BN rows x 32 B
@@ -282,11 +288,14 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int d = wave + NWAVE * q;
-      const int r = d * 16 + (lane >> 2);
-      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      // (fp16 rows: an instruction covers 32 rows x two 16-byte halves, half h of row r at slot h ^ ((r >> 3) & 1))
+      const int r = AH ? d * 32 + (lane >> 1) : d * 16 + (lane >> 2);
+      const int c = AH ? (lane & 1) ^ ((r >> 3) & 1) : (lane & 3) ^ ((r >> 2) & 3);
       long long gm = (long long)m0 + r;
       if (gm >= M) gm = M - 1;   // rows past M: stand-in data, never stored
-      if (KIND == 0) {
+      if (KIND == 0 && AH) {
+        a_voff[q] = (unsigned)(((gm - m0) * (g.H > 0 ? g.H : K) + c * 8) * 2);
+      } else if (KIND == 0) {
         a_voff[q] = (unsigned)(((gm - m0) * (g.H > 0 ? g.H : K) + c * 4) * 4);
       } else if (KIND == 4) {
         a_voff[q] = (unsigned)(((gm - m0) * g.Cin + c * 4) * 4);
@@ -316,7 +325,10 @@ __device__ __forceinline__ void gemm_q_body(
         }
       }
     }
-    if (KIND == 0)
+    if (KIND == 0 && AH)
+      a_base = reinterpret_cast<const unsigned char*>(A) +
+               ((long long)m0 * (g.H > 0 ? g.H : K) + (g.W > 0 ? (long long)(n0 / g.W) * K : 0)) * 2;
+    else if (KIND == 0)
       a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * (g.H > 0 ? g.H : K) +
                                                       (g.W > 0 ? (long long)(n0 / g.W) * K : 0));
     if (KIND == 4) {
@@ -361,7 +373,7 @@ __device__ __forceinline__ void gemm_q_body(
         if (slab < s1) dma16(a_voff[q], a_base + (long long)slab * 64, dst);
         else dma16(a2_voff[q], a2_base + (long long)(slab - s1) * 64, dst);
       } else {
-        dma16(a_voff[q], a_base + (long long)slab * 64, dst);
+        dma16(a_voff[q], a_base + (long long)slab * (AH ? 32 : 64), dst);
       }
     }
 #pragma unroll
@@ -374,7 +386,8 @@ __device__ __forceinline__ void gemm_q_body(
 
   // ---- operand fragment addresses (bytes inside a stage)
   const int sw = (lr >> 2) & 3;
-  const int a_rd0 = (wm * 32 * RM + lr) * 64 + (((2 * kh) ^ sw) * 16);   // (+ 2 KiB per further row tile)
+  const int a_rd0 = AH ? (wm * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16)
+                       : (wm * 32 * RM + lr) * 64 + (((2 * kh) ^ sw) * 16);   // (+ 2 KiB per further row tile)
   const int a_rd1 = a_rd0 ^ 16;
   const int w_rd = A_STAGE + (wn * TN * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);
 
@@ -389,7 +402,7 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
       raw[rt][0] = *reinterpret_cast<const f32x4*>(st + a_rd0 + rt * 2048);
-      raw[rt][1] = *reinterpret_cast<const f32x4*>(st + a_rd1 + rt * 2048);
+      if constexpr (!AH) raw[rt][1] = *reinterpret_cast<const f32x4*>(st + a_rd1 + rt * 2048);
     }
   };
   // column tiles [TQ quarter, TQ quarter + TQ) of the stage's W planes
@@ -465,7 +478,9 @@ __device__ __forceinline__ void gemm_q_body(
         hi[i] = fmaxf(hi[i] + b1[i], 0.f);
       }
     }
-    if constexpr (PL == 3) {
+    if constexpr (AH) {      // the lane's 8 halves ARE the operand
+      apl[set][rt][0] = __builtin_bit_cast(u32x4, lo);
+    } else if constexpr (PL == 3) {
       split8(lo, hi, apl[set][rt]);
     } else {
       apl[set][rt][0] = u32x4{pack_rne_f16(lo.x, lo.y), pack_rne_f16(lo.z, lo.w), pack_rne_f16(hi.x, hi.y),
@@ -709,15 +724,17 @@ __device__ __forceinline__ void gemm_q_body(
     // rows stored that way came out with the next instruction's value in them (tools/debug_encproj.py).
     const int orows = min(BM, M - em0);
     const int ocol0 = en0 + wn * TN * 32 - csh;
+    constexpr int OB = OH ? 2 : 4;   // bytes per stored element
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-        obase + (long long)em0 * ldo + ocol0, 0, (orows * ldo - ocol0) * 4, 0x00020000);
+        reinterpret_cast<unsigned char*>(obase) + ((long long)em0 * ldo + ocol0) * OB, 0, (orows * ldo - ocol0) * OB,
+        0x00020000);
     unsigned oro[NPR];
     int late = 0;   // an opaque zero made HERE: the lane offsets below are not computed ahead of the main
     asm volatile("" : "+v"(late));   // loop (where every register is taken)
 #pragma unroll
     for (int ps = 0; ps < NPR; ++ps) {
       const int lrow = wm * 32 * RM + ps * 8 + erow + late;
-      oro[ps] = lrow < orows ? (unsigned)(lrow * ldo * 4 + ec4 * 16) : kOut;
+      oro[ps] = lrow < orows ? (unsigned)(lrow * ldo * OB + ec4 * 4 * OB) : kOut;
     }
     constexpr bool LNW = LNORM && WIDE;   // LayerNorm computed on the accumulator layout (below)
     if constexpr (LNW) {
@@ -873,6 +890,11 @@ __device__ __forceinline__ void gemm_q_body(
               pave_enc::softmax16(v[ps].x, v[ps].y, v[ps].z, v[ps].w, e, inv);
               v[ps].x = e[0] * inv, v[ps].y = e[1] * inv, v[ps].z = e[2] * inv, v[ps].w = e[3] * inv;
             }
+            if constexpr (OH) {
+              typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+              const u32x2s hv = {pack_rne_f16(v[ps].x, v[ps].y), pack_rne_f16(v[ps].z, v[ps].w)};
+              __builtin_amdgcn_raw_buffer_store_b64(hv, ors, (colok ? oro[rt * NPS + ps] : kOut) + j * 64, 0, 0);
+            } else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ps]), ors,
                                                    (colok ? oro[rt * NPS + ps] : kOut) + j * 128, 0, 0);
           }
@@ -997,13 +1019,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 &&
                                                                os, QLn{nullptr, nullptr, 0.f}, A2);
 }
 // the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
-template <int KIND, int PL = 3>
+template <int KIND, int PL = 3, int IO = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu,
     const QConv g, const QOut os, const float* __restrict__ A2) {
-  gemm_q_body<8, 1, KIND, false, false, true, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, relu, nullptr, g, os,
-                                                        QLn{nullptr, nullptr, 0.f}, A2);
+  gemm_q_body<8, 1, KIND, false, false, true, 0, 1, PL, false, IO>(A, Wp, bias, residual, out, M, K, N, relu, nullptr,
+                                                                   g, os, QLn{nullptr, nullptr, 0.f}, A2);
 }
 // mixed tiles for N % 256 == 128 (the encoder's merged projection, N = 640): the first N / 256 column
 // tiles of a row tile run the wide body, its last 128 columns the narrow one; the blocks of a row
@@ -1155,12 +1177,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Round 3 built this with a second register image of the tile (spills) and with LDS sweeps (equal to
 // the 8-wave form); here bias + identity are added and the statistics taken IN the accumulator
 // registers (see LNW in gemm_q_body), which costs no registers and no LDS pass.
-template <int PL>
+template <int PL, int IO = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_ln_kernel(
     const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const QLn ln) {
-  gemm_q_body<8, 1, 0, false, true, true, 0, 1, PL>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
-                                                    QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
+  gemm_q_body<8, 1, 0, false, true, true, 0, 1, PL, false, IO>(A, Wp, bias, residual, out, M, K, N, 0, nullptr,
+                                                               QConv{0, 0, 0, 0, 0, 0}, QOut{nullptr, 0, 0, N, 0}, ln);
 }
 
 // ---------------------------------------------------------------------------
@@ -1801,6 +1823,55 @@ int pave_internal_gemm_q_ln(const float* a, const void* w_planes, const float* b
   if (planes == 1) return gemm_q_ln_go<1>(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
   if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_q_ln: 3 bf16 planes or 1 fp16 plane");
   return gemm_q_ln_go<3>(a, w_planes, bias, residual, gamma, beta, eps, out, M, K, N, stream);
+}
+
+// fp16 mode with fp16 ACTIVATIONS around a launch (wide tile forms only): a_f16 -- the A rows are fp16 [M, K];
+// gamma == nullptr: out = act(a W^T + bias) as fp32 or (out_f16) fp16 [M, N], N % 256 == 0;  gamma != nullptr:
+// out = LayerNorm(a W^T + bias + residual) fp32, N == 256 (the accumulator-layout LayerNorm form).
+int pave_internal_gemm_f16act(const void* a, int a_f16, const void* w_plane, const float* bias, const float* residual,
+                              const float* gamma, const float* beta, float eps, void* out, int out_f16, long long M,
+                              int K, int N, int relu, void* stream) {
+  if (K % 32 != 0 || K < 64 || N % 256 != 0 || K >= (1 << 23))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: K %% 32 == 0 (64 <= K < 2^23), N %% 256 == 0");
+  if (gamma && (N != 256 || out_f16 || !beta || M * 1024ll >= (1ll << 32)))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: the LayerNorm form has N == 256, fp32 output, M < 2^22");
+  if (!gamma && (residual || relu < 0 || relu > 2))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: the plain form takes bias + activation only");
+  if ((long long)N * 512 >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: rows of >= 16 MiB");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint16_t* w = static_cast<const uint16_t*>(w_plane);
+  const float* af = static_cast<const float*>(a);
+  float* of = static_cast<float*>(out);
+  const QConv g0{0, 0, 0, 0, 0, 0, 0u};
+  const long long gx = ((M + QBM - 1) / QBM) * (N / 256);
+  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: grid too large");
+#define PAVE_F16_GO(KERN, ...)                                                                        \
+  {                                                                                                   \
+    static bool attr = false;                                                                         \
+    if (!attr) {                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              w_smem<1>()) != hipSuccess)                                             \
+        return pave_internal_fail(PAVE_E_LAUNCH, "gemm_fp16_act: cannot raise dynamic LDS limit");    \
+      attr = true;                                                                                    \
+    }                                                                                                 \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)gx), dim3(256), w_smem<1>(), st, __VA_ARGS__);            \
+  }
+  if (gamma) {
+    const QLn ln{gamma, beta, eps};
+    if (a_f16) PAVE_F16_GO((gemm_w_ln_kernel<1, 1>), af, w, bias, residual, of, (int)M, K, N, ln)
+    else PAVE_F16_GO((gemm_w_ln_kernel<1, 0>), af, w, bias, residual, of, (int)M, K, N, ln)
+  } else {
+    const QOut os{nullptr, 0, 0, N, 0};
+    const int io = (a_f16 ? 1 : 0) | (out_f16 ? 2 : 0);
+    if (io == 0) PAVE_F16_GO((gemm_w_kernel<0, 1, 0>), af, w, bias, nullptr, of, (int)M, K, N, relu, g0, os, nullptr)
+    else if (io == 1) PAVE_F16_GO((gemm_w_kernel<0, 1, 1>), af, w, bias, nullptr, of, (int)M, K, N, relu, g0, os, nullptr)
+    else if (io == 2) PAVE_F16_GO((gemm_w_kernel<0, 1, 2>), af, w, bias, nullptr, of, (int)M, K, N, relu, g0, os, nullptr)
+    else PAVE_F16_GO((gemm_w_kernel<0, 1, 3>), af, w, bias, nullptr, of, (int)M, K, N, relu, g0, os, nullptr)
+  }
+#undef PAVE_F16_GO
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
 }
 
 template <bool HAS_A, int KIND2, int CN, int RMC = 1, int PL = 3>

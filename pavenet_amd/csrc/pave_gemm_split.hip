@@ -722,6 +722,16 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
 #undef PAVE_GO
 }
 
+int pave_gemm_fp16_act_f32(const void* a, int a_is_f16, const void* w_plane, const float* bias,
+                           const float* residual, const float* gamma, const float* beta, float eps, void* out,
+                           int out_is_f16, long long M, int K, int N, int relu, void* stream) {
+  if (!a || !w_plane || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: null pointer");
+  if (M <= 0 || M >= (1ll << 31) || K <= 0 || N <= 0)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_fp16_act: bad sizes (0 < M < 2^31)");
+  return pave_internal_gemm_f16act(a, a_is_f16 != 0, w_plane, bias, residual, gamma, beta, eps, out, out_is_f16 != 0,
+                                   M, K, N, relu, stream);
+}
+
 int pave_gemm_bf16x3_cat_f32(const float* a, long long K1, const float* a2, const void* w_planes,
                              const float* bias, const float* residual, float* out, long long M, int K,
                              int N, int relu, int nplanes, void* stream) {

@@ -35,6 +35,8 @@ SIGNATURES = {
     'pave_rows_gemm_bias_res_act_f32': [_vp] * 7 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
     'pave_bias_relu_maxpool_nhwc_f32': [_vp] * 3 + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_f32': [_vp] * 6 + [ctypes.c_longlong] + [_c_int] * 4 + [_vp],
+    'pave_gemm_fp16_act_f32': [_vp, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _c_int,
+                               ctypes.c_longlong, _c_int, _c_int, _c_int, _vp],
     'pave_gemm_bf16x3_ex_f32': [_vp] * 5 + [ctypes.c_longlong, _vp, _vp, _c_int, ctypes.c_longlong]
                                + [_c_int] * 4 + [_vp],
     'pave_gemm_bf16x3_cat_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int,

@@ -949,6 +949,52 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     return out
 
 
+def gemm_fp16_act(a, w_plane, bias=None, relu=False, out_half=False, residual=None, ln=None, out=None):
+    """fp16 operand mode with fp16 activations around the launch (pave_gemm_fp16_act_f32; wide tile forms):
+    a [M, K] fp32 or float16, w_plane = the ONE fp16 plane of split_weight_bf16x3(weight, PLANES_FP16), N % 256 == 0.
+    ln = None: act(a W^T + bias) -> [M, N] fp32, or float16 with out_half (an activation that only feeds the next
+    GEMM).  ln = (gamma, beta, eps): LayerNorm(a W^T + bias + residual) gamma + beta -> [M, 256] fp32 (`residual`
+    may be the tensor given as `out`)."""
+    lib = native.load()
+    _require(isinstance(a, torch.Tensor) and a.is_cuda and a.is_contiguous() and a.dim() == 2
+             and a.dtype in (torch.float32, torch.float16), 'gemm_fp16_act: a [M, K] fp32 or float16 on the device')
+    _require(_planes(w_plane) == PLANES_FP16, 'gemm_fp16_act: one fp16 plane (split_weight_bf16x3(w, PLANES_FP16))')
+    M, K = a.shape
+    N = w_plane.shape[2]
+    _require(w_plane.shape[0] * 16 == K and N % 256 == 0, 'gemm_fp16_act: w_plane [K/16, 1, N % 256 == 0, 16]')
+    if bias is not None:
+        _dev(bias, 'bias', torch.float32)
+        _require(bias.numel() == N, 'gemm_fp16_act: bias [N]')
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    if ln is not None:
+        gamma, beta, eps = ln
+        _dev(gamma, 'gamma', torch.float32)
+        _dev(beta, 'beta', torch.float32)
+        _require(N == 256 and gamma.numel() == 256 and beta.numel() == 256 and not out_half and not relu,
+                 'gemm_fp16_act: the LayerNorm form has N == 256 and an fp32 output')
+        if residual is not None:
+            _dev(residual, 'residual', torch.float32)
+            _require(tuple(residual.shape) == (M, N), 'gemm_fp16_act: residual [M, N]')
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _require(out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.is_contiguous(), 'gemm_fp16_act: out')
+        args = (ptr(residual), gamma.data_ptr(), beta.data_ptr(), float(eps))
+        tag = _gemm_tag('gemm_bf16x3_ln', M)
+    else:
+        _require(residual is None and out is None, 'gemm_fp16_act: the plain form takes bias + activation only')
+        out = torch.empty((M, N), dtype=torch.float16 if out_half else torch.float32, device=a.device)
+        args = (None, None, None, 0.0)
+        tag = _gemm_tag('gemm_bf16x3', M)
+    note = (M, K, N, 'f16act', 'a16' if a.dtype == torch.float16 else '', 'o16' if out_half else '',
+            'ln' if ln is not None else ('relu' if relu else ''), 'res' if residual is not None else '')
+    with torch.cuda.device(a.device), _Timed(tag, 2 * M * K * N, note):
+        st = lib.pave_gemm_fp16_act_f32(a.data_ptr(), int(a.dtype == torch.float16), w_plane.data_ptr(), ptr(bias),
+                                        *args, out.data_ptr(), int(bool(out_half)), M, K, N,
+                                        2 if relu == 'gelu' else int(bool(relu)), _stream_ptr())
+    native.check(st, 'gemm_fp16_act')
+    return out
+
+
 def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_split=0, relu=False,
                    a_bias=None, fp16=False):
     """gemm_bf16x3 with a row-periodic residual table (`residual` [residual_rows, N], row m adds

@@ -1652,6 +1652,42 @@ def test_fp16_operand_mode_on_every_fused_form(form):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('M', [1000, 128, 4100])
+def test_fp16_activations_between_two_launches_change_no_value(M):
+    """pave_gemm_fp16_act_f32: the hidden activation of an FFN stored as fp16 between fc1 and fc2 + LayerNorm
+    (fp16 operand mode).  fc1 with an fp16 output = the fp32-output launch rounded to fp16, bit for bit; fc2 +
+    identity + LayerNorm on the fp16 rows = the same launch fed the fp32 rows (which it would round to fp16 at
+    operand fetch), bit for bit -- so the pair gives exactly the values of the fp32-activation chain; and against
+    the fp64 formulation on fp16-rounded operands.  Ragged M, in-place identity."""
+    from pavenet_amd import ops
+    F16 = ops.PLANES_FP16
+    g = torch.Generator().manual_seed(M)
+    x, w1, b1 = torch.randn(M, 256, generator=g), torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g)
+    w2, b2 = torch.randn(256, 1024, generator=g) / 32, torch.randn(256, generator=g)
+    idt, ga, be = torch.randn(M, 256, generator=g), torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    p1, p2 = ops.split_weight_bf16x3(w1.cuda(), F16), ops.split_weight_bf16x3(w2.cuda(), F16)
+    xd = x.cuda()
+    h32 = ops.gemm_fp16_act(xd, p1, b1.cuda(), relu=True)                      # fp32 in, fp32 out
+    h16 = ops.gemm_fp16_act(xd, p1, b1.cuda(), relu=True, out_half=True)       # fp32 in, fp16 out
+    assert h16.dtype == torch.float16 and torch.equal(h16, h32.half())
+    assert torch.equal(h32, ops.gemm_bf16x3(xd, p1, b1.cuda(), relu=True))     # = the ordinary fp16-mode launch
+    ln = (ga.cuda(), be.cuda(), 1e-5)
+    o32 = ops.gemm_fp16_act(h32, p2, b2.cuda(), residual=idt.cuda(), ln=ln)
+    o16 = ops.gemm_fp16_act(h16, p2, b2.cuda(), residual=idt.cuda(), ln=ln)
+    assert torch.equal(o16, o32)
+    buf = idt.cuda().clone()
+    assert ops.gemm_fp16_act(h16, p2, b2.cuda(), residual=buf, ln=ln, out=buf).data_ptr() == buf.data_ptr()
+    assert torch.equal(buf, o16)
+    hh = torch.relu(x.half().double() @ w1.half().double().t() + b1.double()).half().double()
+    exp = torch.nn.functional.layer_norm(hh @ w2.half().double().t() + b2.double() + idt.double(), (256,), ga.double(),
+                                         be.double(), 1e-5)
+    np.testing.assert_allclose(o16.cpu().numpy(), exp.numpy(), rtol=3e-4, atol=3e-4)   # (h rounds to fp16 near ties)
+    # fp16 rows into a plain fp32-output launch as well
+    y16 = ops.gemm_fp16_act(h16, ops.split_weight_bf16x3(torch.cat([w2, w2], 0).cuda(), F16), None)
+    y32 = ops.gemm_fp16_act(h32, ops.split_weight_bf16x3(torch.cat([w2, w2], 0).cuda(), F16), None)
+    assert torch.equal(y16, y32)
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 64, 64, 1), (1, 20, 9, 128, 128, 1),
                                                    (3, 14, 22, 128, 256, 2), (2, 9, 9, 256, 64, 2),
                                                    (1, 40, 56, 64, 192, 1)])
