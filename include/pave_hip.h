@@ -262,7 +262,11 @@ int pave_bias_add_layernorm_pos_f32(const float* x, const float* bias, const flo
  *   value [n_frames, S, 8, 32]; proj [n_frames*S, proj_stride] (offsets [8][4][4][2], then
  *   logits [8][4][4]); ref [n_frames*S, 4, 2]; out [n_frames*S, 256]
  *   levels_hw   HOST array of 8 ints (h0, w0, ..., h3, w3), levels in flattening order
- *   variant     0: windows of -4 .. +3 px (3 workgroups per CU), 1: -4 .. +4 px (1 per CU)
+ *   variant     a bit mask: 0 = windows of -4 .. +3 px (3 workgroups per CU), 1 = -4 .. +4 px (1 per CU);
+ *               | 4 = `proj` is PREPARED (pave_gemm_bf16x3_encproj_f32: pixel coordinates + attention weights;
+ *               ref is not read; default windows only);  | 8 = `out` is fp16 [n_frames*S, 256] (fp16 operand
+ *               mode: the rows only feed output_proj's MFMA, pave_gemm_fp16_act_f32 -- the same values at half
+ *               the bytes).  Other bits / combinations: PAVE_E_ARG / PAVE_E_UNSUPPORTED before anything is enqueued
  *   window_shift  NULL, or a HOST array [8 heads][4 levels][2] of (dx, dy) in level pixels that
  *               moves the LDS window of (tile, head, level): a head's points sit around
  *               reference + its mean learnt offset (the reference initialises them on a ray 1..4 px

@@ -45,6 +45,7 @@ struct TileParams {
   float* out;          // [F*S, 256]
   int S;
   int proj_stride;
+  int out_f16;         // out is fp16 [F*S, 256] (fp16 operand mode: the rows only feed output_proj's MFMA)
   int nx, ny;          // tiles per frame
   int n_blocks;
   int Hs[4], Ws[4], St[4];
@@ -410,7 +411,13 @@ __global__ __launch_bounds__(384, WPE) void enc_tile_kernel(const TileParams p) 
     accA.x += fa.x, accA.y += fa.y, accA.z += fa.z, accA.w += fa.w;
     accB.x += fb.x, accB.y += fb.y, accB.z += fb.z, accB.w += fb.w;
   }
-  if (valid) {
+  if (valid && p.out_f16) {   // (wave-uniform flag) the lane's two 4-channel chunks as 8 bytes each
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    char* o = reinterpret_cast<char*>(p.out) + ((size_t)unit * 256 + head * 32) * 2;
+    *reinterpret_cast<h4*>(o + (offA >> 1)) = __builtin_convertvector(f4{accA.x, accA.y, accA.z, accA.w}, h4);
+    *reinterpret_cast<h4*>(o + (offB >> 1)) = __builtin_convertvector(f4{accB.x, accB.y, accB.z, accB.w}, h4);
+  } else if (valid) {
     char* o = reinterpret_cast<char*>(p.out + (size_t)unit * 256 + head * 32);
     *reinterpret_cast<float4*>(o + offA) = accA;
     *reinterpret_cast<float4*>(o + offB) = accB;
@@ -426,9 +433,11 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
   // variant bit 2 (value 4): `proj` is PREPARED (pave_gemm_bf16x3_encproj_f32): attention weights and
   // level pixel coordinates instead of logits and offsets; ref is not read
   // every unsupported combination is refused HERE, before anything is enqueued
-  if (variant < 0 || (variant & ~7) != 0)
-    return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: variant is a 3-bit mask (1 = wide windows, 4 = prepared input)");
+  if (variant < 0 || (variant & ~15) != 0)
+    return pave_internal_fail(PAVE_E_ARG, "enc_deform_attn_tile: variant is a 4-bit mask (1 = wide windows, 4 = prepared "
+                                          "input, 8 = fp16 output)");
   const bool prepared = (variant & 4) != 0;
+  const bool out_f16 = (variant & 8) != 0;
   variant &= 3;
   if (prepared && variant != 0)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "enc_deform_attn_tile: prepared input with the default windows only");
@@ -446,6 +455,7 @@ static int enc_tile_launch(const float* value, const float* proj, const float* r
   p.out = out;
   p.S = S;
   p.proj_stride = proj_stride;
+  p.out_f16 = out_f16 ? 1 : 0;
   if (window_shift)
     for (int i = 0; i < kHeads * 8; ++i) {
       if (window_shift[i] < -64 || window_shift[i] > 64)

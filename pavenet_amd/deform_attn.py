@@ -237,7 +237,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             self._merged_key = key
         return self._merged_w, w_cat, b_cat
 
-    def _forward_merged(self, q, pos_row, reference_points, tile_levels):
+    def _forward_merged(self, q, pos_row, reference_points, tile_levels, out_half=False):
         """Self-attention over a frame batch whose positional encoding is the same for every
         frame (no padding): (q + pos) W^T = q W^T + (pos W^T), so value_proj and the offsets /
         logits Linears read the layer input ONCE, as one N = 640 GEMM whose epilogue adds the
@@ -270,7 +270,7 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
                                               tile_levels, value_bias=self.value_proj.bias.detach())
             out = ops.deform_attn_enc_tile(v.view(bs, S, self.num_heads, -1), samp, None,
                                            levels_hw=tile_levels, window_shift=self._tile_shift(),
-                                           prepared=True)
+                                           prepared=True, out_half=out_half)
             return out.view(bs, S, self.embed_dims)
         v, proj = ops.gemm_bf16x3_ex(q.reshape(bs * S, C), _split_weight(w_all), None, table,
                                      residual_rows=S, n_split=nv,
@@ -361,8 +361,24 @@ class MultiScaleDeformableAttention(BaseModule, _CatProj):
             q = batch_first(query)
             if _fused_ok(self, q) and split_gemm_ok(q.reshape(-1, q.shape[-1]),
                                                     self.sampling_offsets.weight):
-                out = self._forward_merged(q, query_pos[:, 0], reference_points, tile_levels)
+                from . import bricks
                 idt = batch_first(identity)
+                # fp16 mode: the sampled rows only ever feed output_proj's MFMA, which rounds them to fp16 at operand
+                # fetch -- written AS fp16 by the sampler they are the same values at half the bytes (bricks.FFN does
+                # the same with its hidden activation)
+                half = (bricks.get_gemm_mode() == 'fp16' and bricks.FP16_ACTIVATIONS and self.prepare_in_gemm
+                        and q.shape[0] * q.shape[1] >= 65536 and post_norm is not None and idt.is_contiguous()
+                        and tuple(post_norm.normalized_shape) == (256,) and post_norm.weight is not None
+                        and post_norm.bias is not None and self.value_proj.out_features == 256)
+                out = self._forward_merged(q, query_pos[:, 0], reference_points, tile_levels, out_half=half)
+                if half and out.dtype == torch.float16:
+                    idt2 = idt.reshape(-1, 256)
+                    inplace = kwargs.get('inplace_residual', False) is True
+                    t = ops.gemm_fp16_act(out.reshape(-1, 256), bricks._split_weight(self.output_proj.weight),
+                                          self.output_proj.bias, residual=idt2,
+                                          ln=(post_norm.weight, post_norm.bias, post_norm.eps),
+                                          out=idt2 if inplace else None)
+                    return seq_first_view(t.view(idt.shape))
                 out = linear_residual_norm(out, self.output_proj, idt, post_norm,
                                            inplace=kwargs.get('inplace_residual', False) is True)
                 return seq_first_view(out)

@@ -500,7 +500,8 @@ def gemm_bf16x3_encproj(a, w_planes, table, ref, levels_hw, value_bias=None, out
     return value, samp
 
 
-def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift=None, prepared=False):
+def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift=None, prepared=False,
+                         out_half=False):
     """Encoder deformable attention ([R2], T = 1) with LDS-staged value windows per image tile.
     value [F, S, 8, 32]; proj [F*S, >= 384]; ref [.., F*S, 4, 2] -> out [F*S, 256].
     Same results as ``deform_attn_grid_fused(..., T=1)``.  Differentiable (fused_autograd.py).
@@ -519,6 +520,8 @@ def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift
     if prepared:
         _require(variant == 0, 'deform_attn_enc_tile: prepared input with the default windows only')
         variant = 4
+    if out_half:     # fp16 output rows (fp16 operand mode: they only feed output_proj's MFMA)
+        variant |= 8
     if ref is not None or not prepared:
         _dev(ref, 'ref', f32)
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
@@ -534,7 +537,7 @@ def deform_attn_enc_tile(value, proj, ref, *, levels_hw, variant=0, window_shift
     if window_shift is not None:
         _require(len(window_shift) == 64, 'deform_attn_enc_tile: window_shift has 64 entries')
         sh_arr = (ctypes.c_int * 64)(*[int(v) for v in window_shift])
-    out = torch.empty((F_ * S, 256), dtype=f32, device=value.device)
+    out = torch.empty((F_ * S, 256), dtype=torch.float16 if out_half else f32, device=value.device)
     with torch.cuda.device(value.device), _Timed('enc_tile'):
         st = lib.pave_enc_deform_attn_tile_f32(
             value.data_ptr(), proj.data_ptr(), ref.data_ptr() if ref is not None else None,

@@ -135,7 +135,7 @@ def test_capi_argument_errors():
     assert lib.pave_merge_softmax_partials_f32(p, p, 2, 3, 250, 8, None) == -1
     # unsupported sampler variants are refused before anything is enqueued (advisor finding, round 4)
     hw = (ctypes.c_int * 8)(16, 24, 8, 12, 4, 6, 2, 3)
-    for variant in (5, 6, 8, -1):
+    for variant in (5, 6, 13, 16, -1):
         assert lib.pave_enc_deform_attn_tile_f32(p, p, None, p, 1, 510, ctypes.cast(hw, ctypes.c_void_p), 384,
                                                  variant, None, None) != 0
 

@@ -1303,9 +1303,32 @@ def test_fill_rows_sets_listed_rows_only():
     assert torch.equal(x, exp)
 
 
+def test_enc_tile_fp16_output_is_the_rounded_fp32_output():
+    """variant | 8: the sampler stores its rows as fp16 (fp16 operand mode: they only feed output_proj's MFMA) --
+    exactly the fp32 rows rounded to nearest even, prepared and un-prepared input, idle tile slots untouched."""
+    from pavenet_amd import ops
+    levels = [(20, 28), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in levels)
+    F_ = 2
+    g = torch.Generator(device='cuda').manual_seed(3)
+    value = torch.randn(F_, S, 8, 32, device='cuda', generator=g)
+    proj = torch.randn(F_ * S, 384, device='cuda', generator=g)
+    ref = torch.rand(1, F_ * S, 4, 2, device='cuda', generator=g)
+    a32 = ops.deform_attn_enc_tile(value, proj, ref, levels_hw=levels)
+    a16 = ops.deform_attn_enc_tile(value, proj, ref, levels_hw=levels, out_half=True)
+    assert a16.dtype == torch.float16 and torch.equal(a16, a32.half())
+    a = torch.randn(F_ * S, 256, device='cuda', generator=g)
+    wp = ops.split_weight_bf16x3(torch.randn(640, 256, device='cuda', generator=g) * 0.05)
+    table = torch.randn(S, 640, device='cuda', generator=g) * 0.1
+    v, samp = ops.gemm_bf16x3_encproj(a, wp, table, ref.view(-1, 4, 2), levels)
+    p32 = ops.deform_attn_enc_tile(v.view(F_, S, 8, 32), samp, None, levels_hw=levels, prepared=True)
+    p16 = ops.deform_attn_enc_tile(v.view(F_, S, 8, 32), samp, None, levels_hw=levels, prepared=True, out_half=True)
+    assert torch.equal(p16, p32.half())
+
+
 def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
     """pave_enc_deform_attn_tile_f32 called directly (ctypes): prepared input with the wide-window variant
-    (5: the non-prepared kernel would read the null `ref`), (6) and bits above the 3-bit mask must come back
+    (5: the non-prepared kernel would read the null `ref`), (6) and bits above the 4-bit mask must come back
     as an error with NOTHING enqueued -- `out` keeps its contents."""
     import ctypes
     from pavenet_amd import native
@@ -1316,7 +1339,7 @@ def test_enc_tile_c_abi_refuses_unsupported_variants_before_launching():
     proj = torch.rand(S, 384, device='cuda')
     out = torch.full((S, 256), 3.0, device='cuda')
     hw = (ctypes.c_int * 8)(*[v for l in levels for v in l])
-    for variant in (5, 6, 7, 8, 12, -1):
+    for variant in (5, 6, 7, 13, 16, 20, -1):
         st = lib.pave_enc_deform_attn_tile_f32(value.data_ptr(), proj.data_ptr(), None, out.data_ptr(), 1, S,
                                                ctypes.cast(hw, ctypes.c_void_p), 384, variant, None, None)
         assert st != 0, variant
