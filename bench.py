@@ -93,8 +93,9 @@ def parse():
                     help="vendor GEMM kernel per shape: 'tuned' = the shipped TunableOp selections "
                          "(pavenet_amd/data/tunableop_gfx950.csv, no tuning at run time), 'default' = "
                          "library heuristic, 'tune' = measure now and write gpurun_out/tunableop_gfx950.csv")
-    ap.add_argument('--backbone', choices=('r50', 'hrnet_w48'), default='r50',
-                    help="'hrnet_w48' = BASELINE configs[3] (HRNet-w48 backbone under the MulFrames head)")
+    ap.add_argument('--backbone', choices=('r50', 'hrnet_w48', 'swin_l'), default='r50',
+                    help="'hrnet_w48' = BASELINE configs[3] (HRNet-w48 backbone under the MulFrames head); 'swin_l' = "
+                         "the reference's 2025-2-7 Swin-L config (use --frames 3 --clips 1)")
     ap.add_argument('--gemm', choices=('native', 'bf16x3', 'bf16x2', 'bf16', 'fp16'), default='bf16x3',
                     help="dense projections / convolutions: 'bf16x3' (the headline) = hand-written "
                          "exact 3-term bf16 split on the bf16 MFMA: fp32 in, fp32 accumulate, "
@@ -472,6 +473,9 @@ def main():
     if args.backbone == 'hrnet_w48':
         from pavenet_amd.models import with_hrnet_w48
         mcfg = with_hrnet_w48(mcfg)
+    elif args.backbone == 'swin_l':
+        from pavenet_amd.models import with_swin_l
+        mcfg = with_swin_l(mcfg, num_frames=T)
     model = build_model(mcfg)
     init_random_weights(model, seed=0)
     model = model.to(dev).eval()
@@ -751,7 +755,7 @@ def main():
                            'bf16x2': 'bf16x2 operands, f32 accumulate', 'bf16': 'bf16 operands, f32 '
                            'accumulate', 'fp16': 'f16 operands, f32 accumulate'}[args.gemm],
                     data='synthetic',
-                    config=dict(workload=f'PAVE-Net {"R-50" if args.backbone == "r50" else "HRNet-w48"} T={T} frames, '
+                    config=dict(workload=f'PAVE-Net {dict(r50="R-50", hrnet_w48="HRNet-w48", swin_l="Swin-L")[args.backbone]} T={T} frames, '
                                          f'batch={B} clips{"" if frame_sharded else "/GPU"}, '
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
