@@ -94,8 +94,9 @@ def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
     from .bricks import _GEMM, fused_mode, get_gemm_mode
     mode_planes = lambda: 3     # noqa: E731  (per-frame branch MLPs on a few hundred query rows: always exact)
     dims = [l[0].weight.shape for l in lins]                      # [(out, in)] per layer
-    # (T Linears per launch: worth it from a few thousand frame-rows on; tests force min_rows = 1)
-    if (fused_mode() and R * T >= min(_GEMM['min_rows'], 4096) and rows.is_contiguous()
+    # (any number of rows: below a few thousand frame-rows -- a one-clip batch -- this used to fall to batched
+    # vendor GEMMs, the `Cijk_*` rows of a T = 3 one-clip step's trace)
+    if (fused_mode() and rows.is_contiguous()
             and dims[0][1] % 64 == 0 and (T * dims[0][0]) % 64 == 0
             and all(d[1] % 64 == 0 for d in dims[1:])      # split_weight_bf16x3 (un-padded): K % 64 == 0
             and all(d[0] % 64 == 0 for d in dims[1:-1]) and dims[-1][0] % 2 == 0):

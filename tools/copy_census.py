@@ -12,7 +12,7 @@ from pavenet_amd.bricks import set_gemm_mode  # noqa: E402
 from pavenet_amd.models import build_model, videopose_r50_cfg  # noqa: E402
 from pavenet_amd.weights import init_random_weights  # noqa: E402
 
-T, B = 7, 4
+T, B = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (7, 4)
 m = init_random_weights(build_model(videopose_r50_cfg(num_frames=T, max_per_img=20)), seed=0).cuda().eval()
 set_gemm_mode('bf16x3')
 img = torch.randn(B, T, 3, 800, 1344, device='cuda')
@@ -21,10 +21,14 @@ import traceback  # noqa: E402
 
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
+LIB = ('addmm', 'mm', 'bmm', 'baddbmm', 'linear', 'matmul', 'convolution', 'cudnn_convolution', 'miopen_convolution',
+       '_scaled_dot_product_flash_attention', '_scaled_dot_product_efficient_attention', 'native_layer_norm',
+       'native_group_norm', '_softmax', 'topk', 'sort')      # `python tools/copy_census.py lib T B`: library kernels
 WANT = ('copy_', 'clone', 'add', 'add_', 'relu', 'clamp_min', 'clamp_min_', 'cat', 'mul', 'sigmoid',
         '_to_copy', 'index', 'gather', 'expand_copy', 'repeat', 'stack')
 # `python tools/copy_census.py all`: every aten op that launches something (all but the view / metadata ops)
 ALL = len(sys.argv) > 1 and sys.argv[1] == 'all'
+LIBONLY = len(sys.argv) > 1 and sys.argv[1] == 'lib'
 VIEWS = ('view', 'reshape', '_unsafe_view', 'permute', 'expand', 'slice', 'select', 'as_strided', 'unsqueeze',
          'squeeze', 'transpose', 't', 'detach', 'alias', 'empty', 'empty_like', 'empty_strided', 'unflatten', 'flatten',
          'split', 'split_with_sizes', 'unbind', 'chunk', 'narrow', 'view_as', '_reshape_alias', 'lift_fresh', 'unfold',
@@ -36,7 +40,7 @@ cnt = collections.Counter()
 class Census(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.__name__.split('.')[0]
-        if (ALL and name not in VIEWS) or name in WANT:
+        if (ALL and name not in VIEWS) or (LIBONLY and name in LIB) or (not LIBONLY and name in WANT):
             fr = [f for f in traceback.extract_stack() if 'pavenet_amd/' in f.filename]
             if fr:
                 f = fr[-1]
