@@ -222,7 +222,7 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cfg = dict(num_frames=frames, num_keypoints=15, num_query=300, max_per_img=args.max_per_img)
     # torch's intra-op pool defaults to half the HOST's hardware threads (128 on a GPU box, which is a 16-CPU
-    # share of that host): the oracle then runs 2.8 x SLOWER than with 16 - 32 threads (tools/oracle_threads.py,
+    # share of that host): the oracle then runs 2.8 x SLOWER than with 16 - 32 threads (tests/oracle_threads.py,
     # profiles/r05_oracle_threads.txt), so the baseline is timed on the share it has
     default_threads = torch.get_num_threads()
     threads = max(1, min(default_threads, args.cpu_threads))

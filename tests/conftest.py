@@ -20,7 +20,7 @@ ORACLE_THREADS = 16   # a 1-GPU box is a 16-CPU share of a 256-thread host
 def _cpu_threads():
     """torch's intra-op pool defaults to half the HOST's hardware threads (128 on the GPU boxes, which are
     16-CPU shares of that host): the CPU oracle then runs 2.8 x slower than with 16 - 32 threads
-    (tools/oracle_threads.py, profiles/r05_oracle_threads.txt: one T = 3 clip 31.8 s at 128 threads, 11.5 s at
+    (tests/oracle_threads.py, profiles/r05_oracle_threads.txt: one T = 3 clip 31.8 s at 128 threads, 11.5 s at
     16 / 32) -- three full-size oracle runs were 4 of the GPU suite's 8.7 minutes."""
     import torch
     if torch.get_num_threads() > ORACLE_THREADS:

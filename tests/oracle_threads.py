@@ -1,11 +1,11 @@
 """How the CPU oracle scales with torch's intra-op thread count on the host (the GPU suite's full-size tests and
 bench.py's cpu_baseline leg spend their time in it): one frame through backbone + neck + one encoder pass.
-python tools/oracle_threads.py [threads ...]"""
+python tests/oracle_threads.py [threads ...]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (lives under tests/: the oracle is test infrastructure)
 import torch  # noqa: E402
 from oracle import pavenet_ref as R  # noqa: E402
 from pavenet_amd.models import build_model, videopose_r50_cfg  # noqa: E402
