@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 17
+#define PAVE_ABI_VERSION 18
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -197,6 +197,22 @@ int pave_pose_finalize_f32(const float* kpts, const float* sigmas, const float* 
  */
 int pave_ref_update_frames_f32(const float* y, const float* ref, float* out, int R, int T, int op, int o,
                                int G, float eps, void* stream);
+
+/*
+ * Two-stage query initialisation behind the proposal top-k (opera/models/utils/transformer.py:21386-21418), two
+ * launches for the reference's gather / repeat / strided add / sigmoid sequence:
+ *   pave_gather_rows_add_f32: rows[n, q, :] = src[n, index[n, q], :] (src [n, S, C] with a batch stride in elements,
+ *     index [n, Q] int64: `tgt`, the selected rows of output_memory) and, when sum != NULL,
+ *     sum[n, q, :] = rows[n, q, :] + add[q, :] (`query = tgt + query`; add [Q, C]).  C %% 4 == 0.
+ *   pave_proposal_refs_f32: kpt [n*Q, ld] (its first K2 = 2 K columns; in place) += props[n, index[n, q], c & 1]
+ *     (props [n, S, 2], batch stride in elements, 0 = one table for every clip; +inf marks an invalid proposal) and
+ *     refs [n, T*Q, K2] = sigmoid(kpt) repeated for the T frames (`topk_kpts_unact.sigmoid().repeat(1, T, 1)`).
+ * An index outside [0, S) is never dereferenced: the gathered row is zero, the proposal term is dropped.
+ */
+int pave_gather_rows_add_f32(const float* src, long long src_batch_stride, const long long* index, const float* add,
+                             float* rows, float* sum, int n, int Q, int S, int C, void* stream);
+int pave_proposal_refs_f32(float* kpt, int ld, const float* props, long long props_batch_stride,
+                           const long long* index, float* refs, int n, int Q, int S, int K2, int T, void* stream);
 
 /*
  * Greedy OKS-NMS, one launch for n_clips clips (replaces oks_nms / oks_iou,

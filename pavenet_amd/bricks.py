@@ -403,19 +403,26 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
     return (out, None) if pos_rows is not None else out
 
 
-def linear_norm(x, linear, norm):
-    """LayerNorm(Linear(x)) on [..., C] rows: ONE launch of the Linear + LayerNorm kernel in the
-    exact split mode (256-wide rows, device fp32, no grad), plain torch modules otherwise."""
-    x2 = x.reshape(-1, x.shape[-1])
-    if (_GEMM['ln_fused'] and _GEMM['mode'] in _QMODES and linear.out_features == 256
+def linear_norm_fused_ok(x2, linear, norm):
+    """linear_norm's one-launch form applies to these rows."""
+    return (_GEMM['ln_fused'] and _GEMM['mode'] in _QMODES and linear.out_features == 256
             and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (256,)
-            and norm.weight is not None and norm.bias is not None and x2.is_contiguous()
+            and norm.weight is not None and norm.bias is not None and x2.dim() == 2 and x2.is_contiguous()
             and not torch.is_grad_enabled() and linear.weight.shape[1] % 64 == 0
-            and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
+            and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight)))
+
+
+def linear_norm(x, linear, norm, out=None):
+    """LayerNorm(Linear(x)) on [..., C] rows: ONE launch of the Linear + LayerNorm kernel in the
+    exact split mode (256-wide rows, device fp32, no grad), plain torch modules otherwise.  out: a
+    [rows, 256] fp32 buffer for the one-launch form (callers check linear_norm_fused_ok first)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if linear_norm_fused_ok(x2, linear, norm):
         from . import ops
         t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight, x2.shape[0]), linear.bias, None, norm.weight,
-                               norm.bias, norm.eps)
+                               norm.bias, norm.eps, out=out)
         return t.view(*x.shape[:-1], 256)
+    assert out is None, 'linear_norm: out= only with the one-launch form'
     return norm(linear(x))
 
 

@@ -546,6 +546,92 @@ extern "C" int pave_ref_update_frames_f32(const float* y, const float* ref, floa
   return PAVE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Two-stage query initialisation behind the proposal top-k (opera/models/utils/transformer.py:21386-21418),
+// two launches instead of thirteen elementwise / gather launches:
+//
+// pave_gather_rows_add_f32:  rows[n, q, :] = src[n, index[n, q], :]  (the top-k rows of output_memory: `tgt`)
+//                            sum[n, q, :]  = rows[n, q, :] + add[q, :]  (`query = tgt + query`, optional)
+// pave_proposal_refs_f32:    kpt[n q, c] += props[n, index[n, q], c & 1]  (in place: the un-activated key points of
+//                            the selected tokens, x at even and y at odd columns, + their proposal's logit position)
+//                            refs[n, t Q + q, c] = sigmoid(kpt[n q, c])  for t = 0 .. T - 1  (`.sigmoid().repeat(1, T, 1)`)
+// An index outside [0, S) is never dereferenced (the row is zero-filled / the proposal term is dropped).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_add_kernel(const float* __restrict__ src,
+                                                              const long long src_batch,
+                                                              const long long* __restrict__ index,
+                                                              const float* __restrict__ add,
+                                                              float* __restrict__ rows, float* __restrict__ sum,
+                                                              const int n, const int Q, const int S, const int C4) {
+  const long long total = (long long)n * Q * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    const long long r = i / C4;
+    const int q = (int)(r % Q), b = (int)(r / Q);
+    const long long s = index[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0 && s < S) v = reinterpret_cast<const float4*>(src + (long long)b * src_batch + s * (C4 * 4ll))[c];
+    reinterpret_cast<float4*>(rows)[i] = v;
+    if (sum) {
+      const float4 a = reinterpret_cast<const float4*>(add)[(long long)q * C4 + c];
+      reinterpret_cast<float4*>(sum)[i] = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void proposal_refs_kernel(float* __restrict__ kpt, const int ld,
+                                                            const float* __restrict__ props,
+                                                            const long long props_batch,
+                                                            const long long* __restrict__ index,
+                                                            float* __restrict__ refs, const int n, const int Q,
+                                                            const int S, const int K2, const int T) {
+  const long long total = (long long)n * Q * K2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % K2);
+    const long long r = i / K2;
+    const int q = (int)(r % Q), b = (int)(r / Q);
+    const long long s = index[r];
+    float v = kpt[r * ld + c];
+    if (s >= 0 && s < S) v += props[(long long)b * props_batch + s * 2 + (c & 1)];
+    kpt[r * ld + c] = v;
+    const float sg = 1.f / (1.f + expf(-v));
+    for (int t = 0; t < T; ++t) refs[(((long long)b * T + t) * Q + q) * K2 + c] = sg;
+  }
+}
+}  // namespace
+
+extern "C" int pave_gather_rows_add_f32(const float* src, long long src_batch_stride, const long long* index,
+                                        const float* add, float* rows, float* sum, int n, int Q, int S, int C,
+                                        void* stream) {
+  if (!src || !index || !rows || (sum && !add))
+    return pave_internal_fail(PAVE_E_ARG, "gather_rows_add: null pointer (sum needs add)");
+  if (n <= 0 || Q <= 0 || S <= 0 || C <= 0 || C % 4 != 0 || src_batch_stride < 0 || src_batch_stride % 4 != 0)
+    return pave_internal_fail(PAVE_E_ARG, "gather_rows_add: n, Q, S > 0, C %% 4 == 0, batch stride %% 4 == 0");
+  const long long total = (long long)n * Q * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(gather_rows_add_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                     src_batch_stride, index, add, rows, sum, n, Q, S, C / 4);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+extern "C" int pave_proposal_refs_f32(float* kpt, int ld, const float* props, long long props_batch_stride,
+                                      const long long* index, float* refs, int n, int Q, int S, int K2, int T,
+                                      void* stream) {
+  if (!kpt || !props || !index || !refs) return pave_internal_fail(PAVE_E_ARG, "proposal_refs: null pointer");
+  if (n <= 0 || Q <= 0 || S <= 0 || K2 <= 0 || K2 % 2 != 0 || T <= 0 || ld < K2 || props_batch_stride < 0)
+    return pave_internal_fail(PAVE_E_ARG, "proposal_refs: n, Q, S, T > 0, K2 even, ld >= K2");
+  const long long total = (long long)n * Q * K2;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(proposal_refs_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), kpt, ld,
+                     props, props_batch_stride, index, refs, n, Q, S, K2, T);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
 // pave_merge_softmax_partials_f32
 // The frame-sharded T-frame attentions (BASELINE configs[4]: frame t on rank t % G) leave on every rank the
 // all-gathered [G, U, C + 2 H] buffer of per-rank partial rows (normalised by the rank's OWN sum) followed by the

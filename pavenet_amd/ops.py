@@ -1128,6 +1128,53 @@ def gather_frame_poses(poses, index, T):
     return out
 
 
+def gather_rows_add(src, index, add=None):
+    """src [n, S, C] fp32 (rows dense, any batch stride), index [n, Q] int64 -> rows [n, Q, C] = src[b, index[b, q]]
+    and, with add [Q, C], (rows, rows + add): the proposal top-k's `tgt` and `query = tgt + query`
+    (OT:21386, 21417) in one launch -- pave_gather_rows_add_f32."""
+    lib = native.load()
+    _require(src.is_cuda and src.dtype == torch.float32 and src.dim() == 3 and src.stride(2) == 1
+             and src.stride(1) == src.shape[2], 'gather_rows_add: src [n, S, C] fp32 on the device, dense rows')
+    _dev(index, 'index', torch.int64)
+    n, S, C = src.shape
+    _require(index.dim() == 2 and index.shape[0] == n, 'gather_rows_add: index [n, Q]')
+    Q = index.shape[1]
+    rows = torch.empty((n, Q, C), dtype=torch.float32, device=src.device)
+    total = None
+    if add is not None:
+        _dev(add, 'add', torch.float32)
+        _require(tuple(add.shape) == (Q, C), 'gather_rows_add: add [Q, C]')
+        total = torch.empty_like(rows)
+    with torch.cuda.device(src.device):
+        st = lib.pave_gather_rows_add_f32(src.data_ptr(), src.stride(0) if n > 1 else 0, index.data_ptr(),
+                                          add.data_ptr() if add is not None else None, rows.data_ptr(),
+                                          total.data_ptr() if total is not None else None, n, Q, S, C,
+                                          _stream_ptr())
+    native.check(st, 'gather_rows_add')
+    return rows if add is None else (rows, total)
+
+
+def proposal_refs_(kpt, props, index, T):
+    """kpt [n, Q, 2K] fp32 (unit column stride; a column slice of a padded matrix is fine), in place:
+    kpt[..., 0::2] += props[b, index, 0], kpt[..., 1::2] += props[b, index, 1] (props [n or 1, S, 2]); returns
+    refs [n, T*Q, 2K] = sigmoid(kpt) repeated for the T frames (OT:21390-21391, 21412) -- pave_proposal_refs_f32."""
+    lib = native.load()
+    _require(kpt.is_cuda and kpt.dtype == torch.float32 and kpt.dim() == 3 and kpt.stride(2) == 1
+             and kpt.stride(0) == kpt.shape[1] * kpt.stride(1), 'proposal_refs_: kpt [n, Q, 2K] fp32, rows evenly strided')
+    _dev(index, 'index', torch.int64)
+    n, Q, K2 = kpt.shape
+    _require(props.is_cuda and props.dtype == torch.float32 and props.dim() == 3 and props.shape[2] == 2
+             and props.shape[0] in (1, n) and props[0].is_contiguous(), 'proposal_refs_: props [n | 1, S, 2] fp32')
+    _require(tuple(index.shape) == (n, Q), 'proposal_refs_: index [n, Q]')
+    refs = torch.empty((n, int(T) * Q, K2), dtype=torch.float32, device=kpt.device)
+    with torch.cuda.device(kpt.device):
+        st = lib.pave_proposal_refs_f32(kpt.data_ptr(), kpt.stride(1), props.data_ptr(),
+                                        props.stride(0) if props.shape[0] > 1 else 0, index.data_ptr(),
+                                        refs.data_ptr(), n, Q, props.shape[1], K2, int(T), _stream_ptr())
+    native.check(st, 'proposal_refs_')
+    return refs
+
+
 def pose_finalize(kpts, sigmas, scores, wh, sf=None):
     """Post-processing of the refined poses (HEAD:1440-1490 + get_p) in one launch:
     kpts, sigmas [B, N, K, 2], scores [B, N], wh [B, 2] (image w, h), sf [B, 2] or None (rescale)

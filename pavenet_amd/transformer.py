@@ -454,6 +454,9 @@ class VideoPoseTransformerMulFrames(Transformer):
             cached = geom.unpadded.get(('proposals', N))
             if cached is not None:   # the grid depends on the level sizes only
                 output_proposals, valid = cached
+                filled = self._output_memory_filled(memory, valid, geom)
+                if filled is not None:
+                    return filled, output_proposals
                 output_memory = memory.masked_fill(~valid, float(0))
                 output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
                 return output_memory, output_proposals
@@ -490,6 +493,33 @@ class VideoPoseTransformerMulFrames(Transformer):
         output_memory = output_memory.masked_fill(~valid, float(0))
         output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
         return output_memory, output_proposals
+
+    def _output_memory_filled(self, memory, valid, geom):
+        """enc_output_norm(enc_output(memory.masked_fill(~valid, 0))) (OT:21206-21214) without the masked copy
+        of the memory: Linear + LayerNorm per clip straight from the (strided) centre-frame rows, then the rows of
+        the invalid proposals -- the level borders, ~5 % of the tokens -- overwritten with the value a zero row
+        gets (the same for all of them: LayerNorm(bias)), computed by the same kernel from a block of zero rows."""
+        from .bricks import linear_norm_fused_ok
+        N, S, C = memory.shape
+        lin, norm = self.enc_output, self.enc_output_norm
+        if not (memory.dtype == torch.float32 and memory.stride(2) == 1 and memory.stride(1) == C
+                and linear_norm_fused_ok(memory[0], lin, norm)):
+            return None
+        from . import ops
+        from .bricks import get_gemm_mode
+        key = SourceKey([lin.weight, lin.bias, norm.weight, norm.bias], extra=get_gemm_mode())
+        const = geom.unpadded.get(('proposal_fill', N))
+        if const is None or const[0] != key:
+            zrows = linear_norm(memory.new_zeros((max(S, 1), C)), lin, norm)   # (the same launch form as a clip)
+            rows = (~valid.reshape(N * S)).nonzero().flatten().to(torch.int32)
+            const = (key, zrows[0].clone(), rows)
+            geom.unpadded[('proposal_fill', N)] = const
+        out = torch.empty((N, S, norm.normalized_shape[0]), dtype=torch.float32, device=memory.device)
+        for b in range(N):
+            linear_norm(memory[b], lin, norm, out=out[b])
+        if const[2].numel():
+            ops.fill_rows_(out.view(N * S, -1), const[2], const[1])
+        return out
 
     @staticmethod
     def get_reference_points(spatial_shapes, valid_ratios, device):
@@ -652,13 +682,30 @@ class VideoPoseTransformerMulFrames(Transformer):
             # top-k rows afterwards (OT:21372-21389); the branches are row-wise, so gathering
             # first is identical and 74x less work (300 of 22 323 rows).  The all-token
             # outputs only feed training losses.
-            tgt = torch.gather(output_memory, 1,
-                               topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
-            top_props = torch.gather(output_proposals, 1,
-                                     topk_proposals.unsqueeze(-1).repeat(1, 1, 2))
+            query_pos, query = torch.split(query_embed, c, dim=1)
+            # device fast path: the gather / repeat / strided add / sigmoid / repeat sequence below as two
+            # launches (ops.gather_rows_add: `tgt` and `tgt + query`; ops.proposal_refs_: the in-place proposal
+            # offset and the T-fold reference points)
+            fused = (output_memory.is_cuda and output_memory.dtype == torch.float32 and frame_shard is None
+                     and not torch.is_grad_enabled() and output_memory.is_contiguous() and c % 4 == 0
+                     and output_proposals.is_contiguous())
+            fused_query = None
+            if fused:
+                from . import ops
+                topk_proposals = topk_proposals.contiguous()
+                tgt, fused_query = ops.gather_rows_add(output_memory, topk_proposals, query.contiguous())
+            else:
+                tgt = torch.gather(output_memory, 1,
+                                   topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
             topk_kpts_unact = mlp_rows(kpt_branches[self.decoder.num_layers], tgt)
-            topk_kpts_unact[..., 0::2] += top_props[..., 0:1]
-            topk_kpts_unact[..., 1::2] += top_props[..., 1:2]
+            fused_refs = None
+            if fused and topk_kpts_unact.stride(-1) == 1:
+                fused_refs = ops.proposal_refs_(topk_kpts_unact, output_proposals, topk_proposals, T)
+            else:
+                top_props = torch.gather(output_proposals, 1,
+                                         topk_proposals.unsqueeze(-1).repeat(1, 1, 2))
+                topk_kpts_unact[..., 0::2] += top_props[..., 0:1]
+                topk_kpts_unact[..., 1::2] += top_props[..., 1:2]
             enc_outputs_kpt_unact = topk_kpts_unact
             enc_outputs_sigma_unact = mlp_rows(sigma_branches[self.decoder.num_layers], tgt)
             if frame_shard is not None:
@@ -669,12 +716,12 @@ class VideoPoseTransformerMulFrames(Transformer):
                 enc_outputs_sigma_unact = enc_outputs_sigma_unact.contiguous()
                 for t_ in (tgt, topk_kpts_unact, enc_outputs_sigma_unact):
                     pdist.broadcast_from(t_, frame_shard.center_owner, frame_shard.group)
-            reference_points = topk_kpts_unact.sigmoid().repeat(1, T, 1)
+            reference_points = fused_refs if fused_refs is not None else \
+                topk_kpts_unact.sigmoid().repeat(1, T, 1)
             init_reference_out = reference_points
-            query_pos, query = torch.split(query_embed, c, dim=1)
             query_pos = query_pos.unsqueeze(0).expand(n_clips, -1, -1)
-            query = query.unsqueeze(0).expand(n_clips, -1, -1)
-            query = tgt + query
+            query = fused_query if fused_query is not None else \
+                tgt + query.unsqueeze(0).expand(n_clips, -1, -1)
         else:
             query_pos, query = torch.split(query_embed, c, dim=1)
             query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)

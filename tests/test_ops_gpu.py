@@ -1872,6 +1872,47 @@ def test_topk_rows_vs_torch(rows, n, k):
         topk_rows(xd, n + 1)
 
 
+@pytest.mark.parametrize('n,T', [(1, 3), (4, 7)])
+def test_proposal_query_kernels_vs_torch(n, T):
+    """The two launches behind the proposal top-k (OT:21386-21418) against the tensor expressions they replace:
+    tgt = gather(output_memory), query = tgt + query_embed, kpt[..., 0::2 / 1::2] += gathered proposal logits (with
+    +inf proposals), reference points = sigmoid(kpt) repeated for the T frames -- bit for bit; strided inputs (the
+    centre frames of a [n*T, S, C] memory, a 30-column slice of a 32-column matrix)."""
+    from pavenet_amd.ops import gather_rows_add, proposal_refs_
+    g = torch.Generator().manual_seed(11 + n)
+    S, C, Q, K2 = 997, 256, 300, 30
+    mem = torch.randn(n * T, S, C, generator=g).cuda()
+    src = mem[T // 2::T]                                         # [n, S, C], batch stride T S C
+    idx = torch.stack([torch.randperm(S, generator=g)[:Q] for _ in range(n)]).cuda()
+    add = torch.randn(Q, C, generator=g).cuda()
+    rows, total = gather_rows_add(src, idx, add)
+    exp = torch.gather(src, 1, idx.unsqueeze(-1).repeat(1, 1, C))
+    assert torch.equal(rows, exp) and torch.equal(total, exp + add.unsqueeze(0))
+    assert torch.equal(gather_rows_add(src, idx), exp)
+    for shared in (False, True):
+        props = torch.randn(1 if shared else n, S, 2, generator=g).cuda() * 3
+        props[:, ::13] = float('inf')                            # invalid proposals (OT:21204)
+        wide = torch.randn(n * Q, 32, generator=g).cuda()
+        keep = wide.clone()
+        kpt = wide[:, :K2].unflatten(0, (n, Q))
+        ref = kpt.clone()
+        tp = torch.gather(props.expand(n, -1, -1), 1, idx.unsqueeze(-1).repeat(1, 1, 2))
+        ref[..., 0::2] += tp[..., 0:1]
+        ref[..., 1::2] += tp[..., 1:2]
+        refs = proposal_refs_(kpt, props, idx, T)
+        assert torch.equal(kpt, ref) and torch.equal(wide[:, K2:], keep[:, K2:])
+        exp_refs = ref.sigmoid().repeat(1, T, 1)
+        assert refs.shape == (n, T * Q, K2)
+        np.testing.assert_allclose(refs.cpu().numpy(), exp_refs.cpu().numpy(), rtol=0, atol=1.2e-7)
+        assert torch.equal(refs[:, :Q], refs[:, (T - 1) * Q:])
+    bad = idx.clone()
+    bad[0, 0], bad[-1, -1] = -1, S                               # never dereferenced
+    rows = gather_rows_add(src, bad)
+    assert torch.equal(rows[0, 0], torch.zeros(C, device='cuda')) and torch.equal(rows[0, 1], exp[0, 1])
+    with pytest.raises(RuntimeError):
+        gather_rows_add(src.cpu(), idx.cpu())
+
+
 def test_gather_frame_poses_and_pose_finalize_vs_torch():
     """The selection gather (HEAD:1419-1427, 610) and the fused post-processing (HEAD:1440-1490,
     get_p) against the tensor expressions they replace."""

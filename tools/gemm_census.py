@@ -1,6 +1,6 @@
 """Per-shape census of the split-GEMM / convolution launches of one bench step (T = 7 x 4 clips,
 800x1344, --gemm bf16x3): HIP-event time, TFLOP/s and launch count per (entry point, M, K, N, form),
-in launch order.   python tools/gemm_census.py [steps=3] [diag variant]"""
+in launch order.   python tools/gemm_census.py [steps=3] [diag variant (0 = none)] [T=7] [clips=4] [r50 | hrnet_w48 | swin_l]"""
 import collections
 import os
 import sys
@@ -16,11 +16,20 @@ from pavenet_amd.weights import init_random_weights  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    if len(sys.argv) > 2:   # kernel-form override (pave_diag_gemm_variant), e.g. 8 = no wide tiles
+    if len(sys.argv) > 2 and int(sys.argv[2]):   # kernel-form override (pave_diag_gemm_variant), e.g. 8 = no wide tiles
         from pavenet_amd import native
         native.use_diag_build(int(sys.argv[2]))
     T, B, H, W = 7, 4, 800, 1344
-    m = build_model(videopose_r50_cfg(num_frames=T, max_per_img=20))
+    if len(sys.argv) > 4:
+        T, B = int(sys.argv[3]), int(sys.argv[4])
+    cfg = videopose_r50_cfg(num_frames=T, max_per_img=20)
+    if len(sys.argv) > 5 and sys.argv[5] == 'hrnet_w48':
+        from pavenet_amd.models import with_hrnet_w48
+        cfg = with_hrnet_w48(cfg)
+    elif len(sys.argv) > 5 and sys.argv[5] == 'swin_l':
+        from pavenet_amd.models import with_swin_l
+        cfg = with_swin_l(cfg, num_frames=T)
+    m = build_model(cfg)
     init_random_weights(m, seed=0)
     m = m.cuda().eval()
     set_gemm_mode('bf16x3')
