@@ -102,6 +102,9 @@ int pave_ms_deform_attn_forward_f64(const double* value, const int64_t* spatial_
  * POSE form ([R3]): L levels x P = K keypoints (K <= 24);
  *   ref [n_clips, T, Q, L, 2K] with n_units = n_clips*Q;  wh = clamp(max-min over K, 1e-4);
  *   loc = ref_k + off * wh * 0.5
+ * ref_levels = L, or 1: ref is [T, n_units, 1, 2] / [n_clips, T, Q, 1, 2K] and every level reads the same
+ *   row (un-padded batches: all valid ratios are 1, the reference broadcasts `reference_points[:, :, None]`
+ *   over the levels, OT:6712-6720 / MT:845-856 -- no materialised copy).
  */
 int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start, const float* proj,
@@ -109,14 +112,14 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
                                     int T, int S, int L, int P, int proj_stride,
-                                    const int32_t* frame_table, int n_slabs, void* stream);
+                                    const int32_t* frame_table, int n_slabs, int ref_levels, void* stream);
 
 int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start, const float* proj,
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
                                     int K, int proj_stride, const int32_t* frame_table, int n_slabs,
-                                    void* stream);
+                                    int ref_levels, void* stream);
 
 /*
  * The encoder layer's merged projection (value_proj | sampling_offsets | attention_weights as ONE
@@ -182,11 +185,13 @@ int pave_gather_frame_poses_f32(const float* poses, const long long* index, floa
  * min / max over the K key points, p = 0.7 (1 - exp(-0.2 / sigma_x)) (1 - exp(-0.2 / sigma_y)),
  * kpt <- kpt p^5 / (p^5 + 1e-10), key-point score = pose score * p.
  *   kpts, sigmas [B, N, K, 2]; scores [B, N]; wh, sf [B, 2] (sf only read when rescale != 0)
+ *   sigma_ld: floats between consecutive (x, y) rows of sigmas (2 = dense; 4 = the sigma branch's output as its
+ *   GEMM leaves it, padded to the 4-column grid)
  *   -> det_kpts [B, N, K, 3] (x, y, score), det_bboxes [B, N, 5] (x1, y1, x2, y2, score);  K <= 64
  */
 int pave_pose_finalize_f32(const float* kpts, const float* sigmas, const float* scores, const float* wh,
                            const float* sf, float* det_kpts, float* det_bboxes, int B, int N, int K,
-                           int rescale, void* stream);
+                           int rescale, int sigma_ld, void* stream);
 
 /*
  * Reference-point update of the decoders read straight from the grouped per-frame MLP output
@@ -369,8 +374,9 @@ int pave_bias_relu_maxpool_nhwc_f32(const float* x, const float* bias, float* y,
  *                with fp32 accumulation and fp32 in/out.
  *   out[M, N] = act(A'[M, K] * W[N, K]^T + bias[N] + residual[M, N]),
  *   A' = a_bias ? relu(a + a_bias[K]) : a;  act: relu = 0 none | 1 ReLU | 2 exact GELU x Phi(x) (nn.GELU, the
- *   activation of the Swin block's FFN, third_party/mmdetection/mmdet/models/backbones/swin.py:330-341;
- *   3 planes / fp16 only)
+ *   activation of the Swin block's FFN, third_party/mmdetection/mmdet/models/backbones/swin.py:330-341) |
+ *   3 sigmoid 1 / (1 + exp(-x)) (the heads' sigma branches, videopose_head_mul_frames.py:533, 652);  2 and 3:
+ *   3 planes / fp16 only
  * = nn.Linear (mmcv FFN / projections, bricks/transformer.py:1046-1120) with the residual and
  * activation of its caller in the epilogue.  `w_planes` = the weight [N, K] split once by
  * pave_split_bf16x3_f32 into `nplanes` bf16 planes and re-laid slab-major [K/16][nplanes][N][16]

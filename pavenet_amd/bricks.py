@@ -286,27 +286,33 @@ def small_split_ok(x2, weight):
             and not torch.is_grad_enabled())
 
 
-def mlp_rows(module, x):
+def mlp_rows(module, x, act=None):
     """A branch of the heads on [..., K] rows: nn.Linear, heads.Linear_with_norm(norm=False) or an
     nn.Sequential of those and nn.ReLU, every Linear through linear_rows (ReLU in its epilogue)
     -- on the device in the exact split mode these are launches of this package's GEMM; anything
-    else (other layer types, training) is the module's own forward."""
+    else (other layer types, training) is the module's own forward.  act='sigmoid': the caller's
+    `.sigmoid()` of the branch output, in the last Linear's epilogue where that is a kernel of ours."""
+    assert act in (None, 'sigmoid')
+    post = (lambda t: t.sigmoid()) if act else (lambda t: t)
     if not (x.is_cuda and x.dtype == torch.float32 and _GEMM['mode'] in _QMODES
             and not torch.is_grad_enabled()):
-        return module(x)
+        return post(module(x))
     layers = list(module) if isinstance(module, nn.Sequential) else [module]
     plan = []
     for i, m in enumerate(layers):
         if isinstance(m, nn.ReLU):
             if not plan or plan[-1][2]:
-                return module(x)
+                return post(module(x))
             plan[-1][2] = True
             continue
         lin = m if isinstance(m, nn.Linear) else getattr(m, 'linear', None)
         if not isinstance(lin, nn.Linear) or (lin is not m and getattr(m, 'norm', True)):
-            return module(x)
+            return post(module(x))
         use_bias = lin.bias is not None and (lin is m or bool(getattr(m, 'bias', True)))
         plan.append([lin.weight, lin.bias if use_bias else None, False])
+    if act and plan and not plan[-1][2]:
+        plan[-1][2] = act
+        post = lambda t: t    # noqa: E731
     rows = x.reshape(-1, x.shape[-1])
     if not rows.is_contiguous():
         rows = rows.contiguous()
@@ -316,7 +322,7 @@ def mlp_rows(module, x):
             rows = rows.contiguous()
     # (an output width off the 4-column grid comes back as a column slice of a padded matrix: kept
     # as a strided view, the consumers are elementwise)
-    return rows.unflatten(0, tuple(x.shape[:-1]))
+    return post(rows.unflatten(0, tuple(x.shape[:-1])))
 
 
 def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residual=False,
@@ -346,6 +352,9 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
             b4 = None if bias is None else _split_cached(
                 bias, 'bias_pad4', lambda planes: F.pad(bias.detach(), (0, N4 - N)).contiguous())
             return ops.gemm_bf16x3(x2, wp, b4, None, relu=relu, n_out=N4)[:, :N]
+    if isinstance(relu, str):     # 'gelu' / 'sigmoid' outside the split kernels: the plain torch expression
+        t = linear_rows(x2, weight, bias, False, residual, inplace_residual, a_bias, exact)
+        return F.gelu(t) if relu == 'gelu' else torch.sigmoid(t)
     if a_bias is not None:
         x2 = torch.relu(x2 + a_bias)
     if residual is not None:

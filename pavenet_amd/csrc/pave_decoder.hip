@@ -438,14 +438,16 @@ __global__ __launch_bounds__(64) void pose_finalize_kernel(const float* __restri
                                                            const float* __restrict__ scores,
                                                            const float* __restrict__ wh,
                                                            const float* __restrict__ sf, float* det_kpts,
-                                                           float* det_bboxes, int N, int K, int rescale) {
+                                                           float* det_bboxes, int N, int K, int rescale,
+                                                           int sigma_ld) {
   const int pose = blockIdx.x, b = pose / N, j = threadIdx.x;
   const bool act = j < K;
   const float w = wh[b * 2], h = wh[b * 2 + 1];
   float x = 0.f, y = 0.f, sx = 1.f, sy = 1.f;
   if (act) {
     const float2 kp = *reinterpret_cast<const float2*>(kpts + ((size_t)pose * K + j) * 2);
-    const float2 sg = *reinterpret_cast<const float2*>(sigmas + ((size_t)pose * K + j) * 2);
+    const float* sp = sigmas + ((size_t)pose * K + j) * sigma_ld;   // (sigma_ld = 2: dense rows)
+    const float2 sg = make_float2(sp[0], sp[1]);
     x = fminf(fmaxf(kp.x * w, 0.f), w);
     y = fminf(fmaxf(kp.y * h, 0.f), h);
     if (rescale) x = x / sf[b * 2], y = y / sf[b * 2 + 1];
@@ -492,14 +494,15 @@ extern "C" int pave_gather_frame_poses_f32(const float* poses, const long long* 
 
 extern "C" int pave_pose_finalize_f32(const float* kpts, const float* sigmas, const float* scores,
                                       const float* wh, const float* sf, float* det_kpts,
-                                      float* det_bboxes, int B, int N, int K, int rescale, void* stream) {
+                                      float* det_bboxes, int B, int N, int K, int rescale, int sigma_ld,
+                                      void* stream) {
   if (!kpts || !sigmas || !scores || !wh || !det_kpts || !det_bboxes || (rescale && !sf))
     return pave_internal_fail(PAVE_E_ARG, "pose_finalize: null pointer");
-  if (B <= 0 || N <= 0 || K <= 0 || K > 64)
-    return pave_internal_fail(PAVE_E_ARG, "pose_finalize: B, N > 0 and 0 < K <= 64");
+  if (B <= 0 || N <= 0 || K <= 0 || K > 64 || sigma_ld < 2)
+    return pave_internal_fail(PAVE_E_ARG, "pose_finalize: B, N > 0, 0 < K <= 64, sigma_ld >= 2");
   hipLaunchKernelGGL(pose_finalize_kernel, dim3((unsigned)(B * N)), dim3(64), 0,
                      reinterpret_cast<hipStream_t>(stream), kpts, sigmas, scores, wh, sf, det_kpts,
-                     det_bboxes, N, K, rescale);
+                     det_bboxes, N, K, rescale, sigma_ld);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

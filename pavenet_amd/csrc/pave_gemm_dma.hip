@@ -153,6 +153,8 @@ __device__ __forceinline__ float half32_sum(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// torch.sigmoid's expression (ATen: 1 / (1 + exp(-x))), as the reference-point kernels use it
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 // max(x, 0) as the single v_max_f32 fmaxf ends in (the compiler puts a canonicalising v_max in front of it)
 __device__ __forceinline__ float relu_max(float x) {
@@ -876,6 +878,12 @@ __device__ __forceinline__ void gemm_q_body(
             for (int ps = 0; ps < NPS; ++ps)
               v[ps].x = gelu_erf(v[ps].x), v[ps].y = gelu_erf(v[ps].y), v[ps].z = gelu_erf(v[ps].z),
               v[ps].w = gelu_erf(v[ps].w);
+          } else if (relu == 3) {     // sigmoid (the heads' sigma branches)
+            asm volatile("" ::);
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps)
+              v[ps].x = sigmoid_f(v[ps].x), v[ps].y = sigmoid_f(v[ps].y), v[ps].z = sigmoid_f(v[ps].z),
+              v[ps].w = sigmoid_f(v[ps].w);
           }
 #pragma unroll
           for (int ps = 0; ps < NPS; ++ps) {
@@ -1497,6 +1505,7 @@ __global__ __launch_bounds__(256) void gemm_s_kernel(
         }
         if (relu == 1) v = fmaxf(v, 0.f);
         else if (relu == 2) v = gelu_erf(v);
+        else if (relu == 3) v = sigmoid_f(v);
         out[(long long)row * n_real + col] = v;
       }
     }
@@ -1593,7 +1602,8 @@ static int gemm_q_dispatch(const float* a, const float* a_bias, const void* w_pl
                            int ksplit, int ks_slabs) {
   const QConv g{H, W, Cin, Ho, Wo, stride,
                 (kind == 1 && Cin > 16) ? (unsigned)(((1ull << 32) + (Cin >> 4) - 1) / (unsigned)(Cin >> 4)) : 0u};
-  if (relu < 0 || relu > 2) return pave_internal_fail(PAVE_E_ARG, "gemm_q: activation 0 (none), 1 (ReLU) or 2 (GELU)");
+  if (relu < 0 || relu > 3)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_q: activation 0 (none), 1 (ReLU), 2 (GELU) or 3 (sigmoid)");
   const bool narrow = N < 0;   // (grouped rows with 64-column groups: 64-wide tiles)
   if (narrow) N = -N;
   if (n_real <= 0) n_real = N;

@@ -668,8 +668,8 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
                             const float* bias, const float* residual, float* out, long long M,
                             int K, int N, int relu, int nplanes, void* stream, OutSplit os) {
   if (!a || !w_planes || !out) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: null pointer");
-  if (relu < 0 || relu > 2 || (relu == 2 && (!q_planes(nplanes) || g_diag_variant == 9)))
-    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: relu = 0 | 1 | 2 (2 = exact GELU: 3 planes / fp16 only)");
+  if (relu < 0 || relu > 3 || (relu >= 2 && (!q_planes(nplanes) || g_diag_variant == 9)))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: relu = 0 | 1 | 2 | 3 (2 = exact GELU, 3 = sigmoid: 3 planes / fp16 only)");
   if (M <= 0 || K <= 0 || N <= 0 || M >= (1ll << 31))
     return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3: bad sizes (0 < M < 2^31)");
   // 3 planes (the exact split): the LDS-DMA generation (pave_gemm_dma.hip) takes K %% 32 == 0 and any

@@ -238,6 +238,7 @@ struct FusedParams {
   int S;
   int L;
   int P;  // points per level (GRID: 4; POSE: K)
+  int ref_L;  // level rows behind every reference entry: L, or 1 = one row shared by the L levels
   int n_slabs;  // frame slabs behind `value`: every slab index is clamped into [0, n_slabs)
   int proj_stride;
   int n_blocks_logical;
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParam
       // ref [n_clips, T, Q, L, 2K]; unit = clip*Q + q
       const int q = unit - clip * p.units_per_clip;
       const float* rp =
-          p.ref + ((((long long)clip * T + t) * p.units_per_clip + q) * L + lvl) * (2 * P);
+          p.ref + ((((long long)clip * T + t) * p.units_per_clip + q) * p.ref_L + (p.ref_L == 1 ? 0 : lvl)) * (2 * P);
       float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
 #pragma unroll
       for (int s = 0; s < PPL; ++s) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void fused_deform_attn_kernel(const FusedParam
         if (MODE == kGrid) {
           // ref [T, n_units, L, 2]
           const float2 r = *reinterpret_cast<const float2*>(
-              p.ref + (((long long)t * p.n_units + unit) * L + l) * 2);
+              p.ref + (((long long)t * p.n_units + unit) * p.ref_L + (p.ref_L == 1 ? 0 : l)) * 2);
           lx = r.x + o.x / (float)W;
           ly = r.y + o.y / (float)H;
         } else {
@@ -789,7 +790,8 @@ __global__ __launch_bounds__(256) void enc_head_major_kernel(const FusedParams p
     const int ii = pts_ok ? i0 : 0;
     q.lg = *reinterpret_cast<const float2*>(row + kHeads * LP * 2 + head * LP + ii);
     q.of = *reinterpret_cast<const float4*>(row + head * LP * 2 + 2 * ii);
-    q.rf = *reinterpret_cast<const float2*>(p.ref + ((long long)unit * L + (pts_ok ? lvl : 0)) * 2);
+    q.rf = *reinterpret_cast<const float2*>(
+        p.ref + ((long long)unit * p.ref_L + ((pts_ok && p.ref_L != 1) ? lvl : 0)) * 2);
     return q;
   };
   int unit = unit_of(0);
@@ -1580,9 +1582,11 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
                                     const int32_t* order, float* out, float* stat_max,
                                     float* stat_sum, int n_units, int units_per_clip, int n_clips,
                                     int T, int S, int L, int P, int proj_stride,
-                                    const int32_t* frame_table, int n_slabs, void* stream) {
+                                    const int32_t* frame_table, int n_slabs, int ref_levels, void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_grid_fused: null pointer");
+  if (ref_levels != L && ref_levels != 1)
+    return fail(PAVE_E_ARG, "deform_attn_grid_fused: ref_levels = L (a row per level) or 1 (one row for all levels)");
   if (frame_table ? n_slabs <= 0 : (n_slabs != 0 && n_slabs != n_clips * T))
     return fail(PAVE_E_ARG, "deform_attn_grid_fused: n_slabs = the frame slabs behind value (> 0 with a frame table; "
                             "0 or n_clips * T without)");
@@ -1617,6 +1621,7 @@ int pave_deform_attn_grid_fused_f32(const float* value, const int64_t* spatial_s
   p.S = S;
   p.L = L;
   p.P = P;
+  p.ref_L = ref_levels;
   p.proj_stride = proj_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (T == 1 && P == 4 && L <= 4) {
@@ -1635,9 +1640,11 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
                                     const float* ref, float* out, float* stat_max,
                                     float* stat_sum, int n_clips, int Q, int T, int S, int L,
                                     int K, int proj_stride, const int32_t* frame_table, int n_slabs,
-                                    void* stream) {
+                                    int ref_levels, void* stream) {
   if (!value || !spatial_shapes || !level_start || !proj || !ref || !out)
     return fail(PAVE_E_ARG, "deform_attn_pose_fused: null pointer");
+  if (ref_levels != L && ref_levels != 1)
+    return fail(PAVE_E_ARG, "deform_attn_pose_fused: ref_levels = L (a row per level) or 1 (one row for all levels)");
   if (frame_table ? n_slabs <= 0 : (n_slabs != 0 && n_slabs != n_clips * T))
     return fail(PAVE_E_ARG, "deform_attn_pose_fused: n_slabs = the frame slabs behind value (> 0 with a frame table; "
                             "0 or n_clips * T without)");
@@ -1670,6 +1677,7 @@ int pave_deform_attn_pose_fused_f32(const float* value, const int64_t* spatial_s
   p.S = S;
   p.L = L;
   p.P = K;
+  p.ref_L = ref_levels;
   p.proj_stride = proj_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (K <= 16) return launch_fused<kPose, 2, 4>(p, st);

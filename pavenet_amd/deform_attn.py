@@ -534,8 +534,8 @@ class MulFramesMultiScaleDeformablePoseAttention(BaseModule, _CatProj):
         w, b = self._cat_proj()
         proj = linear_rows(q.reshape(bs * num_query, self.embed_dims), w, b)
         if _fused_ok(self, q, v) and L <= 4 and K <= 24:
-            ref = reference_points if reference_points.is_contiguous() \
-                else reference_points.contiguous()
+            # (inference: a level axis that is a broadcast is passed as such, ops._level_rows)
+            ref = reference_points.contiguous() if torch.is_grad_enabled() else reference_points
             stats = kwargs.get('return_softmax_stats', False)
             res = ops.deform_attn_pose_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
@@ -790,7 +790,7 @@ class MulFramesMultiScaleDeformableAttention(BaseModule, _CatProj):
             unit_clip = hit[1]
             out = ops.deform_attn_grid_fused(
                 v if v.is_contiguous() else v.contiguous(), spatial_shapes, level_start_index,
-                proj, ref if ref.is_contiguous() else ref.contiguous(), T=T, n_clips=n_clips,
+                proj, ref.contiguous() if torch.is_grad_enabled() else ref, T=T, n_clips=n_clips,
                 units_per_clip=num_query, unit_clip=unit_clip, frame_table=table)
             out = out.view(N, num_query, self.embed_dims)
         else:

@@ -320,7 +320,7 @@ class VideoPoseHeadMulFrames(BaseModule):
                 outputs_kpt = _ref_update(mlp_rows(self.kpt_branches[lvl], hs[lvl]),
                                           reference[:, c * Q:(c + 1) * Q])
             outputs_class = mlp_rows(self.cls_branches[lvl], hs[lvl])
-            output_sigma = mlp_rows(self.dec_fc_sigma_branches[lvl], hs[lvl]).sigmoid()
+            output_sigma = mlp_rows(self.dec_fc_sigma_branches[lvl], hs[lvl], act='sigmoid')
             outputs_classes.append(outputs_class)
             outputs_kpts.append(outputs_kpt)
             output_sigmas.append(output_sigma)
@@ -365,17 +365,20 @@ class VideoPoseHeadMulFrames(BaseModule):
         # (only the last refine level is read outside training, HEAD:1430-1438: one-level stacks)
         n_lvl = hs.shape[0]
         only_last = self.eval_last_level_only if last_level_only is None else bool(last_level_only)
-        levels = [n_lvl - 1] if (only_last and not self.training) else range(n_lvl)
+        lazy = only_last and not self.training
+        levels = [n_lvl - 1] if lazy else range(n_lvl)
         for lvl in levels:
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             n = reference.shape[0] // T
-            tmp_kpt = mlp_rows(self.refine_kpt_branches[lvl], hs[lvl])
-            tmp_sigma = mlp_rows(self.refine_fc_sigma_branches[lvl], hs[lvl]).sigmoid()
-            outs_score.append(torch.mean(1 - tmp_sigma, dim=2, keepdim=True))
+            h = hs[lvl] if hs[lvl].is_contiguous() else hs[lvl].contiguous()   # (one layout copy for both branches)
+            tmp_kpt = mlp_rows(self.refine_kpt_branches[lvl], h)
+            tmp_sigma = mlp_rows(self.refine_fc_sigma_branches[lvl], h, act='sigmoid')
+            if not lazy:    # (the refine score only feeds the training loss, HEAD:640-674: get_bboxes never reads it)
+                outs_score.append(torch.mean(1 - tmp_sigma, dim=2, keepdim=True))
             outs_kpt.append(_ref_update(tmp_kpt, reference[c * n:(c + 1) * n]))
             outs_sigma.append(tmp_sigma)
         stack = (lambda ts: ts[0].unsqueeze(0)) if len(outs_kpt) == 1 else torch.stack
-        return stack(outs_kpt), stack(outs_score), stack(outs_sigma), hs
+        return stack(outs_kpt), (None if lazy else stack(outs_score)), stack(outs_sigma), hs
 
     @staticmethod
     def get_p(output_regression_sigma, p_x=0.2):
@@ -473,7 +476,10 @@ class VideoPoseHeadMulFrames(BaseModule):
                         refine_sigma=det_sigmas)
         dev = det_kpts.device
         wh, sf = self._meta_scales(img_metas, dev)
-        if fused and K <= 64 and det_kpts.is_contiguous() and det_sigmas.is_contiguous():
+        # (det_sigmas may be the 2-column slice of the sigma branch's padded GEMM output: evenly strided rows)
+        sig_rows = det_sigmas.stride(3) == 1 and det_sigmas.stride(1) == K * det_sigmas.stride(2) \
+            and det_sigmas.stride(0) == N * det_sigmas.stride(1)
+        if fused and K <= 64 and det_kpts.is_contiguous() and sig_rows:
             # pixels / clamp / rescale / box / RLE confidence / key-point scores: one launch
             scores = scores.contiguous()
             det_kpts, det_bboxes = ops.pose_finalize(det_kpts, det_sigmas, scores, wh.view(B, 2),

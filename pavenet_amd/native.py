@@ -19,8 +19,8 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     'pave_ms_deform_attn_forward_f32': [_vp] * 6 + [_c_int] * 8 + [_vp],
     'pave_ms_deform_attn_forward_f64': [_vp] * 6 + [_c_int] * 8 + [_vp],
-    'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp, _c_int, _vp],
-    'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp, _c_int, _vp],
+    'pave_deform_attn_grid_fused_f32': [_vp] * 10 + [_c_int] * 8 + [_vp, _c_int, _c_int, _vp],
+    'pave_deform_attn_pose_fused_f32': [_vp] * 8 + [_c_int] * 7 + [_vp, _c_int, _c_int, _vp],
     'pave_fuse_sum_nhwc_f32': [_vp, _c_int] * 4 + [_vp] + [_c_int] * 5 + [_vp],
     'pave_bias_act_rows_f32': [_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_fill_rows_f32': [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _c_int, _vp],
@@ -59,7 +59,7 @@ SIGNATURES = {
     'pave_mha_core_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_topk_rows_f32': [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
     'pave_gather_frame_poses_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [_vp],
-    'pave_pose_finalize_f32': [_vp] * 7 + [_c_int] * 4 + [_vp],
+    'pave_pose_finalize_f32': [_vp] * 7 + [_c_int] * 5 + [_vp],
     'pave_ref_update_frames_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [ctypes.c_float, _vp],
     'pave_swin_window_attn_f32': [_vp] * 4 + [_c_int] * 7 + [ctypes.c_float, _vp],
     'pave_merge_softmax_partials_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],

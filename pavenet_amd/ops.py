@@ -195,6 +195,19 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
         return grad_value, None, None, grad_loc, grad_aw, None
 
 
+def _level_rows(ref, L, name):
+    """(dense tensor, ref_levels) of a reference tensor [.., L, c]: a level axis that is a broadcast
+    (`reference_points[:, :, None].expand(..)`, stride 0: un-padded batches) is passed as ONE row per entry
+    (ref_levels = 1, no materialised copy); anything else must be dense with L rows."""
+    if ref.dim() >= 2 and ref.shape[-2] == L and L > 1 and ref.stride(-2) == 0:
+        base = ref.select(-2, 0)
+        if base.is_contiguous():
+            return base, 1
+        ref = ref.contiguous()
+    _dev(ref, name, torch.float32)
+    return ref, L
+
+
 def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, *, T,
                            n_clips, units_per_clip, unit_clip=None, order=None,
                            return_stats=False, frame_table=None):
@@ -216,7 +229,7 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _dev(spatial_shapes, 'spatial_shapes', torch.int64)
     _dev(level_start_index, 'level_start_index', torch.int64)
     _dev(proj, 'proj', f32)
-    _dev(ref, 'ref', f32)
+    _require(ref.is_cuda and ref.dtype == f32, 'deform_attn_grid_fused: ref fp32 on the device')
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_grid_fused: value must be [frames, S, 8, 32]')
     if frame_table is not None:   # value = per-frame cache, slab of (clip, t) = frame_table[clip*T + t]
@@ -232,6 +245,7 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
     n_units = proj.shape[0]
     _require(tuple(ref.shape) == (T, n_units, L, 2),
              f'deform_attn_grid_fused: ref must be [T, n_units, L, 2], got {tuple(ref.shape)}')
+    ref, ref_levels = _level_rows(ref, L, 'ref')
     if unit_clip is not None:
         _dev(unit_clip, 'unit_clip', torch.int32)
         _require(unit_clip.numel() == n_units, 'deform_attn_grid_fused: unit_clip length')
@@ -253,7 +267,8 @@ def deform_attn_grid_fused(value, spatial_shapes, level_start_index, proj, ref, 
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, n_units, int(units_per_clip),
             int(n_clips), int(T), S, L, 4, proj.stride(0),
-            frame_table.data_ptr() if frame_table is not None else None, int(value.shape[0]), _stream_ptr())
+            frame_table.data_ptr() if frame_table is not None else None, int(value.shape[0]), ref_levels,
+            _stream_ptr())
     native.check(st, 'deform_attn_grid_fused')
     if return_stats:
         return out, smax, ssum
@@ -280,7 +295,7 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     _dev(spatial_shapes, 'spatial_shapes', torch.int64)
     _dev(level_start_index, 'level_start_index', torch.int64)
     _dev(proj, 'proj', f32)
-    _dev(ref, 'ref', f32)
+    _require(ref.is_cuda and ref.dtype == f32, 'deform_attn_pose_fused: ref fp32 on the device')
     _require(value.dim() == 4 and value.shape[2] == 8 and value.shape[3] == 32,
              'deform_attn_pose_fused: value must be [frames, S, 8, 32]')
     if frame_table is not None:
@@ -293,8 +308,9 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
     Q, K = int(num_query), int(num_keypoints)
     _require(proj.dim() == 2 and proj.shape[0] == n_clips * Q,
              'deform_attn_pose_fused: proj must be [n_clips*Q, cols]')
-    _require(ref.numel() == n_clips * T * Q * L * 2 * K,
+    _require(ref.numel() == n_clips * T * Q * L * 2 * K and ref.shape[-2:] == (L, 2 * K),
              'deform_attn_pose_fused: ref must be [n_clips, T*Q, L, 2K]')
+    ref, ref_levels = _level_rows(ref, L, 'ref')
     out = torch.empty((n_clips * Q, 256), dtype=f32, device=value.device)
     smax = ssum = None
     if return_stats:
@@ -307,7 +323,7 @@ def deform_attn_pose_fused(value, spatial_shapes, level_start_index, proj, ref, 
             smax.data_ptr() if return_stats else None,
             ssum.data_ptr() if return_stats else None, int(n_clips), Q, int(T), S, L, K,
             proj.stride(0), frame_table.data_ptr() if frame_table is not None else None,
-            int(value.shape[0]), _stream_ptr())
+            int(value.shape[0]), ref_levels, _stream_ptr())
     native.check(st, 'deform_attn_pose_fused')
     if return_stats:
         return out, smax, ssum
@@ -660,11 +676,14 @@ def split_weight_bf16x3(weight, planes=3, pad=False):
     return pl.view(pl.shape[0], N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
 
 
+_ACT_CODE = {'gelu': 2, 'sigmoid': 3}     # pave_gemm_bf16x3_f32's `relu` argument beyond 0 / 1
+
+
 def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None,
                 fp16=False, n_out=None):
     """out[M, N] = act(A' @ W^T + bias + residual), A' = relu(a + a_bias) if a_bias is given, on
     the bf16 matrix cores with both operands split into P = w_planes.shape[1] bf16 terms
-    (relu: False | True | 'gelu' = exact GELU, 3 planes / fp16 only)
+    (relu: False | True | 'gelu' = exact GELU | 'sigmoid'; the last two: 3 planes / fp16 only)
     (P = 3: exact split, 6 MFMA products, fp32-level accuracy;  2: 3 products, ~2^-16;
     1: plain bf16 operands, or fp16 operands with fp16=True and a PLANES_FP16 weight), fp32
     accumulate, fp32 in / out.
@@ -701,7 +720,7 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N,
-                                      2 if relu == 'gelu' else int(bool(relu)), npl, _stream_ptr())
+                                      _ACT_CODE.get(relu, int(bool(relu))), npl, _stream_ptr())
     native.check(st, 'gemm_bf16x3')
     return out
 
@@ -861,6 +880,18 @@ def ref_update(tmp, ref, eps=1e-5):
     lib = native.load()
     _require(tmp.is_cuda and tmp.dtype == torch.float32 and ref.dtype == torch.float32
              and tuple(tmp.shape) == tuple(ref.shape), 'ref_update: fp32 device tensors, same shape')
+    if (tmp.dim() >= 2 and not tmp.is_contiguous() and tmp.stride(-1) == 1 and ref.is_contiguous()
+            and tmp.numel() > 0 and tmp.stride(-2) >= tmp.shape[-1]
+            and all(tmp.stride(i) == tmp.stride(i + 1) * tmp.shape[i + 1] for i in range(tmp.dim() - 2))):
+        # a column slice of a wider matrix (a branch output padded to the 4-column grid): read in place
+        # by the strided form of the same kernel (T = 1: rows [R, ld], the first o columns)
+        R, o = tmp.numel() // tmp.shape[-1], tmp.shape[-1]
+        out = torch.empty_like(ref)
+        with torch.cuda.device(tmp.device), _Timed('ref_update'):
+            st = lib.pave_ref_update_frames_f32(tmp.data_ptr(), ref.data_ptr(), out.data_ptr(), R, 1,
+                                                tmp.stride(-2), o, R, float(eps), _stream_ptr())
+        native.check(st, 'ref_update')
+        return out
     tmp, ref = tmp.contiguous(), ref.contiguous()
     out = torch.empty_like(tmp)
     if tmp.numel() == 0:
@@ -1180,8 +1211,14 @@ def pose_finalize(kpts, sigmas, scores, wh, sf=None):
     kpts, sigmas [B, N, K, 2], scores [B, N], wh [B, 2] (image w, h), sf [B, 2] or None (rescale)
     -> (det_kpts [B, N, K, 3], det_bboxes [B, N, 5])."""
     lib = native.load()
-    for t, nm in ((kpts, 'kpts'), (sigmas, 'sigmas'), (scores, 'scores'), (wh, 'wh')):
+    for t, nm in ((kpts, 'kpts'), (scores, 'scores'), (wh, 'wh')):
         _dev(t, nm, torch.float32)
+    # sigmas: dense, or evenly strided (x, y) rows -- a 2-column slice of the sigma branch's padded output
+    _require(sigmas.is_cuda and sigmas.dtype == torch.float32 and sigmas.dim() == 4 and sigmas.stride(3) == 1
+             and sigmas.stride(1) == sigmas.shape[2] * sigmas.stride(2)
+             and sigmas.stride(0) == sigmas.shape[1] * sigmas.stride(1) and sigmas.stride(2) >= 2,
+             'pose_finalize: sigmas [B, N, K, 2] fp32 on the device, rows evenly strided')
+    sigma_ld = sigmas.stride(2)
     _require(kpts.dim() == 4 and kpts.shape[-1] == 2 and kpts.shape == sigmas.shape
              and tuple(scores.shape) == tuple(kpts.shape[:2]) and wh.numel() == 2 * kpts.shape[0],
              'pose_finalize: kpts / sigmas [B, N, K, 2], scores [B, N], wh [B, 2]')
@@ -1195,7 +1232,7 @@ def pose_finalize(kpts, sigmas, scores, wh, sf=None):
         st = lib.pave_pose_finalize_f32(kpts.data_ptr(), sigmas.data_ptr(), scores.data_ptr(),
                                         wh.data_ptr(), sf.data_ptr() if sf is not None else None,
                                         det_kpts.data_ptr(), det_bboxes.data_ptr(), B, N, K,
-                                        int(sf is not None), _stream_ptr())
+                                        int(sf is not None), sigma_ld, _stream_ptr())
     native.check(st, 'pose_finalize')
     return det_kpts, det_bboxes
 

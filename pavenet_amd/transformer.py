@@ -416,6 +416,9 @@ class VideoPoseTransformerMulFrames(Transformer):
         # encoder sampling through the LDS-tile kernel (pave_enc_tile.hip); False = head-major
         # direct-gather kernel (also the path for pyramids the tile kernel does not cover)
         self.enc_lds_tile = True
+        # proposal stage on the fused launches (ops.gather_rows_add / proposal_refs_, the per-clip Linear +
+        # LayerNorm with filled border rows); False = the tensor expressions of OT:21204-21418 (tools/ab_switch.py)
+        self.fused_proposal_stage = True
 
     def init_layers(self):
         self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
@@ -454,7 +457,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             cached = geom.unpadded.get(('proposals', N))
             if cached is not None:   # the grid depends on the level sizes only
                 output_proposals, valid = cached
-                filled = self._output_memory_filled(memory, valid, geom)
+                filled = self._output_memory_filled(memory, valid, geom) if self.fused_proposal_stage else None
                 if filled is not None:
                     return filled, output_proposals
                 output_memory = memory.masked_fill(~valid, float(0))
@@ -493,6 +496,19 @@ class VideoPoseTransformerMulFrames(Transformer):
         output_memory = output_memory.masked_fill(~valid, float(0))
         output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
         return output_memory, output_proposals
+
+    def _dense_const(self, name, source, view, rows=None):
+        """A dense copy of `view` (a slice / broadcast of the parameter `source`), made once per version of the
+        parameter instead of once per step; rows: the leading broadcast size of the copy."""
+        key = SourceKey((source,), extra=rows)
+        hit = self.__dict__.get('_pave_' + name)
+        if hit is None or hit[0] != key or torch.is_grad_enabled():
+            dense = view.detach().contiguous() if not torch.is_grad_enabled() else view.contiguous()
+            if torch.is_grad_enabled():
+                return dense
+            hit = (key, dense)
+            self.__dict__['_pave_' + name] = hit
+        return hit[1]
 
     def _output_memory_filled(self, memory, valid, geom):
         """enc_output_norm(enc_output(memory.masked_fill(~valid, 0))) (OT:21206-21214) without the masked copy
@@ -686,14 +702,16 @@ class VideoPoseTransformerMulFrames(Transformer):
             # device fast path: the gather / repeat / strided add / sigmoid / repeat sequence below as two
             # launches (ops.gather_rows_add: `tgt` and `tgt + query`; ops.proposal_refs_: the in-place proposal
             # offset and the T-fold reference points)
-            fused = (output_memory.is_cuda and output_memory.dtype == torch.float32 and frame_shard is None
+            fused = (self.fused_proposal_stage and output_memory.is_cuda
+                     and output_memory.dtype == torch.float32 and frame_shard is None
                      and not torch.is_grad_enabled() and output_memory.is_contiguous() and c % 4 == 0
                      and output_proposals.is_contiguous())
             fused_query = None
             if fused:
                 from . import ops
                 topk_proposals = topk_proposals.contiguous()
-                tgt, fused_query = ops.gather_rows_add(output_memory, topk_proposals, query.contiguous())
+                tgt, fused_query = ops.gather_rows_add(output_memory, topk_proposals,
+                                                       self._dense_const('query_half', query_embed, query))
             else:
                 tgt = torch.gather(output_memory, 1,
                                    topk_proposals.unsqueeze(-1).repeat(1, 1, self.embed_dims))
@@ -789,12 +807,19 @@ class VideoPoseTransformerMulFrames(Transformer):
         pos_num = reference_points_pose.size(0) // T
         query_pos = query_pos.unsqueeze(0).expand(pos_num, -1, -1)
         query = query.unsqueeze(0).expand(pos_num, -1, -1)
+        if query.is_cuda and not torch.is_grad_enabled():
+            # (the decoder reads its first query from a dense tensor: the same rows every step)
+            query = self._dense_const('refine_query', rq, query, rows=pos_num)
         reference_points = reference_points_pose.reshape(-1, reference_points_pose.size(1) // 2, 2)
         mask_bt = mask_flatten.reshape(-1, Tl, mask_flatten.size(-1))         # [B, T_loc, S]
-        vr = valid_ratios.reshape(-1, Tl, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
-        if frame_shard is not None:
-            # every frame of a clip has the same valid ratios: rebuild the [N, T, L, 2] table
-            vr = vr[:, :1].expand(-1, T, -1, -1)
+        if has_padding:
+            vr = valid_ratios.reshape(-1, Tl, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
+            if frame_shard is not None:
+                # every frame of a clip has the same valid ratios: rebuild the [N, T, L, 2] table
+                vr = vr[:, :1].expand(-1, T, -1, -1)
+            vr_rows = vr.flatten(0, 1)
+        else:   # every valid ratio is exactly 1: a broadcast row, no gather / copy per step
+            vr_rows = valid_ratios[:1].expand(img_inds.shape[0] * T, -1, -1)
         dec_kwargs = {}
         if branches is not None:
             dec_kwargs['frame_reg_branches'] = branches
@@ -819,6 +844,6 @@ class VideoPoseTransformerMulFrames(Transformer):
             query=seq_first_view(query.contiguous()), key=None, value=memory,
             query_pos=seq_first_view(query_pos), key_padding_mask=attn_mask,
             reference_points=reference_points, spatial_shapes=spatial_shapes,
-            level_start_index=level_start_index, valid_ratios=vr.flatten(0, 1),
+            level_start_index=level_start_index, valid_ratios=vr_rows,
             memory_clip_index=img_inds, **dec_kwargs)
         return inter_states, reference_points, inter_references

@@ -121,14 +121,20 @@ def test_capi_argument_errors():
     st = lib.pave_ms_deform_attn_forward_f32(p, p, p, p, p, p, 3, 1, 1, 4, 1, 1, 1, 2, None)
     assert st == -3  # batch 3 not divisible by im2col_step 2 (ms_deform_attn_cuda.cu:242-245)
     st = lib.pave_deform_attn_grid_fused_f32(p, p, p, p, p, None, None, p, None, None, 4, 4, 1, 1,
-                                             10, 3, 4, 384, None, 0, None)
+                                             10, 3, 4, 384, None, 0, 3, None)
     assert st == -1 and b'L = 4' in lib.pave_last_error()
     # a frame table without the number of slabs behind `value`, and a slab count that contradicts n_clips * T
     st = lib.pave_deform_attn_grid_fused_f32(p, p, p, p, p, None, None, p, None, None, 4, 4, 1, 1,
-                                             10, 4, 4, 384, p, 0, None)
+                                             10, 4, 4, 384, p, 0, 4, None)
     assert st == -1 and b'n_slabs' in lib.pave_last_error()
-    st = lib.pave_deform_attn_pose_fused_f32(p, p, p, p, p, p, None, None, 1, 4, 3, 10, 4, 15, 4320, None, 7, None)
+    st = lib.pave_deform_attn_pose_fused_f32(p, p, p, p, p, p, None, None, 1, 4, 3, 10, 4, 15, 4320, None, 7, 4, None)
     assert st == -1 and b'n_slabs' in lib.pave_last_error()
+    # reference rows per entry: one per level, or one shared by all levels -- nothing else
+    st = lib.pave_deform_attn_pose_fused_f32(p, p, p, p, p, p, None, None, 1, 4, 3, 10, 4, 15, 4320, None, 0, 2, None)
+    assert st == -1 and b'ref_levels' in lib.pave_last_error()
+    st = lib.pave_deform_attn_grid_fused_f32(p, p, p, p, p, None, None, p, None, None, 4, 4, 1, 1,
+                                             10, 4, 4, 384, None, 0, 0, None)
+    assert st == -1 and b'ref_levels' in lib.pave_last_error()
     # the listed-rows fill and the softmax merge validate their sizes without touching the device
     assert lib.pave_fill_rows_f32(p, 6, 10, p, 1, None, 6, None) == -1      # C % 4
     assert lib.pave_fill_rows_f32(p, 8, 10, None, 0, None, 8, None) == 0    # nothing to fill: no launch

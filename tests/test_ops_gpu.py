@@ -215,7 +215,7 @@ def test_grid_fused_T1_unaligned_rows_take_the_per_query_kernel():
     out = torch.empty(U, 256, device='cuda')
     st = lib.pave_deform_attn_grid_fused_f32(
         vd.data_ptr(), sd.data_ptr(), ld.data_ptr(), pd.data_ptr(), rd.data_ptr(), None, None,
-        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride, None, 0,
+        out.data_ptr(), None, None, U, U, 1, 1, S, 4, 4, stride, None, 0, 4,
         torch.cuda.current_stream().cuda_stream)
     native.check(st, 'grid_fused (unaligned rows)')
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), rtol=2e-5, atol=2e-5)
@@ -285,6 +285,40 @@ def test_frame_table_entries_outside_the_value_cache_cannot_fault():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('T', [1, 3, 5])
+def test_level_broadcast_reference_points_equal_the_materialised_copy(T):
+    """Un-padded batches: the decoders pass `reference_points[:, :, None].expand(.., L, ..)` (OT:6712-6720,
+    MT:845-856).  The fused kernels read such a tensor as ONE row per entry (ref_levels = 1) -- bit-identical to
+    the materialised [.., L, ..] copy, pose and grid form, with and without a frame table."""
+    from pavenet_amd.ops import deform_attn_grid_fused, deform_attn_pose_fused
+    shapes, lsi, sd, ld = _levels(LEVELS)
+    S = int(shapes.prod(1).sum())
+    clips, Q, K, L = 2, 11, 15, 4
+    value = _t(seeded_array(f'lb.value.{T}', (clips * T, S, 8, 32))).cuda()
+    proj = _t(seeded_array(f'lb.proj.{T}', (clips * Q, T * 8 * L * K * 3))).cuda()
+    base = torch.sigmoid(_t(seeded_array(f'lb.ref.{T}', (clips, T * Q, 2 * K), 1.0))).cuda()
+    ref = base[:, :, None].expand(-1, -1, L, -1)
+    assert not ref.is_contiguous()
+    kw = dict(T=T, n_clips=clips, num_query=Q, num_keypoints=K)
+    a = deform_attn_pose_fused(value, sd, ld, proj, ref, **kw)
+    b = deform_attn_pose_fused(value, sd, ld, proj, ref.contiguous(), **kw)
+    assert torch.equal(a, b)
+    table = torch.arange(clips * T - 1, -1, -1, dtype=torch.int32).cuda()
+    a = deform_attn_pose_fused(value, sd, ld, proj, ref, frame_table=table, **kw)
+    b = deform_attn_pose_fused(value, sd, ld, proj, ref.contiguous(), frame_table=table, **kw)
+    assert torch.equal(a, b)
+    U = clips * Q
+    gproj = _t(seeded_array(f'lb.gproj.{T}', (U, T * 8 * 16 * 3))).cuda()
+    gbase = (_t(seeded_array(f'lb.gref.{T}', (T * U, 1, 2), 0.2)) + 0.5).cuda()
+    gref = gbase[:, :, None].expand(-1, -1, L, -1).reshape(T, U, L, 2)     # the joint decoder's view
+    assert gref.stride(2) == 0
+    uc = torch.arange(U, dtype=torch.int32).cuda() // Q
+    gk = dict(T=T, n_clips=clips, units_per_clip=Q, unit_clip=uc)
+    a = deform_attn_grid_fused(value, sd, ld, gproj, gref, **gk)
+    b = deform_attn_grid_fused(value, sd, ld, gproj, gref.contiguous(), **gk)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('B,H,W,heads,shift', [(2, 14, 21, 3, 0), (2, 14, 21, 3, 3), (1, 20, 33, 6, 3),
                                                (3, 7, 7, 12, 0), (1, 5, 9, 3, 3), (1, 29, 48, 6, 3)])
 def test_swin_window_attention_kernel_vs_reference_formulation(B, H, W, heads, shift):
@@ -324,6 +358,24 @@ def test_gemm_gelu_epilogue_and_wide_layernorm_rows():
         got = ops.gemm_bf16x3(a.cuda(), ops.split_weight_bf16x3(w.cuda()), b.cuda(), relu='gelu')
         exp = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double())
         np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-6)
+        # the sigmoid epilogue (the heads' sigma branches): the fp32 GEMM result through torch.sigmoid's expression
+        lin = ops.gemm_bf16x3(a.cuda(), ops.split_weight_bf16x3(w.cuda()), b.cuda())
+        got = ops.gemm_bf16x3(a.cuda(), ops.split_weight_bf16x3(w.cuda()), b.cuda(), relu='sigmoid')
+        np.testing.assert_allclose(got.cpu().numpy(), lin.sigmoid().cpu().numpy(), rtol=0, atol=1.2e-7)
+    # ... and through the heads' helper on a 2-output branch (planes padded to 64 columns, output to 4)
+    from pavenet_amd.bricks import mlp_rows
+    br = torch.nn.Sequential(torch.nn.Linear(192, 64), torch.nn.ReLU(), torch.nn.Linear(64, 2)).cuda()
+    x = torch.randn(3, 50, 192, generator=g).cuda()
+    from pavenet_amd.bricks import get_gemm_mode, set_gemm_mode
+    mode = get_gemm_mode()
+    set_gemm_mode('bf16x3')
+    try:
+        with torch.no_grad():
+            got, exp = mlp_rows(br, x, act='sigmoid'), br(x).sigmoid()
+    finally:
+        set_gemm_mode(mode)
+    assert got.shape == exp.shape and got.stride(-2) == 4         # the padded matrix's column slice
+    np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=0, atol=2e-6)
     for C in (1536, 3072, 1028):
         x, ga, be = torch.randn(77, C, generator=g) * 3 + 1, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
         got = ops.bias_add_layernorm(x.cuda(), None, None, ga.cuda(), be.cuda(), 1e-5)
@@ -743,6 +795,10 @@ def test_ref_update_vs_torch_formulation():
     exp = (tmp.double() + inverse_sigmoid(ref.double())).sigmoid()
     got = ref_update(tmp.cuda(), ref.cuda())
     np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=2e-6, atol=1e-7)
+    # a 30-column slice of a 32-column matrix (a branch output as its GEMM leaves it) is read in place
+    wide = torch.randn(4, 300, 32, generator=g).cuda()
+    wide[..., :30] = tmp.cuda()
+    assert torch.equal(ref_update(wide[..., :30], ref.cuda()), got)
 
 
 @pytest.mark.parametrize('N,HW,C,G', [(3, 1000, 256, 32), (2, 35, 256, 32), (1, 7, 64, 8),
@@ -1931,8 +1987,12 @@ def test_gather_frame_poses_and_pose_finalize_vs_torch():
     sc = torch.rand(B, N, generator=g).cuda()
     wh = torch.tensor([[1344., 800.], [1200., 780.], [640., 480.]]).cuda()
     sf = torch.tensor([[1.5, 1.25], [0.8, 0.9], [1., 1.]]).cuda()
+    sg4 = torch.zeros(B, N, K, 4).cuda()          # the sigma branch's output as its GEMM leaves it: [.., 4] rows
+    sg4[..., :2] = sg
     for rescale in (False, True):
         dk, db = pose_finalize(kp, sg, sc, wh, sf if rescale else None)
+        dk4, db4 = pose_finalize(kp, sg4[..., :2], sc, wh, sf if rescale else None)
+        assert torch.equal(dk, dk4) and torch.equal(db, db4)
         whb, sfb = wh.view(B, 1, 1, 2), sf.view(B, 1, 1, 2)
         k = kp * whb
         k = torch.minimum(k.clamp(min=0), whb)

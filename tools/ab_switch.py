@@ -15,7 +15,7 @@ from pavenet_amd.weights import init_random_weights  # noqa: E402
 
 path = sys.argv[1].split('.')
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-T, B = 7, 4
+T, B = int(os.environ.get('AB_T', 7)), int(os.environ.get('AB_B', 4))     # AB_T=3 AB_B=1: configs[1]
 m = init_random_weights(build_model(videopose_r50_cfg(num_frames=T, max_per_img=20)), seed=0).cuda().eval()
 set_gemm_mode('bf16x3')
 img = torch.randn(B, T, 3, 800, 1344, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
