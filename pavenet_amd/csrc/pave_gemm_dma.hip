@@ -1523,7 +1523,15 @@ int launch_s(const float* a, const uint16_t* w, const float* bias, const float* 
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
 }
-constexpr long long kSmallRows = 8192;   // launches with fewer rows take the small-row form
+// Which launches take the small-row form: fewer than 64 tiles of 128 x 128 (and < 8 192 rows).  tools/
+// small_vs_tile.py (us, small-row | tile kernels): 1 200 x 1024 x 256: 26 | 35, 1 200 x 512 x 512: 16 | 21,
+// 3 150 x 1536 x 256: 42 | 50 -- 2 100 x 2048 x 512: 86 | 65, 3 150 x 2048 x 512: 92 | 69, 6 000 x 1024 x 256: 47 | 36,
+// 8 000 x 2048 x 512: 167 | 83 (until round 5 the rule was rows alone, < 8 192: a one-clip batch's layer4
+// convolutions sat on the wrong side of it).  The forms are bit-identical.
+constexpr long long kSmallRows = 8192;
+inline bool small_rows_form(long long M, int N) {
+  return M < kSmallRows && ((M + 127) / 128) * ((N + 127) / 128) < 64;
+}
 
 constexpr int W_SMEM = 2 * (QBM * 64 + 3 * 256 * 32);   // wide form: ring of 2 x 32 KiB
 template <int PL>
@@ -1637,7 +1645,7 @@ static int gemm_q_dispatch(const float* a, const float* a_bias, const void* w_pl
   // tile kernels (64- and 128-column wave tiles: 1200 x 256 x 10080 45 -> 73 us, the grouped branch MLPs
   // 38 -> 76 us), so they keep those.  Measured with it: 1200 x 1024 x 256 + LayerNorm 62 -> 35 us,
   // 1200 x 256 x 256 + LayerNorm 24 -> 19 us.
-  if (kind == 0 && M < kSmallRows && N <= 512 && !a_bias && !out2 && ksplit == 1 &&
+  if (kind == 0 && small_rows_form(M, N) && N <= 512 && !a_bias && !out2 && ksplit == 1 &&
       pave_internal_diag_variant() == 0)
     return launch_s<1, 4, PL>(a, w, bias, residual, out, M, K, N, relu, H > 0 ? H : K, W > 0 ? W : 0, os.res_rows,
                           n_real, st);
@@ -1780,7 +1788,7 @@ static int gemm_q_ln_go(const float* a, const void* w_planes, const float* bias,
                         int K, int N, void* stream) {
   if (K % 32 != 0 || K < 64 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_q_ln: K %% 32 == 0, K >= 64 and N == 256 required");
-  if (M < kSmallRows && pave_internal_diag_variant() == 0) {
+  if (small_rows_form(M, N) && pave_internal_diag_variant() == 0) {
     // few rows: the small-row GEMM (bias + identity in its epilogue), then LayerNorm in place -- two
     // launches of a few microseconds instead of 10 row tiles walking K behind barriers
     const int st1 = launch_s<1, 4, PL>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K,
