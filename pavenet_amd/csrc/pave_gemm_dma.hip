@@ -1577,9 +1577,11 @@ void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks
   // alone and inside a batch, as long as the batch stays under the tile threshold).
   if (tiles >= 200 || nsl < 128 || pave_internal_diag_variant() == 6) return;
   // 2 048 <= K < 8 192 (the ChannelMapper's extra level behind HRNet-w48: 3x3 / stride 2 on 384 channels,
-  // K = 3 456): 4 parts -- a fixed count per K range, for the same reason
+  // K = 3 456; ResNet layer3 / layer4's 3x3 on a one-clip batch): 4 parts -- a fixed count per K range, for the
+  // same reason -- below 128 tiles (tools/conv_small_batch.py: 256 -> 256 on 3 x 50 x 84, 99 tiles, 113 -> 101 us;
+  // on 6 x 50 x 84, 197 tiles, 173 -> 179: not there)
   const int want = nsl < 512 ? 4 : 8;
-  if (nsl < 512 && tiles >= 64) return;
+  if (nsl < 512 && tiles >= 128) return;
   int per = ((nsl + want - 1) / want + 1) & ~1;
   int parts;
   for (;; per += 2) {   // the last part keeps >= 4 slabs (nsl and per are even: its size is even)
