@@ -522,6 +522,16 @@ int pave_conv3x3_splitk_f32(const float* x, const void* w_planes, const float* b
                             int nplanes, void* stream);
 
 /*
+ * The same split-K plan for the plain row GEMM out[M, N] = act(a[M, K] W^T + bias + residual) (relu = 0 | 1): few
+ * row tiles and K >= 2048 -- ResNet layer4's 1x1 reductions (resnet.py:264-271) and the ChannelMapper's C5 lateral
+ * on a one-clip batch.  pave_gemm_splitk_workspace_bytes = 0: the shape has no plan, use pave_gemm_bf16x3_f32.
+ */
+long long pave_gemm_splitk_workspace_bytes(long long M, int K, int N);
+int pave_gemm_bf16x3_splitk_f32(const float* a, const void* w_planes, const float* bias, const float* residual,
+                                float* out, long long M, int K, int N, int relu, int nplanes, void* workspace,
+                                long long workspace_bytes, void* stream);
+
+/*
  * ResNet Bottleneck of the 64-channel stage from its 3x3 convolution on, CHAINED with the next
  * block's conv1, in ONE launch (third_party/mmdetection/mmdet/models/backbones/resnet.py:263-300
  * Bottleneck.forward: conv2 + bn2 + relu -> conv3 + bn3 -> + identity | downsample(x) -> relu; then

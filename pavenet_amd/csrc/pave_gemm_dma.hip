@@ -1580,7 +1580,8 @@ void pave_internal_splitk_plan(long long M, int Kp, int Np, int* ksplit, int* ks
   // K = 3 456; ResNet layer3 / layer4's 3x3 on a one-clip batch): 4 parts -- a fixed count per K range, for the
   // same reason -- below 128 tiles (tools/conv_small_batch.py: 256 -> 256 on 3 x 50 x 84, 99 tiles, 113 -> 101 us;
   // on 6 x 50 x 84, 197 tiles, 173 -> 179: not there)
-  const int want = nsl < 512 ? 4 : 8;
+  // (K >= 8 192 on fewer than 16 tiles -- that level of a one-clip batch: 819 pixels = 7 tiles -- 32 parts)
+  const int want = nsl < 512 ? 4 : (tiles < 16 ? 32 : 8);
   if (nsl < 512 && tiles >= 128) return;
   int per = ((nsl + want - 1) / want + 1) & ~1;
   int parts;

@@ -722,6 +722,35 @@ static int gemm_split_entry(const float* a, const float* a_bias, const void* w_p
 #undef PAVE_GO
 }
 
+// Split-K form of the plain row GEMM (few row tiles, K >= 2048: ResNet layer4's 1x1 reductions and the neck's
+// C5 lateral on a one-clip batch).  The plan is pave_internal_splitk_plan's -- the 3x3 form's.
+long long pave_gemm_splitk_workspace_bytes(long long M, int K, int N) {
+  if (M <= 0 || M >= (1ll << 31) || K < 64 || K % 32 != 0 || N <= 0 || N % 4 != 0 || g_diag_variant == 9) return 0;
+  int parts, per;
+  pave_internal_splitk_plan(M, K, (N + 63) / 64 * 64, &parts, &per);
+  return parts > 1 ? (long long)parts * M * N * 4 : 0;
+}
+
+int pave_gemm_bf16x3_splitk_f32(const float* a, const void* w_planes, const float* bias, const float* residual,
+                                float* out, long long M, int K, int N, int relu, int nplanes, void* workspace,
+                                long long workspace_bytes, void* stream) {
+  if (!a || !w_planes || !out || !workspace || (relu != 0 && relu != 1))
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_splitk: null pointer (or relu not 0 | 1)");
+  if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_splitk: nplanes must be 3 or PAVE_PLANES_FP16");
+  const long long need = pave_gemm_splitk_workspace_bytes(M, K, N);
+  if (need == 0 || workspace_bytes < need)
+    return pave_internal_fail(PAVE_E_ARG, "gemm_bf16x3_splitk: shape has no split-K plan (use pave_gemm_bf16x3_f32) or "
+                                          "the workspace is smaller than pave_gemm_splitk_workspace_bytes");
+  const int Np = (N + 63) / 64 * 64;
+  int parts, per;
+  pave_internal_splitk_plan(M, K, Np, &parts, &per);
+  float* ws = static_cast<float*>(workspace);
+  const int rc = pave_internal_gemm_q(a, nullptr, w_planes, nullptr, nullptr, 0, ws, nullptr, 0, M, K, Np, 0, 0, 0, 0,
+                                      0, 0, 0, 0, stream, nullptr, N, parts, per, q_planes(nplanes));
+  if (rc != PAVE_OK) return rc;
+  return pave_internal_splitk_reduce(ws, parts, M, N, bias, residual, relu, out, stream);
+}
+
 int pave_gemm_fp16_act_f32(const void* a, int a_is_f16, const void* w_plane, const float* bias,
                            const float* residual, const float* gamma, const float* beta, float eps, void* out,
                            int out_is_f16, long long M, int K, int N, int relu, void* stream) {

@@ -63,12 +63,15 @@ SIGNATURES = {
     'pave_ref_update_frames_f32': [_vp, _vp, _vp] + [_c_int] * 5 + [ctypes.c_float, _vp],
     'pave_swin_window_attn_f32': [_vp] * 4 + [_c_int] * 7 + [ctypes.c_float, _vp],
     'pave_merge_softmax_partials_f32': [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
+    'pave_gemm_bf16x3_splitk_f32': [_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_int, _c_int, _vp,
+                                    ctypes.c_longlong, _vp],
     'pave_gather_rows_add_f32': [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp],
     'pave_proposal_refs_f32': [_vp, _c_int, _vp, ctypes.c_longlong, _vp, _vp] + [_c_int] * 5 + [_vp],
     'pave_oks_nms_f32': [_vp] * 3 + [ctypes.c_double] + [_vp] * 2 + [_c_int] * 3 + [_vp],
 }
 # every symbol include/pave_hip.h declares
-EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes')
+EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes',
+                                'pave_gemm_splitk_workspace_bytes')
 
 _lib = None
 ABI_VERSION = 18  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
@@ -95,6 +98,8 @@ def _open(path):
     lib.pave_last_error.argtypes = []
     lib.pave_conv3x3_splitk_workspace_bytes.restype = ctypes.c_longlong
     lib.pave_conv3x3_splitk_workspace_bytes.argtypes = [_c_int] * 6
+    lib.pave_gemm_splitk_workspace_bytes.restype = ctypes.c_longlong
+    lib.pave_gemm_splitk_workspace_bytes.argtypes = [ctypes.c_longlong, _c_int, _c_int]
     have = lib.pave_abi_version()
     if have != ABI_VERSION:   # a stale .so called with the wrong argument list corrupts memory
         raise NativeLibraryError(

@@ -677,6 +677,7 @@ def split_weight_bf16x3(weight, planes=3, pad=False):
 
 
 _ACT_CODE = {'gelu': 2, 'sigmoid': 3}     # pave_gemm_bf16x3_f32's `relu` argument beyond 0 / 1
+SPLITK_ROWS = True     # plain row GEMMs with a split-K plan take pave_gemm_bf16x3_splitk_f32 (tools: A/B switch)
 
 
 def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_bias=None,
@@ -717,6 +718,18 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    # few row tiles and a long K (a one-clip batch's layer4 1x1 reductions, the neck's C5 lateral): the split-K
+    # form, as for the 3x3 convolutions (workspace from torch's stream-aware caching allocator)
+    ws_bytes = lib.pave_gemm_splitk_workspace_bytes(M, K, N) \
+        if (SPLITK_ROWS and npl in _Q_PLANES and a_bias is None and relu in (False, True, 0, 1)) else 0
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'split-K')):
+            st = lib.pave_gemm_bf16x3_splitk_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
+                                                 out.data_ptr(), M, K, N, int(bool(relu)), npl, ws.data_ptr(),
+                                                 ws_bytes, _stream_ptr())
+        native.check(st, 'gemm_bf16x3_splitk')
+        return out
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'abias' if a_bias is not None else '')):
         st = lib.pave_gemm_bf16x3_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),
                                       ptr(residual), out.data_ptr(), M, K, N,

@@ -965,11 +965,16 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
     from pavenet_amd.ops import conv3x3_split, split_conv3x3_weight
     lib = native.load()
     M = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
-    # (a fixed number of parts per K range -- 8 from K = 8 192 on, 4 for 2 048 <= K < 8 192 (the neck's extra level
-    # behind HRNet-w48: K = 3 456) --: the summation order does not depend on the batch size)
-    parts = 8 if 9 * Cin >= 8192 else 4
-    assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride) == parts * M * Cout * 4
-    assert lib.pave_conv3x3_splitk_workspace_bytes(4 * N, H, W, Cin, Cout, stride) in (0, parts * 4 * M * Cout * 4)
+    # (a fixed number of parts per K range and tile-count class -- from K = 8 192 on: 8, or ~32 below 16 row tiles (a
+    # one-clip batch); 4 for 2 048 <= K < 8 192 (the neck's extra level behind HRNet-w48: K = 3 456) --: the
+    # summation order does not depend on the batch size inside a class)
+    ws = lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout, stride)
+    assert ws > 0 and ws % (M * Cout * 4) == 0
+    parts = ws // (M * Cout * 4)
+    tiles = (M + 127) // 128 * ((Cout + 255) // 256 if Cout % 256 == 0 else (Cout + 127) // 128)
+    assert parts == 4 if 9 * Cin < 8192 else (parts == 8 if tiles >= 16 else 24 <= parts <= 32)
+    ws4 = lib.pave_conv3x3_splitk_workspace_bytes(4 * N, H, W, Cin, Cout, stride)
+    assert ws4 == 0 or (ws4 % (4 * M * Cout * 4) == 0 and ws4 // (4 * M * Cout * 4) in (4, 8, parts))
     assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, 256, Cout, stride) == 4 * M * Cout * 4   # K = 2 304
     assert lib.pave_conv3x3_splitk_workspace_bytes(N, H, W, 128, Cout, stride) == 0    # K = 1 152: one pass
     g = torch.Generator().manual_seed(Cin * Cout + H)
@@ -998,6 +1003,41 @@ def test_conv3x3_split_k_form_vs_fp64(N, H, W, Cin, Cout, stride):
                        cout=Cout)
     expn = torch.isnan(torch.nn.functional.conv2d(xn, w, None, stride, 1)[0]).any(0)
     assert torch.equal(torch.isnan(yn[0]).any(0).cpu(), expn)
+
+
+@pytest.mark.parametrize('M,K,N', [(3150, 2048, 512), (3150, 2048, 256), (1050, 4096, 300), (7350, 2048, 512)])
+def test_plain_gemm_split_k_form_vs_fp64_and_one_pass(M, K, N):
+    """The same split-K plan for the plain row GEMM (pave_gemm_bf16x3_splitk_f32: a one-clip batch's layer4 1x1
+    reductions, the neck's C5 lateral): ops.gemm_bf16x3 takes it where the plan exists; bias / residual (in place
+    too) / ReLU are applied by the reduction launch; fp64 bound, bit-reproducible, equal to the one-pass kernel up
+    to the summation order; shapes without a plan (short K, many tiles) keep the one-pass entry."""
+    from pavenet_amd import native, ops
+    lib = native.load()
+    ws = lib.pave_gemm_splitk_workspace_bytes(M, K, N)
+    assert ws > 0 and ws % (M * N * 4) == 0 and ws // (M * N * 4) == 4
+    assert lib.pave_gemm_splitk_workspace_bytes(M, 1024, N) == 0 and lib.pave_gemm_splitk_workspace_bytes(40000, K, N) == 0
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).relu_()
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    wp = ops.split_weight_bf16x3(w.cuda(), pad=N % 64 != 0)
+    kw = dict(n_out=N) if N % 64 else {}
+    exp = a.double() @ w.double().t() + b.double()
+    y = ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), relu=True, **kw)
+    np.testing.assert_allclose(y.cpu().numpy(), exp.clamp(min=0).numpy(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(y, ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), relu=True, **kw))
+    rd = r.cuda()
+    y2 = ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), rd, out=rd, **kw)
+    assert y2.data_ptr() == rd.data_ptr()
+    np.testing.assert_allclose(y2.cpu().numpy(), (exp + r.double()).numpy(), rtol=1e-5, atol=2e-5)
+    with native.diag_build(6) as dlib:     # no split-K plan: the one-pass kernels
+        assert dlib.pave_gemm_splitk_workspace_bytes(M, K, N) == 0
+        one = ops.gemm_bf16x3(a.cuda(), wp, b.cuda(), relu=True, **kw)
+    np.testing.assert_allclose(y.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    an = a.clone()
+    an[5, 7] = float('nan')                # a NaN poisons its row, in every part's sum
+    yn = ops.gemm_bf16x3(an.cuda(), wp, None, **kw)
+    assert torch.isnan(yn[5]).all() and not torch.isnan(yn[4]).any() and not torch.isnan(yn[6]).any()
 
 
 @pytest.mark.parametrize('shifts', [(0,), (0, 1), (1, 0, 2), (0, 0, 1, 3), (2, 1, 0, 0)])
