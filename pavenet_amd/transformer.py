@@ -500,13 +500,12 @@ class VideoPoseTransformerMulFrames(Transformer):
     def _dense_const(self, name, source, view, rows=None):
         """A dense copy of `view` (a slice / broadcast of the parameter `source`), made once per version of the
         parameter instead of once per step; rows: the leading broadcast size of the copy."""
+        if torch.is_grad_enabled():      # (training: the copy is part of the graph, nothing is cached)
+            return view.contiguous()
         key = SourceKey((source,), extra=rows)
         hit = self.__dict__.get('_pave_' + name)
-        if hit is None or hit[0] != key or torch.is_grad_enabled():
-            dense = view.detach().contiguous() if not torch.is_grad_enabled() else view.contiguous()
-            if torch.is_grad_enabled():
-                return dense
-            hit = (key, dense)
+        if hit is None or hit[0] != key:
+            hit = (key, view.detach().contiguous())
             self.__dict__['_pave_' + name] = hit
         return hit[1]
 

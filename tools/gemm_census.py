@@ -1,6 +1,7 @@
 """Per-shape census of the split-GEMM / convolution launches of one bench step (T = 7 x 4 clips,
 800x1344, --gemm bf16x3): HIP-event time, TFLOP/s and launch count per (entry point, M, K, N, form),
-in launch order.   python tools/gemm_census.py [steps=3] [diag variant (0 = none)] [T=7] [clips=4] [r50 | hrnet_w48 | swin_l]"""
+in launch order.   python tools/gemm_census.py [steps=3] [diag variant (0 = none)] [T=7] [clips=4] [r50 | hrnet_w48 | swin_l] [bf16x3 | fp16]
+(the last column: algorithmic TB/s of the launch -- A + W + out (+ residual) once, fp32 unless the mode stores fp16)"""
 import collections
 import os
 import sys
@@ -32,7 +33,7 @@ def main():
     m = build_model(cfg)
     init_random_weights(m, seed=0)
     m = m.cuda().eval()
-    set_gemm_mode('bf16x3')
+    set_gemm_mode(sys.argv[6] if len(sys.argv) > 6 else 'bf16x3')
     tuning.use_tuned_gemms()
     img = torch.randn(B, T, 3, H, W, device='cuda')
     metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=(1., 1., 1., 1.))] * B
@@ -53,12 +54,18 @@ def main():
         d[0] += 1
         d[1] += s.elapsed_time(e)
     tot = 0.0
-    print(f'{"entry point":18s} {"shape":44s} {"n/step":>6s} {"ms each":>8s} {"ms/step":>8s} {"TF/s":>6s}')
+    print(f'{"entry point":18s} {"shape":44s} {"n/step":>6s} {"ms each":>8s} {"ms/step":>8s} {"TF/s":>6s} {"TB/s":>6s}')
     for (tag, shp), (n, ms, fl) in agg.items():
         each = ms / n
         tot += ms / steps
         tf = f'{fl / each / 1e9:6.0f}' if fl else '     -'
-        print(f'{tag:18s} {str(shp):44s} {n / steps:6.1f} {each:8.3f} {ms / steps:8.3f} {tf}')
+        tb = '     -'
+        if shp and len(shp) >= 3 and all(isinstance(v, int) for v in shp[:3]) and fl:
+            M_, K_, N_ = shp[:3]
+            kk = K_ // 9 if any('3x3' in str(v) for v in shp) else K_     # (3x3: the map is read once, not 9 times)
+            byt = 4 * (M_ * kk + M_ * N_ * (2 if 'res' in shp else 1)) + 6 * K_ * N_
+            tb = f'{byt / each / 1e9:6.2f}'
+        print(f'{tag:18s} {str(shp):44s} {n / steps:6.1f} {each:8.3f} {ms / steps:8.3f} {tf} {tb}')
     print(f'total of the listed launches: {tot:.2f} ms/step')
 
 
