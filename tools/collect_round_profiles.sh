@@ -13,6 +13,11 @@ bash tools/pmc_bench_mfma.sh ${P}_mfma > /dev/null && cp gpurun_out/${P}_mfma/mf
 bash tools/pmc_enc_tile.sh ${P}_pmc_enc > gpurun_out/${P}_pmc_enc_tile.txt 2>&1 && echo "enc pmc ok"
 bash tools/pmc_bench_enc.sh ${P}_enc_traffic > gpurun_out/${P}_enc_traffic.log 2>&1 && echo "enc traffic ok"
 python3 tools/gemm_census.py 3 > gpurun_out/${P}_gemm_shapes.txt 2>&1 && echo "census ok"
+SEQ_MIN_US=0 bash tools/profile_bench.sh ${P}_t3b1 --frames 3 --clips 1 --steps 6 && echo "configs[1] trace ok"
+SEQ_MIN_US=40 bash tools/profile_bench.sh ${P}_swin_l_t3 --backbone swin_l --frames 3 --clips 1 && echo "swin trace ok"
+python3 tools/gemm_census.py 3 0 3 1 r50 > gpurun_out/${P}_gemm_shapes_t3b1.txt 2>&1 && echo "census t3 ok"
+python3 tools/gemm_census.py 3 0 15 1 r50 fp16 > gpurun_out/${P}_gemm_shapes_t15_fp16.txt 2>&1 && echo "census t15 fp16 ok"
+python3 tools/gemm_census.py 3 0 3 1 swin_l > gpurun_out/${P}_gemm_shapes_swin_l_t3.txt 2>&1 && echo "census swin ok"
 python3 tools/bench_kernels.py --frames 28 --sigma 0.9 --enc-only --prepared --ablate > gpurun_out/${P}_enc_kernels_28frames.txt 2>&1 && echo "enc kernels ok"
 rm -rf gpurun_out/${P}_mfma/p1 gpurun_out/${P}_pmc_enc/p1 gpurun_out/${P}_pmc_enc/p2 gpurun_out/${P}_pmc_enc/p3 gpurun_out/${P}_enc_traffic/p1 gpurun_out/${P}_enc_traffic/p2
 ls -la gpurun_out | grep ${P}_ | head -30
