@@ -788,6 +788,192 @@ __global__ __launch_bounds__(64) void swin_window_attn_kernel(
   for (int c = 0; c < kD; c += 4)
     *reinterpret_cast<float4*>(o + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
 }
+
+// The same attention core on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products, 64 FLOP / clk / SIMD)
+// -- the shipped form.  Why: in the per-lane form above every lane walks all 49 keys, i.e. 16 broadcast
+// ds_read_b128 per key and wave -- 6.4 k cycles of the CU's ONE LDS pipe per wave, which bounds that form while the
+// vector and matrix pipes idle (packed FMAs changed nothing, scalar loads of the wave-uniform K / V rows are one L2
+// round trip per key: DESIGN.md section 9).  Here the window's 49 tokens are padded to 64 and the wave computes
+//   S^T [key, query] = K Q^T   (2 x 2 tiles of 32 x 32, 16 K-steps: 64 MFMAs.  Step s contracts channel s -- supplied
+//                               by the lanes of half 0 -- and channel 16 + s -- half 1 --, so lane (row r, half)
+//                               needs 16 CONSECUTIVE channels of its two tokens' q and k: four float4 loads per
+//                               row straight into registers, no staging, no LDS read in the loop)
+// -- TRANSPOSED, so that a query's scores lie along the accumulator's ROW axis: lane (query, half) holds 32 of its
+// 64 keys in registers, the other half-wave the rest, and max / sum are 31 in-lane operations and one cross-half
+// exchange.  The probabilities never leave the registers: the accumulator layout of S^T (lane = query column,
+// register r of key tile kt = key 32 kt + 8 (r / 4) + 4 half + r % 4) IS a B operand of
+//   O^T [channel, query] = V^T P^T  (K axis = keys, taken in exactly that register order: step (kt, r) contracts
+//                                    the keys 32 kt + 8 (r / 4) + r % 4 (half 0) and + 4 (half 1); the A operand
+//                                    reads V [that key][channel = lane % 32] from LDS, the only staged tensor)
+// 64 more MFMAs.  Relative-position bias (all 32 values of a lane requested before the first is used), shift mask
+// (regions of the 64 tokens in LDS) and -inf for the 15 pad keys are added to the S^T registers; outputs are four
+// float4 stores per lane and query tile.  9.5 KB of LDS, 158 + 64 registers: two waves per SIMD.
+// tools/swin_attn_ab.py, 3 frames of 800 x 1344, us per launch (per-lane form -> this): stage 1 267 -> 221,
+// stage 2 149 -> 117, stage 3 75.6 -> 60.4, stage 4 46.3 -> 35.5.  (Built and measured on the way: Q / K / V all
+// staged in LDS, a lane per token: 253 / 136 / 77 / 43; the same with 8 lanes per 128-byte piece and the output
+// transposed through LDS: 317 / 165 / 84 / 47; bounded to three waves per SIMD: 36 bytes of scratch, 244 / 129 /
+// 63 / 38.)
+template <int WS>
+__global__ __launch_bounds__(64) void swin_window_attn_mfma_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ bias_t, const float* __restrict__ pad_qkv,
+    float* __restrict__ out, const int B, const int H, const int W, const int C, const int heads,
+    const int shift, const float scale) {
+  constexpr int N = WS * WS;
+  static_assert(N <= 64, "one wave per window");
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(16))) float vs[64 * kPad];
+  __shared__ int regs[64];
+  const int lane = threadIdx.x;
+  const int r32 = lane & 31, hf = lane >> 5;
+  const int nwx = (W + WS - 1) / WS, nwy = (H + WS - 1) / WS;
+  const int Hp = nwy * WS, Wp = nwx * WS;
+  int bid = blockIdx.x;
+  const int h = bid % heads;
+  bid /= heads;
+  const int wx = bid % nwx;
+  bid /= nwx;
+  const int wy = bid % nwy;
+  const int b = bid / nwy;
+  // token `t` of the window: source pixel (the roll by -shift), pad flag, roll region
+  auto token = [&](const int t, bool& real, int& reg) -> long long {
+    const int iy = t / WS, ix = t - iy * WS;
+    const int ys = wy * WS + iy, xs = wx * WS + ix;
+    int y = ys + shift, x = xs + shift;
+    if (y >= Hp) y -= Hp;
+    if (x >= Wp) x -= Wp;
+    real = t < N && y < H && x < W;
+    reg = 0;
+    if (shift > 0) {
+      const int rh = ys < Hp - WS ? 0 : (ys < Hp - shift ? 1 : 2);
+      const int rw = xs < Wp - WS ? 0 : (xs < Wp - shift ? 1 : 2);
+      reg = rh * 3 + rw;
+    }
+    return ((long long)b * H + y) * W + x;
+  };
+  // V of token `lane` (zeros for the 15 pad slots of the 64-token tile) and its roll region go to LDS; the Q and K
+  // operands come straight from the rows: K-step s of S^T contracts channel s (supplied by the lanes of half 0)
+  // and channel 16 + s (half 1), so lane (row r, half) needs 16 CONSECUTIVE channels of its two tokens' q and k
+  // -- four float4 loads per row, nothing staged, no LDS read in the loop
+  float qr[2][16], kr[2][16];
+  {
+    bool real;
+    int reg;
+    const long long pix = token(lane, real, reg);
+    const float* row = (real ? qkv + pix * 3 * C : pad_qkv) + 2 * C + h * kD;
+    const float on = lane < N ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < kD; c += 4) {
+      float4 tv = *reinterpret_cast<const float4*>(row + c);
+      tv.x *= on, tv.y *= on, tv.z *= on, tv.w *= on;
+      *reinterpret_cast<float4*>(vs + lane * kPad + c) = tv;
+    }
+    regs[lane] = reg;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 32 * tt + r32;
+      const long long px = token(t, real, reg);
+      const float* rq = (real ? qkv + px * 3 * C : pad_qkv) + h * kD + 16 * hf;
+      const float onq = t < N ? 1.f : 0.f, qscale = onq * scale;
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) {
+        const float4 tq = *reinterpret_cast<const float4*>(rq + c);
+        const float4 tk = *reinterpret_cast<const float4*>(rq + C + c);
+        qr[tt][c] = tq.x * qscale, qr[tt][c + 1] = tq.y * qscale, qr[tt][c + 2] = tq.z * qscale, qr[tt][c + 3] = tq.w * qscale;
+        kr[tt][c] = tk.x * onq, kr[tt][c + 1] = tk.y * onq, kr[tt][c + 2] = tk.z * onq, kr[tt][c + 3] = tk.w * onq;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- S^T = K Q^T
+  f16v st[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[a][q][r] = 0.f;
+#pragma unroll
+  for (int sstep = 0; sstep < kD / 2; ++sstep) {
+    st[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[0][sstep], qr[0][sstep], st[0][0], 0, 0, 0);
+    st[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[0][sstep], qr[1][sstep], st[0][1], 0, 0, 0);
+    st[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[1][sstep], qr[0][sstep], st[1][0], 0, 0, 0);
+    st[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[1][sstep], qr[1][sstep], st[1][1], 0, 0, 0);
+  }
+  // ---- bias, mask, softmax over the keys of each query column (qt: the lane's query 32 qt + r32)
+  float inv[2];
+  const float pen = shift > 0 ? -100.f : 0.f;      // (without a shift every token is in region 0)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int query = 32 * qt + r32;
+    const bool qok = query < N;
+    const int regq = regs[query];
+    const float* bt = bias_t + (long long)h * N * N + (qok ? query : 0);
+    // (all 32 bias values of the lane requested before the first is used: the loads are unconditional -- a pad
+    // key reads the last row and is overwritten with -inf below -- so that they are ONE round trip, not 32)
+    float bv[2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + 8 * (r >> 2) + 4 * hf + (r & 3);
+        bv[kt][r] = bt[(key < N ? key : N - 1) * N];
+      }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + 8 * (r >> 2) + 4 * hf + (r & 3);
+        float d = st[kt][qt][r] + bv[kt][r];
+        d += regs[key] != regq ? pen : 0.f;
+        d = key < N ? d : -INFINITY;
+        st[kt][qt][r] = d;
+        m = fmaxf(m, d);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(st[kt][qt][r] - m);
+        st[kt][qt][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32, 64);
+    inv[qt] = 1.f / l;
+  }
+  // ---- O^T = V^T P^T
+  f16v ot[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[q][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * kt + 8 * (r >> 2) + 4 * hf + (r & 3);
+      const float a = vs[key * kPad + r32];
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[kt][0][r], ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[kt][1][r], ot[1], 0, 0, 0);
+    }
+  // ---- the lane's two queries: channels 8 g + 4 half + 0 .. 3 of register group g (through LDS to whole
+  // 128-byte pieces measured slower: 253 -> 317 us at stage 1)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    bool real;
+    int reg;
+    const long long pix = token(32 * qt + r32, real, reg);
+    if (!real) continue;           // pad slot or pad token: attended to by its window, never written back
+    float* o = out + pix * C + h * kD + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(o + 8 * g) =
+          make_float4(ot[qt][4 * g] * inv[qt], ot[qt][4 * g + 1] * inv[qt], ot[qt][4 * g + 2] * inv[qt],
+                      ot[qt][4 * g + 3] * inv[qt]);
+  }
+}
 }  // namespace
 
 extern "C" int pave_swin_window_attn_f32(const float* qkv, const float* bias_t, const float* pad_qkv, float* out,
@@ -800,9 +986,14 @@ extern "C" int pave_swin_window_attn_f32(const float* qkv, const float* bias_t, 
   if (shift < 0 || shift >= window) return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: 0 <= shift < window");
   const long long nb = (long long)B * ((H + window - 1) / window) * ((W + window - 1) / window) * heads;
   if (nb >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "swin_window_attn: grid too large");
-  hipLaunchKernelGGL((swin_window_attn_kernel<7>), dim3((unsigned)nb), dim3(64), 0,
-                     reinterpret_cast<hipStream_t>(stream), qkv, bias_t, pad_qkv, out, B, H, W, C, heads, shift,
-                     scale);
+  if (pave_internal_diag_variant() == 18)   // the per-lane form (tests compare the two)
+    hipLaunchKernelGGL((swin_window_attn_kernel<7>), dim3((unsigned)nb), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), qkv, bias_t, pad_qkv, out, B, H, W, C, heads, shift,
+                       scale);
+  else
+    hipLaunchKernelGGL((swin_window_attn_mfma_kernel<7>), dim3((unsigned)nb), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), qkv, bias_t, pad_qkv, out, B, H, W, C, heads, shift,
+                       scale);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -557,6 +557,8 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // 13 / 14 = LayerNorm-epilogue GEMM: always the 8-wave / the wide form,
                          // 8 = LDS-DMA generation without its wide tile form, 7 = wide
                          // tile form wherever it applies (default: from 512 tiles up),
+                         // 18 = Swin window attention on the per-lane (LDS broadcast) form instead of the
+                         // fp32-MFMA form (pave_decoder.hip),
                          // 15 / 16 = two row tiles per wave (256-row blocks) for the 64- / 96-column
                          // tile forms and the ResNet layer1 chain: never / wherever the form exists,
                          // 17 = no half-tail form (33 .. 48 output columns of a 3x3 as zero-padded 32x32x16

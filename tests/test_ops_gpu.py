@@ -346,6 +346,14 @@ def test_swin_window_attention_kernel_vs_reference_formulation(B, H, W, heads, s
         bt = bt.permute(2, 1, 0).contiguous().float()
     got = ops.swin_window_attn(qkv.cuda(), bt.cuda(), m.w_msa.qkv.bias.float().cuda(), heads, 7, shift, m.w_msa.scale)
     np.testing.assert_allclose(got.view(B, H * W, C).cpu().numpy(), exp.numpy(), rtol=2e-4, atol=2e-5)
+    # the shipped form runs the two products on the fp32 matrix pipe; the per-lane form (diag variant 18) must
+    # agree with it up to the summation order
+    from pavenet_amd import native
+    with native.diag_build(18):
+        lanes = ops.swin_window_attn(qkv.cuda(), bt.cuda(), m.w_msa.qkv.bias.float().cuda(), heads, 7, shift,
+                                     m.w_msa.scale)
+    np.testing.assert_allclose(got.cpu().numpy(), lanes.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lanes.view(B, H * W, C).cpu().numpy(), exp.numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_gemm_gelu_epilogue_and_wide_layernorm_rows():
