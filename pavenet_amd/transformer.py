@@ -490,6 +490,11 @@ class VideoPoseTransformerMulFrames(Transformer):
         output_proposals = output_proposals.masked_fill(~valid, float('inf'))
         if memory_padding_mask is None and memory.is_cuda and not torch.is_grad_enabled():
             geom.unpadded[('proposals', N)] = (output_proposals, valid)
+            # (the very first call takes the same launches as every later one: the per-clip Linear + LayerNorm and the
+            # batch-wide one may pick different LayerNorm-epilogue forms, which differ in the last bits)
+            filled = self._output_memory_filled(memory, valid, geom) if self.fused_proposal_stage else None
+            if filled is not None:
+                return filled, output_proposals
         output_memory = memory
         if memory_padding_mask is not None:
             output_memory = output_memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
