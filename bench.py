@@ -25,6 +25,11 @@ region: achieved = sum of FLOP / sum of launch times against the dense bf16 MFMA
 ``roofline_hbm`` is the encoder deformable-attention launch (the dominant HBM-bound kernel) measured
 the same way; ``cpu_baseline`` is the CPU oracle (a port of the reference's CPU path) timed on rank 0
 at N = 1 on a bounded sample; ``parity`` compares clip 0 of the timed batch with that oracle run.
+``roofline.clock`` is the in-kernel clock of that class (delta s_memtime / delta s_memrealtime around sampled
+workgroups, taken on the -DPAVE_DIAG build of the same sources in a pass of its own after the timed region) and
+``frac_of_sustained_clock_peak`` the same achieved figure against the MFMA peak AT that clock;
+``fallback_ops_per_step`` / ``aten_launches_per_step`` are a census of the ATen operators one extra, un-timed step
+executed on device tensors (pavenet_amd/census.py): a non-zero fallback count means a gate left the hand-written path.
 """
 import argparse
 import hashlib
@@ -207,6 +212,57 @@ def algorithmic_bytes_encoder_launch(n_frames):
     return 4 * n_frames * S_TOKENS * (256 + 8 * 16 * 3 + 256)
 
 
+def census_of_step(model, img, metas, **kw):
+    """One extra, un-timed forward under pavenet_amd.census.LaunchCensus (the caches are warm: it runs after the
+    timed steps): which ATen operators still ran on device tensors."""
+    from pavenet_amd.census import LaunchCensus
+    with torch.no_grad(), LaunchCensus() as c:
+        model.forward_device(img, metas, **kw)
+    torch.cuda.synchronize()
+    d = c.summary()
+    return dict(fallback_ops_per_step=d['fallback_ops'], fallback_op_names=d['fallback_op_names'],
+                aten_launches_per_step=d['aten_launches'], aten_launch_names=d['aten_launch_names'],
+                host_syncs=d['host_syncs'], slow_paths=d['slow_paths'])
+
+
+CLOCK_KINDS = ('gemm_q', 'gemm_w', 'gemm_wn', 'gemm_wn_enc', 'bottleneck_chain', 'gemm_q_ln', 'gemm_w_ln', 'stem7x7')
+
+
+def class_clock_pass(run_step, steps=3):
+    """The in-kernel clock of the split GEMM class under THIS workload (MI355X_MICROARCH.md, 'DVFS give-back' item 6):
+    `steps` more steps on the -DPAVE_DIAG build of the same sources, whose GEMM / convolution kernels stamp
+    s_memtime (shader clock) and s_memrealtime (100 MHz) around every 64th workgroup; clock = sum of shader ticks /
+    sum of 100 MHz ticks x 100 MHz, over the class and per kernel.  Runs after the timed region (the chip has been
+    under this load for seconds); the shipped library executes no stamp."""
+    import ctypes
+    from pavenet_amd import native
+    try:
+        with native.diag_build() as lib:
+            lib.pave_diag_clock_reset.restype = ctypes.c_int
+            lib.pave_diag_clock_read.restype = ctypes.c_int
+            lib.pave_diag_clock_read.argtypes = [ctypes.c_void_p]
+            run_step()                       # (first launches of the other binary: code objects load here)
+            torch.cuda.synchronize()
+            if lib.pave_diag_clock_reset() != 0:
+                return dict(error='pave_diag_clock_reset failed')
+            for _ in range(steps):
+                run_step()
+            buf = (ctypes.c_ulonglong * 16)()
+            if lib.pave_diag_clock_read(ctypes.cast(buf, ctypes.c_void_p)) != 0:
+                return dict(error='pave_diag_clock_read failed')
+    except Exception as e:      # a measurement aid must not cost the line
+        return dict(error=f'{type(e).__name__}: {e}'[:200])
+    tot_s = sum(buf[2 * k] for k in range(8))
+    tot_r = sum(buf[2 * k + 1] for k in range(8))
+    if tot_r == 0:
+        return dict(error='no stamped workgroup ran')
+    by = {CLOCK_KINDS[k]: round(buf[2 * k] / buf[2 * k + 1] * 100.0, 1) for k in range(8) if buf[2 * k + 1]}
+    return dict(sustained_clock_mhz=round(tot_s / tot_r * 100.0, 1), by_kernel_mhz=by, nominal_mhz=2400,
+                measured='delta s_memtime / delta s_memrealtime x 100 MHz around every 64th workgroup of the class\'s '
+                         f'kernels, summed over {steps} steps of this workload on the -DPAVE_DIAG build '
+                         '(time-weighted over the class), after the timed region')
+
+
 def clip0_image(args, frames):
     """Clip 0 of rank 0 is generated on the host (seed 0) so that the CPU oracle and the device
     path see the same frames."""
@@ -271,7 +327,7 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     return base, parity
 
 
-def secondary_workloads(args, dev, budget_s=100.0):
+def secondary_workloads(args, dev, budget_s=110.0):
     """The other BASELINE configurations on the driver's clock (`extra` of the JSON line): short
     single-stream runs -- 3 warm-up + 10 timed steps each, results copied to the host per step as in
     the headline, the split-GEMM class timed by HIP events over the last 3 steps -- of configs[1]
@@ -287,18 +343,24 @@ def secondary_workloads(args, dev, budget_s=100.0):
     # 750 x 1333 images in the 800 x 1344 batch, configs/_base_/datasets/coco_keypoint.py:79): two runs of clips
     # with their own masks, positional tables and valid ratios
     pad = [(args.height, args.width - 11)] * 2 + [(args.height - 50, args.width - 11)] * 2
-    todo = [('configs[2] as a padded batch (img_shape 2 x 800x1333, 2 x 750x1333)', 'r50', 7, 4, 'bf16x3', pad),
-            ('configs[1]', 'r50', 3, 1, 'bf16x3', None),
-            ('configs[3] on one GPU', 'hrnet_w48', 7, 4, 'bf16x3', None),
-            ('configs[4] shape on one GPU', 'r50', 15, 1, 'bf16x3', None),
-            ('configs[4] shape on one GPU, fp16-operand projections', 'r50', 15, 1, 'fp16', None),
+    todo = [('configs[2] as a padded batch (img_shape 2 x 800x1333, 2 x 750x1333)', 'r50', 7, 4, 'bf16x3', pad, None),
+            ('configs[1]', 'r50', 3, 1, 'bf16x3', None, None),
+            # the canvas the reference's own video test pipeline produces: keep-ratio resize to (1333, 800) and
+            # Pad(size_divisor=1), i.e. NO padding -- a 1080p frame is a 750 x 1333 batch, odd width
+            # (configs/_base_/datasets/posetrack17_video_keypoint.py:68-84)
+            ('configs[1] on the reference\'s PoseTrack test canvas (750x1333, size_divisor=1)', 'r50', 3, 1, 'bf16x3',
+             None, (750, 1333)),
+            ('configs[3] on one GPU', 'hrnet_w48', 7, 4, 'bf16x3', None, None),
+            ('configs[4] shape on one GPU', 'r50', 15, 1, 'bf16x3', None, None),
+            ('configs[4] shape on one GPU, fp16-operand projections', 'r50', 15, 1, 'fp16', None, None),
             # the reference's flagship backbone (configs/videopose/2025-2-7/2025_2_7_swin_num_frames_3_posetrack17.py)
-            ('Swin-L T=3 (the reference\'s 2025-2-7 config)', 'swin_l', 3, 1, 'bf16x3', None)]
+            ('Swin-L T=3 (the reference\'s 2025-2-7 config)', 'swin_l', 3, 1, 'bf16x3', None, None)]
     out, t_begin, model, key = [], time.perf_counter(), None, None
     steps, warmup, ev_steps = 10, 3, 3
-    for name, backbone, T, B, gemm, shapes in todo:
+    for name, backbone, T, B, gemm, shapes, canvas in todo:
         bname = {'r50': 'R-50', 'hrnet_w48': 'HRNet-w48', 'swin_l': 'Swin-L'}[backbone]
-        label = f'{name}: PAVE-Net {bname} T={T}, batch={B} clips, {args.height}x{args.width}, gemm={gemm}'
+        H_, W_ = canvas if canvas is not None else (args.height, args.width)
+        label = f'{name}: PAVE-Net {bname} T={T}, batch={B} clips, {H_}x{W_}, gemm={gemm}'
         if time.perf_counter() - t_begin > budget_s:
             out.append(dict(workload=label, skipped=f'secondary budget of {budget_s:.0f} s used up'))
             continue
@@ -314,11 +376,10 @@ def secondary_workloads(args, dev, budget_s=100.0):
             model = init_random_weights(build_model(mcfg), seed=0).to(dev).eval()
             key = (backbone, T)
         set_gemm_mode(gemm)
-        metas = [dict(batch_input_shape=(args.height, args.width),
-                      img_shape=(shapes[i] if shapes else (args.height, args.width)) + (3,),
+        metas = [dict(batch_input_shape=(H_, W_), img_shape=(shapes[i] if shapes else (H_, W_)) + (3,),
                       scale_factor=(1., 1., 1., 1.)) for i in range(B)]
         g = torch.Generator(device=dev).manual_seed(4321)
-        img = torch.randn(B, T, 3, args.height, args.width, device=dev, generator=g)
+        img = torch.randn(B, T, 3, H_, W_, device=dev, generator=g)
         host = None
         tail, tail_note = None, 'off'
         use_tail = [False]
@@ -389,6 +450,10 @@ def secondary_workloads(args, dev, budget_s=100.0):
         else:
             rec.update(bound='mfma', peak_tflops=round(peak, 1),
                        frac=round(fl / tt / 1e12 / peak, 4) if tt > 0 else None)
+        try:
+            rec.update(census_of_step(model, img, metas))
+        except Exception as e:
+            rec['census_error'] = f'{type(e).__name__}: {e}'[:200]
         if tail is not None:
             # the same workload with everything behind the encoder replayed as ONE hipGraph (TailGraphedForward)
             use_tail[0] = True
@@ -429,11 +494,10 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    # let MIOpen time its solvers per convolution shape once (during warm-up) instead of
-    # trusting the immediate-mode heuristic of a cold find-db.  Only where MIOpen carries weight:
-    # in the headline mode one small neck convolution is left on it, and N ranks searching (and
-    # writing the user find-db) at once buys nothing
-    torch.backends.cudnn.benchmark = world == 1 or args.gemm == 'native'
+    # MIOpen's per-shape solver search only where MIOpen runs at all: the vendor-kernel modes (the headline mode
+    # launches no library convolution -- `fallback_ops_per_step` on the line says so; the `native_fp32_mfma` side
+    # measurement switches the search on for its own steps)
+    torch.backends.cudnn.benchmark = args.gemm == 'native'
     dev = torch.device('cuda', local_rank)
     dist = None
     host_collectives = False
@@ -462,6 +526,13 @@ def main():
         ranks_seen = [int(v) for v in seen.cpu().tolist()]
         devices = [None] * world
         dist.all_gather_object(devices, f'cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}')
+        # the job is what the line will say it is: every rank 0 .. world-1 present exactly once, and -- outside the
+        # one-device rehearsal mode -- every rank on a device of its own (every rank sees the same lists, so all of
+        # them leave together; the reference's launcher gives rank i GPU i: tools/dist_test.sh:8-10)
+        if sorted(ranks_seen) != list(range(world)):
+            raise SystemExit(f'bench.py: rank census {ranks_seen} is not a permutation of 0..{world - 1}')
+        if not one_device and len(set(d.split(' ')[0] for d in devices)) != world:
+            raise SystemExit(f'bench.py: {world} ranks but the devices are not pairwise distinct: {devices}')
 
     from pavenet_amd import ops
     from pavenet_amd.models import build_model, videopose_r50_cfg
@@ -605,6 +676,8 @@ def main():
                 ev.synchronize()
         return out
 
+    RANK_DT = []     # per-rank wall time of the last timed region (N > 1)
+
     def timed(record_events, P=None):
         P = max(1, args.pipeline) if P is None else P
         run_steps(args.warmup, P)
@@ -628,6 +701,9 @@ def main():
         ops.KERNEL_EVENTS = ops.KERNEL_EVENT_SHAPES = None
         if dist is not None:
             tt = torch.tensor([dt], device='cpu' if host_collectives else dev, dtype=torch.float64)
+            every = torch.empty((world,), device=tt.device, dtype=torch.float64)
+            dist.all_gather_into_tensor(every, tt)         # each rank's own clock: a straggler shows on the line
+            RANK_DT[:] = [float(v) for v in every.cpu().tolist()]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, ev, out
@@ -637,11 +713,14 @@ def main():
         # the same workload on the vendor fp32-MFMA kernels, printed beside the headline
         set_gemm_mode('native')
         TAIL_ON[0] = False          # (the captured tail holds the headline mode's kernels)
+        torch.backends.cudnn.benchmark = True       # (MIOpen times its solvers once, during this leg's warm-up)
         native_dt, _, _ = timed(False)
+        torch.backends.cudnn.benchmark = False
         TAIL_ON[0] = True
         set_gemm_mode(args.gemm)
     dt, events, last = timed(True)
     last = last.clone()     # (the pinned result buffer is reused by later runs)
+    rank_dt = list(RANK_DT)
     ev_steps_main = (min(3, args.steps) if (graphed is None and not args.no_events) else 0)
     pipe_dt = None
     if args.pipeline == 1 and world == 1 and graphed is None and not args.no_native_side:
@@ -650,6 +729,16 @@ def main():
         TAIL_ON[0] = False
         pipe_dt, _, _ = timed(False, 2)
         TAIL_ON[0] = True
+    # un-timed passes behind the timed regions, on every rank (the steps hold the job's collectives):
+    # (a) the ATen-operator census of one forward, (b) the class's in-kernel clock on the diagnostic build
+    census = None
+    try:
+        census = census_of_step(model, img, metas, **(dict(frame_shard=shard) if shard is not None else {}))
+    except Exception as e:
+        census = dict(census_error=f'{type(e).__name__}: {e}'[:200])
+    clock = None
+    if args.gemm != 'native' and graphed is None and tail_graph is None and not args.no_events:
+        clock = class_clock_pass(lambda: step())
     timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl, _ in events]
     shaped_ev = [(tag, s.elapsed_time(e) * 1e-3, fl, sh) for tag, s, e, fl, sh in events]
     enc = [(tag, t) for tag, t, _ in timed_ev if tag in ('enc_tile', 'enc_grid_T1')]
@@ -705,6 +794,20 @@ def main():
                 avg_us=round(gv[1] / gv[0] * 1e6, 1), ms_per_step=round(gv[1] / max(1, ev_steps_main) * 1e3, 3),
                 achieved=round(gv[2] / gv[1] / 1e12, 1), peak=round(peak, 1), unit='TFLOP/s',
                 frac=round(gv[2] / gv[1] / 1e12 / peak, 4))
+        if clock is not None:
+            roofline_mfma['clock'] = clock
+            mhz = clock.get('sustained_clock_mhz')
+            if mhz:
+                # "bound by power" as a number on this line: the class's own clock under this workload, and the same
+                # achieved TFLOP/s against the MFMA peak AT that clock (peak x clock / 2400 MHz)
+                roofline_mfma['sustained_clock_mhz'] = mhz
+                roofline_mfma['frac_of_sustained_clock_peak'] = round(tot_f / tot_t / 1e12 / (peak * mhz / 2400.0), 4)
+                dk = roofline_mfma.get('dominant_kernel')
+                dmhz = clock['by_kernel_mhz'].get('gemm_w' if (dk and 'gemm_w_kernel' in dk.get('kernel', ''))
+                                                  else 'gemm_w_ln')
+                if dk and dmhz:
+                    dk['sustained_clock_mhz'] = dmhz
+                    dk['frac_of_sustained_clock_peak'] = round(dk['achieved'] / (peak * dmhz / 2400.0), 4)
         sm = [(t, fl) for tag, t, fl in timed_ev if tag in SMALL_GEMM_TAGS]
         if sm:
             st_, sf_ = sum(t for t, _ in sm), sum(fl for _, fl in sm)
@@ -759,12 +862,21 @@ def main():
                                          f'batch={B} clips{"" if frame_sharded else "/GPU"}, '
                                          f'{args.height}x{args.width}, Q=300, K=15, '
                                          f'max_per_img={N}, fwd simple_test incl. OKS-NMS',
-                                parallelism=unit_note, gemm=args.gemm,
-                                gemm_select=args.gemm_select, tail_graph=tail_note,
+                                parallelism=unit_note, gemm=args.gemm, tail_graph=tail_note,
                                 detections_last_step=int(last[..., -N:].sum().item())),
                     backend=backend, ranks_seen=ranks_seen, devices=devices,
                     roofline=roofline_mfma if roofline_mfma is not None else roofline,
                     roofline_hbm=roofline)
+        if args.gemm == 'native':      # (the only mode that runs TunableOp-selected vendor GEMMs)
+            line['config']['gemm_select'] = args.gemm_select
+        if census is not None:
+            line.update(census)
+        if rank_dt:
+            line['rank_ms_per_step'] = dict(min=round(min(rank_dt) / args.steps * 1e3, 3),
+                                            max=round(max(rank_dt) / args.steps * 1e3, 3),
+                                            by_rank=[round(v / args.steps * 1e3, 3) for v in rank_dt],
+                                            note='each rank\'s own wall clock over the timed region; `ms_per_step` '
+                                                 'is the max')
         if args.pipeline > 1:
             line['config']['pipeline'] = f'{args.pipeline} steps in flight on {args.pipeline} HIP streams'
         if pipe_dt is not None:
@@ -778,6 +890,7 @@ def main():
         if native_dt is not None:
             line['native_fp32_mfma'] = dict(value=round(clips / native_dt, 4), unit='clips/s',
                                             ms_per_step=round(native_dt / args.steps * 1e3, 3),
+                                            gemm_select=args.gemm_select,
                                             note='same run, same inputs, --gemm native (vendor '
                                                  'fp32-MFMA GEMM / convolution kernels)')
         if args.backbone == 'r50' and (args.height, args.width) == (800, 1344):

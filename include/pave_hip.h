@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 18
+#define PAVE_ABI_VERSION 19
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -581,9 +581,22 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
  * y [N, Ho, Wo, 64] NHWC, Ho = (H - 1) / 2 + 1.
  * nplanes = PAVE_PLANES_FP16: w_planes = [23][1][64][16] fp16 (the same two layouts, one plane); only the
  * LDS-window kernel exists for it (W %% 4 == 0, x 16-byte aligned; PAVE_E_UNSUPPORTED otherwise).
+ * row_pitch (ABI 19): elements between two image rows (0 or W: dense rows).  row_pitch > W is the layout
+ * pave_repitch_rows_f32 writes: row_pitch %% 4 == 0, x 16-byte aligned, columns W .. row_pitch - 1 of every row
+ * ZERO (they are the convolution's right-hand zero padding) -- an image of ANY width, e.g. the 750 x 1333 frames
+ * of the reference's PoseTrack test pipeline (configs/_base_/datasets/posetrack17_video_keypoint.py:68-81,
+ * size_divisor = 1), then takes the LDS-window kernel; Wo = (W - 1) / 2 + 1 is that of the real width.
  */
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                                  int N, int H, int W, int Cout, int relu, int nplanes, void* stream);
+                                  int N, int H, int W, int row_pitch, int Cout, int relu, int nplanes,
+                                  void* stream);
+
+/*
+ * dst[r, 0:W] = src[r, 0:W], dst[r, W:pitch] = 0 for r < rows: dense fp32 rows re-laid at a row pitch that is a
+ * multiple of 4 elements (16-byte aligned rows for the LDS-DMA stem above).  pitch %% 4 == 0, pitch >= W, dst
+ * 16-byte aligned, src any alignment; one pass, ~2 x the image bytes.
+ */
+int pave_repitch_rows_f32(const float* src, float* dst, long long rows, int W, int pitch, void* stream);
 
 /*
  * The (shifted-)window multi-head self-attention core of a Swin block -- ShiftWindowMSA.forward around

@@ -208,11 +208,13 @@ class ResNet(BaseModule):
                 or x_nchw.dtype != torch.float32 or tuple(w.shape) != (64, 3, 7, 7) \
                 or x_nchw.shape[1] != 3 or x_nchw.shape[3] < 8 or not x_nchw.is_contiguous():
             return None
-        if get_gemm_mode() == 'fp16' and (x_nchw.shape[3] % 4 or x_nchw.data_ptr() % 16):
-            # (the fp16 stem exists as the LDS-window kernel only: odd widths take the exact planes)
-            wp = _split_cached(w, 'stem7x7_x3', lambda planes: ops.split_stem7x7_weight(w.detach(), 3))
-        else:
-            wp = _split_cached(w, 'stem7x7', lambda planes: ops.split_stem7x7_weight(w.detach(), planes))
+        wp = _split_cached(w, 'stem7x7', lambda planes: ops.split_stem7x7_weight(w.detach(), planes))
+        if x_nchw.shape[3] % 4 or x_nchw.data_ptr() % 16:
+            # a width off the 4-pixel grid (the reference's PoseTrack pipeline pads with size_divisor = 1: 750 x 1333
+            # frames) or an unaligned view: the rows are re-laid once at a 16-byte aligned pitch with zero pad
+            # columns -- the convolution's own right-hand padding -- and the LDS-window kernel reads that (one copy
+            # of the 3-channel image instead of the per-lane window-load kernel: the stem is 60 x the image's FLOPs)
+            return ops.conv7x7s2_nchw_split(ops.repitch_rows(x_nchw), wp, valid_w=x_nchw.shape[3])
         return ops.conv7x7s2_nchw_split(x_nchw, wp)
 
     @staticmethod

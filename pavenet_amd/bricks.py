@@ -369,7 +369,7 @@ def linear_rows(x2, weight, bias=None, relu=False, residual=None, inplace_residu
     return torch.relu_(y) if relu else y
 
 
-def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False, pos_rows=None):
+def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=False, pos_rows=None, out=None):
     """(x @ W^T + b + identity) [-> LayerNorm], batch-first tensors [..., C].
 
     Device fp32: the residual rides the GEMM (beta = 1, C = identity) and bias + LayerNorm are
@@ -386,9 +386,13 @@ def linear_residual_norm(x_bf, linear, identity_bf, post_norm=None, inplace=Fals
                 and linear.weight.shape[1] % 64 == 0
                 and (split_gemm_ok(x2, linear.weight) or small_split_ok(x2, linear.weight))):
             # Linear + bias + residual + LayerNorm as ONE launch (the block tile owns whole rows)
+            # (out: a dense [.., 256] buffer of the caller's -- a level of a decoder's preallocated stack of
+            # intermediate states -- written by this launch instead of a fresh tensor; other paths ignore it)
+            dst = out.view(-1, C_out) if (out is not None and out.is_contiguous() and out.numel() == idt2.numel()
+                                          and out.dtype == torch.float32 and out.device == idt2.device) else None
             t = ops.gemm_bf16x3_ln(x2, _split_weight(linear.weight, x2.shape[0]), linear.bias, idt2,
                                    post_norm.weight, post_norm.bias, post_norm.eps,
-                                   out=idt2 if inplace else None)
+                                   out=dst if dst is not None else (idt2 if inplace else None))
             return t.view(identity_bf.shape)
         if split_gemm_ok(x2, linear.weight):
             t = linear_rows(x2, linear.weight, None, residual=idt2, inplace_residual=inplace)
@@ -538,7 +542,7 @@ class FFN(BaseModule):
                 and _fusable(x) and x.dim() == 3)
 
     def forward(self, x, identity=None, post_norm=None, inplace_residual=False, carry=None,
-                query_pos=None):
+                query_pos=None, out=None):
         """carry (dict with carry['emit'] = True) + query_pos: also produce out + query_pos in the
         LayerNorm pass and leave it in carry['q_plus'] for the next layer's attention."""
         if identity is None:
@@ -573,7 +577,7 @@ class FFN(BaseModule):
                 elif pb.is_contiguous() and pb.shape == xb.shape:
                     pos_rows = pb.reshape(-1, pb.shape[-1])
             out = linear_residual_norm(h.view(xb.shape[0], xb.shape[1], -1), fc2, ib, post_norm,
-                                       inplace=inplace_residual, pos_rows=pos_rows)
+                                       inplace=inplace_residual, pos_rows=pos_rows, out=out)
             if pos_rows is not None:
                 out, plus = out
                 out = seq_first_view(out)
@@ -801,6 +805,10 @@ class BaseTransformerLayer(BaseModule):
         order = self.operation_order
         skip_norm = False
         carry = kwargs.pop('fusion_carry', None)
+        # layer_out: a dense batch-first [bs, n, C] buffer the layer's LAST launch may write its result into (the
+        # decoders' preallocated stack of intermediate states: no torch.stack copy afterwards); a layer that does
+        # not end in a fused FFN + LayerNorm ignores it -- the caller checks where the result lives
+        layer_out = kwargs.pop('layer_out', None)
         for pos, layer in enumerate(order):
             # post-norm layers: hand the following LayerNorm to a module that can fuse it with
             # its own bias + residual epilogue (one pass instead of three)
@@ -844,6 +852,9 @@ class BaseTransformerLayer(BaseModule):
                 if carry is not None and fuse.get('post_norm') is not None and \
                         pos + 2 == len(order) and isinstance(self.ffns[ffn_index], FFN):
                     fuse = dict(fuse, carry=carry, query_pos=query_pos)
+                if layer_out is not None and fuse.get('post_norm') is not None and pos + 2 == len(order) \
+                        and isinstance(self.ffns[ffn_index], FFN):
+                    fuse = dict(fuse, out=layer_out)
                 query = self.ffns[ffn_index](query, identity if self.pre_norm else None, **fuse)
                 ffn_index += 1
             skip_norm = bool(fuse)

@@ -664,6 +664,8 @@ __global__ __launch_bounds__(256) void merge_softmax_partials_kernel(const float
     const float s = row[C + H + h];
     if (!(s > 0.f)) continue;
     const float w = s * expf(row[C + h] - m);
+    if (!(w > 0.f)) continue;     // a rank whose weight underflows contributes nothing -- not 0 x its row (a
+                                  // non-finite row there would give NaN: the host formulation masks w == 0 too)
     const float4 v = *reinterpret_cast<const float4*>(row + c);
     acc.x = fmaf(v.x, w, acc.x), acc.y = fmaf(v.y, w, acc.y), acc.z = fmaf(v.z, w, acc.z), acc.w = fmaf(v.w, w, acc.w);
     wsum += w;

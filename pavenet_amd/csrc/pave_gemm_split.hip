@@ -924,25 +924,31 @@ int pave_conv1x1_strided_split_f32(const float* x, const void* w_planes, const f
 }
 
 int pave_conv7x7s2_nchw_split_f32(const float* x, const void* w_planes, const float* bias, float* y,
-                                  int N, int H, int W, int Cout, int relu, int nplanes, void* stream) {
+                                  int N, int H, int W, int row_pitch, int Cout, int relu, int nplanes,
+                                  void* stream) {
   if (!x || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: null pointer");
   if (N <= 0 || H <= 0 || W < 8 || (relu != 0 && relu != 1))
     return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: bad sizes (W >= 8; relu 0 | 1)");
+  if (row_pitch == 0) row_pitch = W;
+  if (row_pitch < W || (row_pitch != W && ((row_pitch & 3) || (reinterpret_cast<uintptr_t>(x) & 15))))
+    return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: row_pitch >= W; a pitch beyond W must be a "
+                                          "multiple of 4 on a 16-byte aligned image (pave_repitch_rows_f32)");
   if (Cout != 64)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: Cout == 64 (the ResNet / HRNet stem)");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long M = (long long)N * Ho * Wo;
-  if (M >= (1ll << 31) || (long long)N * 3 * H * W >= (1ll << 40))
+  if (M >= (1ll << 31) || (long long)N * 3 * H * row_pitch >= (1ll << 40))
     return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: tensor too large");
   // w_planes holds two layouts of the same weights (ops.split_stem7x7_weight): 12 slabs
   // (c, ky, kx | pad) for the kernel of this file, then 11 slabs (c, ky, kx + 1) for the LDS-window
   // kernel of pave_gemm_dma.hip, which needs 16-byte aligned image rows
   if (!q_planes(nplanes)) return pave_internal_fail(PAVE_E_ARG, "conv7x7s2_nchw_split: nplanes must be 3 or PAVE_PLANES_FP16");
-  if ((g_diag_variant != 9 || nplanes != 3) && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+  if ((g_diag_variant != 9 || nplanes != 3 || row_pitch != W) && row_pitch % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     return pave_internal_stem7x7_q(x, static_cast<const uint16_t*>(w_planes) + 12 * q_planes(nplanes) * 64 * 16, bias, y,
-                                   N, H, W, relu, stream, q_planes(nplanes));
+                                   N, H, W, row_pitch, relu, stream, q_planes(nplanes));
   if (nplanes != 3)
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: fp16 operands need W %% 4 == 0 and a 16-byte aligned image");
+    return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv7x7s2_nchw_split: fp16 operands need W %% 4 == 0 (or a repitched image) and a 16-byte aligned image");
   const ConvGeom g{H, W, 3, Ho, Wo, 2};
   return launch_gemm<2, 1, false, 3, false, 2, true>(x, static_cast<const uint16_t*>(w_planes), bias,
                                                      nullptr, y, M, 192, Cout, relu, nullptr,

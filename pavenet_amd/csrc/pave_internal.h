@@ -32,5 +32,5 @@ int pave_internal_gemm_f16act(const void* a, int a_f16, const void* w_plane, con
                               const float* gamma, const float* beta, float eps, void* out, int out_f16, long long M,
                               int K, int N, int relu, void* stream);
 int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bias, float* y, int N,
-                            int H, int W, int relu, void* stream, int planes = 3);
+                            int H, int W, int pitch, int relu, void* stream, int planes = 3);
 #endif /* PAVE_INTERNAL_H_ */

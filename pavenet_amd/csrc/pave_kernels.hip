@@ -610,6 +610,26 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ x, c
   }
 }
 
+// dst[r, 0:W] = src[r, 0:W], dst[r, W:pitch] = 0: image rows re-laid at a 16-byte aligned pitch (one lane per
+// 16-byte chunk of dst; the source rows start at any 4-byte boundary, so they are read dword by dword -- the
+// four loads of a lane are consecutive addresses and neighbouring lanes continue them: full lines either way)
+__global__ __launch_bounds__(256) void repitch_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           const long long rows, const int W, const int pitch4) {
+  const long long n4 = rows * pitch4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / pitch4;
+    const int c = 4 * (int)(i - r * pitch4);
+    const float* s = src + r * W + c;
+    float4 v;
+    v.x = c < W ? s[0] : 0.f;
+    v.y = c + 1 < W ? s[1] : 0.f;
+    v.z = c + 2 < W ? s[2] : 0.f;
+    v.w = c + 3 < W ? s[3] : 0.f;
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void bias_act_rows_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ res,
@@ -1710,6 +1730,20 @@ int pave_fill_rows_f32(float* x, long long ld, long long total_rows, const int* 
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      x, ld, rows, n4, C >> 2, total_rows, values);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_repitch_rows_f32(const float* src, float* dst, long long rows, int W, int pitch, void* stream) {
+  if (!src || !dst) return fail(PAVE_E_ARG, "repitch_rows: null pointer");
+  if (rows <= 0 || W <= 0 || pitch < W || (pitch & 3) || (reinterpret_cast<uintptr_t>(dst) & 15))
+    return fail(PAVE_E_ARG, "repitch_rows: pitch >= W, pitch % 4 == 0, dst 16-byte aligned");
+  const long long n4 = rows * (pitch >> 2);
+  long long nb = (n4 + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(repitch_rows_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, dst, rows, W, pitch >> 2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

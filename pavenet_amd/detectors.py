@@ -58,13 +58,35 @@ class VideoPoseV1(BaseModule):
         return x
 
     @torch.no_grad()
-    def forward_device(self, img, img_metas, rescale=False, force_score_topk=None,
+    def forward_device(self, img, img_metas, rescale=False, force_score_topk=None, strict=False,
                        **head_kwargs):
         """img [B, T, 3, H, W] on the device; img_metas: one dict per clip.  Returns the
         head's fixed-shape device result dict (see VideoPoseHeadMulFrames.get_bboxes).
 
         Frame-sharded multi-GPU: pass ``frame_shard=FrameShard(T, rank, world)`` and only the
-        rank's frames, img [B, T_loc, 3, H, W] (frames t with t % world == rank, in order)."""
+        rank's frames, img [B, T_loc, 3, H, W] (frames t with t % world == rank, in order).
+
+        strict=True: the forward runs under ``census.LaunchCensus`` (after one un-counted warm-up of these
+        shapes, which builds the per-shape constant tables) and raises ``census.FallbackError`` if a torch /
+        vendor compute operator (GEMM, convolution, attention, normalisation, pooling, ...) ran on a device
+        tensor, i.e. if a module-level gate dropped off the hand-written path; the census of the last strict
+        call stays in ``self.last_census``."""
+        if strict:
+            from .census import LaunchCensus
+            key = (tuple(img.shape), str(img.device),
+                   tuple((tuple(m['batch_input_shape']), tuple(m['img_shape'][:2])) for m in img_metas),
+                   bool(rescale), force_score_topk is not None, tuple(sorted(head_kwargs)))
+            warm = self.__dict__.setdefault('_strict_warm', set())
+            if key not in warm:
+                self.forward_device(img, img_metas, rescale=rescale, force_score_topk=force_score_topk,
+                                    **head_kwargs)
+                warm.add(key)
+            with LaunchCensus(where=strict == 'where') as census:    # strict='where': record the call sites too
+                res = self.forward_device(img, img_metas, rescale=rescale, force_score_topk=force_score_topk,
+                                          **head_kwargs)
+            self.last_census = census
+            census.raise_on_fallback(f'{type(self).__name__}.forward_device(strict=True)')
+            return res
         feat = self.extract_feat(img)
         head_kwargs.setdefault('last_level_only', True)   # get_bboxes reads [-1] only
         outs = self.bbox_head(feat, img_metas, **head_kwargs)

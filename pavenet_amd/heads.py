@@ -60,7 +60,8 @@ class Linear_with_norm(nn.Module):  # noqa: N801  (reference class name, HEAD:16
 
     def constructor_init(self):
         """The reference's constructor-time initialisation (HEAD:1611: xavier_uniform, gain 0.01), which
-        `init_weights` never redoes: re-applied by weights.init_random_weights after it re-draws the defaults."""
+        `init_weights` never redoes.  weights.init_random_weights(reference_sigma_init=True) re-applies it after
+        re-drawing the defaults (the bench / parity recipe leaves it off: see weights.py)."""
         nn.init.xavier_uniform_(self.linear.weight, gain=0.01)
 
     def forward(self, x):

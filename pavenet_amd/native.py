@@ -47,7 +47,8 @@ SIGNATURES = {
     'pave_groupnorm_nhwc_f32': [_vp] * 4 + [ctypes.c_longlong] + [_c_int] * 4 + [ctypes.c_float, _vp,
                                 _c_int, _vp, _vp],
     'pave_ref_update_f32': [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_float, _vp],
-    'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 6 + [_vp],
+    'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
+    'pave_repitch_rows_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _c_int, _vp],
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
@@ -74,7 +75,7 @@ EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_con
                                 'pave_gemm_splitk_workspace_bytes')
 
 _lib = None
-ABI_VERSION = 18  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 19  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

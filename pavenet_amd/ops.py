@@ -720,8 +720,11 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     # few row tiles and a long K (a one-clip batch's layer4 1x1 reductions, the neck's C5 lateral): the split-K
     # form, as for the 3x3 convolutions (workspace from torch's stream-aware caching allocator)
+    # (a plan exists only for K >= 2048 on fewer than 200 row tiles -- pave_internal_splitk_plan --, so the ~170
+    # K = 256 / 1024 launches of the decoder tail do not pay a library call to learn that)
     ws_bytes = lib.pave_gemm_splitk_workspace_bytes(M, K, N) \
-        if (SPLITK_ROWS and npl in _Q_PLANES and a_bias is None and relu in (False, True, 0, 1)) else 0
+        if (SPLITK_ROWS and K >= 2048 and M < 200 * 128 and npl in _Q_PLANES and a_bias is None
+            and relu in (False, True, 0, 1)) else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'relu' if relu else '', 'res' if residual is not None else '', 'split-K')):
@@ -865,15 +868,34 @@ def split_stem7x7_weight(weight, planes=3):
     return torch.cat([a, b], 0)
 
 
-def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
+def repitch_rows(x):
+    """x [..., W] dense fp32 -> the same rows at a pitch of roundup(W, 4) elements with zero pad columns
+    (pave_repitch_rows_f32): 16-byte aligned rows for the LDS-DMA stem when W % 4 != 0 (the 750 x 1333 frames of
+    the reference's PoseTrack pipeline).  Returns the padded tensor [..., roundup(W, 4)]."""
+    lib = native.load()
+    _dev(x, 'x', torch.float32)
+    W = x.shape[-1]
+    pitch = (W + 3) // 4 * 4
+    out = torch.empty(tuple(x.shape[:-1]) + (pitch,), dtype=torch.float32, device=x.device)
+    rows = x.numel() // W
+    with torch.cuda.device(x.device):
+        st = lib.pave_repitch_rows_f32(x.data_ptr(), out.data_ptr(), rows, W, pitch, _stream_ptr())
+    native.check(st, 'repitch_rows')
+    return out
+
+
+def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False, valid_w=None):
     """7x7 / stride 2 / pad 3 stem convolution of the NCHW image batch x [N, 3, H, W] through the
-    3-plane split kernel -> [N, 64, Ho, Wo] channels_last."""
+    3-plane split kernel -> [N, 64, Ho, Wo] channels_last.  valid_w: x is a `repitch_rows` result whose real
+    width is valid_w (columns valid_w .. W - 1 are zero): the output is that of the valid_w-wide image."""
     lib = native.load()
     _dev(x, 'x', torch.float32)
     npl = _planes(w_planes, only=_Q_PLANES)
     _require(x.dim() == 4 and x.shape[1] == 3, 'conv7x7s2_nchw_split: x [N, 3, H, W] (NCHW, dense)')
     _require(w_planes.shape[0] == 23, 'conv7x7s2_nchw_split: w_planes from split_stem7x7_weight')
-    N, _, H, W = x.shape
+    N, _, H, pitch = x.shape
+    W = pitch if valid_w is None else int(valid_w)
+    _require(0 < W <= pitch and (W == pitch or pitch % 4 == 0), 'conv7x7s2_nchw_split: valid_w <= W, W % 4 == 0')
     Cout = w_planes.shape[2]
     if bias is not None:
         _dev(bias, 'bias', torch.float32)
@@ -883,7 +905,7 @@ def conv7x7s2_nchw_split(x, w_planes, bias=None, relu=False):
     with torch.cuda.device(x.device), _Timed('conv7x7_stem', 2 * N * Ho * Wo * Cout * 147, (N * Ho * Wo, 147, Cout)):
         st = lib.pave_conv7x7s2_nchw_split_f32(
             x.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
-            y.data_ptr(), N, H, W, Cout, int(bool(relu)), npl, _stream_ptr())
+            y.data_ptr(), N, H, W, pitch, Cout, int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'conv7x7s2_nchw_split')
     return y.permute(0, 3, 1, 2)
 
@@ -916,7 +938,7 @@ def ref_update(tmp, ref, eps=1e-5):
     return out
 
 
-def ref_update_frames(y, ref, T, o, group, eps=1e-5):
+def ref_update_frames(y, ref, T, o, group, eps=1e-5, out=None):
     """sigmoid(y_t + inverse_sigmoid(ref)) read straight from the grouped per-frame MLP output
     y [R, T * op] (frame t's `o` outputs at columns [t op, t op + o)); ref [..., o] with R * T rows
     ordered (r // group, t, r % group) -> same shape as ref.  One launch, no layout copy."""
@@ -928,7 +950,11 @@ def ref_update_frames(y, ref, T, o, group, eps=1e-5):
     _require(y.dim() == 2 and op * T == y.shape[1] and op >= o and ref.shape[-1] == o
              and ref.numel() == R * T * o and R % int(group) == 0,
              'ref_update_frames: y [R, T*op], ref [R*T rows, o], R % group == 0')
-    out = torch.empty_like(ref)
+    if out is None:
+        out = torch.empty_like(ref)
+    else:       # (a level of the decoder's preallocated [levels, ...] stack of intermediate references)
+        _dev(out, 'out', torch.float32)
+        _require(tuple(out.shape) == tuple(ref.shape), 'ref_update_frames: out shaped like ref')
     with torch.cuda.device(y.device), _Timed('ref_update'):
         st = lib.pave_ref_update_frames_f32(y.data_ptr(), ref.data_ptr(), out.data_ptr(), R, int(T),
                                             op, int(o), int(group), float(eps), _stream_ptr())

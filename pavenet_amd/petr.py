@@ -108,7 +108,13 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
                 memory, attn_mask, geom)
             enc_outputs_class = mlp_rows(cls_branches[self.decoder.num_layers], output_memory)
             topk = self.two_stage_num_proposals
-            topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
+            logits = enc_outputs_class[..., 0]
+            if (logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] <= 32768
+                    and topk <= 1024 and not torch.is_grad_enabled()):
+                from . import ops
+                topk_proposals = ops.topk_rows(logits, topk)[1]     # one launch (torch.topk: ~22)
+            else:
+                topk_proposals = torch.topk(logits, topk, dim=1)[1]
             forced = kwargs.pop('force_topk_proposals', None)
             if forced is not None:
                 topk_proposals = forced
@@ -289,7 +295,12 @@ class PETRHead(BaseModule):
         K = self.num_keypoints
         N = self.test_cfg.get('max_per_img', self.num_query)
         cls_score = cls_scores.sigmoid().view(B, -1)
-        scores, indexs = cls_score.topk(N, dim=1)
+        if (cls_score.is_cuda and cls_score.dtype == torch.float32 and not torch.is_grad_enabled()
+                and cls_score.shape[1] <= 32768 and N <= 1024):
+            from . import ops
+            scores, indexs = ops.topk_rows(cls_score, N)          # one launch
+        else:
+            scores, indexs = cls_score.topk(N, dim=1)
         if force_score_topk is not None:
             indexs = force_score_topk
             scores = torch.gather(cls_score, 1, indexs)

@@ -56,7 +56,33 @@ def _ref_update(tmp, ref):
     return (tmp + inverse_sigmoid(ref)).sigmoid()
 
 
-def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
+def _stack_buffers(query, reference_points, n_layers, return_intermediate):
+    """Preallocated [levels, ...] stacks of a decoder's intermediate states / reference points (device inference):
+    every layer's last launch writes its level in place, so `torch.stack` (a copy launch per stack on the
+    latency-bound tail) is not needed.  states: batch-first storage [levels, bs, Q, C], handed out as the
+    sequence-first view the reference's stack has; -> (states | None, refs | None)."""
+    if not (return_intermediate and query.is_cuda and query.dtype == torch.float32 and not torch.is_grad_enabled()
+            and reference_points.dtype == torch.float32):
+        return None, None
+    Q, bs, C = query.shape
+    states = torch.empty((n_layers, bs, Q, C), dtype=torch.float32, device=query.device)
+    refs = torch.empty((n_layers,) + tuple(reference_points.shape), dtype=torch.float32, device=query.device)
+    return states, refs
+
+
+def _into_level(buf, lid, value_seq_first=None, value=None):
+    """Level `lid` of a preallocated stack holds `value` (copied only if the producing launch did not write there)."""
+    if value_seq_first is not None:
+        v = value_seq_first.transpose(0, 1)                  # batch-first view
+        if v.data_ptr() != buf[lid].data_ptr() or v.stride() != buf[lid].stride():
+            buf[lid].copy_(v)
+        return buf[lid].transpose(0, 1)
+    if value.data_ptr() != buf[lid].data_ptr() or value.stride() != buf[lid].stride():
+        buf[lid].copy_(value)
+    return buf[lid]
+
+
+def _frame_branches(branches, lid, x, cat_dim, update_ref=None, out=None):
     """torch.cat([b[lid](x) for b in branches], dim=cat_dim) for T per-frame MLPs of identical
     structure (Linear / ReLU chains, OT:6728-6732, MT:861-864).  On the device the T first Linears
     run as ONE GEMM over the row-concatenated weights and the following per-frame Linears as
@@ -133,7 +159,7 @@ def _frame_branches(branches, lid, x, cat_dim, update_ref=None):
                 and update_ref.shape[-1] == o and update_ref.numel() == R * T * o:
             # update_ref given: return sigmoid(cat_t(branch_t(x)) + inverse_sigmoid(update_ref)), read
             # straight from the grouped output (no layout copy, one launch)
-            return ops.ref_update_frames(y, update_ref, T, o, lead[1] if cat_dim == 1 else R)
+            return ops.ref_update_frames(y, update_ref, T, o, lead[1] if cat_dim == 1 else R, out=out)
         y = y.view(R, T, -1)[:, :, :o].permute(1, 0, 2)            # [T, R, out]
         y = y.reshape((T,) + tuple(lead) + (o,))
         if cat_dim == 0:
@@ -176,7 +202,10 @@ class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
         unit_ratios = kwargs.pop('unit_valid_ratios', False)
         output = query
         intermediate, intermediate_reference_points = [], []
+        states, refs = _stack_buffers(query, reference_points, len(self.layers), self.return_intermediate)
         for lid, layer in enumerate(self.layers):
+            if states is not None:
+                kwargs['layer_out'] = states[lid]
             if reference_points.shape[-1] == K * 2 and unit_ratios:
                 reference_points_input = reference_points[:, :, None].expand(
                     -1, -1, valid_ratios.shape[1], -1)
@@ -194,11 +223,17 @@ class VideoPoseTransformerDecoderMulFrames(TransformerLayerSequence):
                 if reference_points.shape[-1] != K * 2:
                     raise NotImplementedError
                 reference_points = _frame_branches(branches, lid, output, 1,       # OT:6728-6735
-                                                   update_ref=reference_points)
+                                                   update_ref=reference_points,
+                                                   out=refs[lid] if refs is not None else None)
             output = output.permute(1, 0, 2)
-            if self.return_intermediate:
+            if states is not None:
+                output = _into_level(states, lid, value_seq_first=output)
+                reference_points = _into_level(refs, lid, value=reference_points)
+            elif self.return_intermediate:
                 intermediate.append(output)
                 intermediate_reference_points.append(reference_points)
+        if states is not None:
+            return states.transpose(1, 2), refs
         if self.return_intermediate:
             return torch.stack(intermediate), torch.stack(intermediate_reference_points)
         return output, reference_points
@@ -228,7 +263,10 @@ class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
         unit_ratios = kwargs.pop('unit_valid_ratios', False)   # (see the pose decoder)
         output = query
         intermediate, intermediate_reference_points = [], []
+        states, refs = _stack_buffers(query, reference_points, len(self.layers), self.return_intermediate)
         for lid, layer in enumerate(self.layers):
+            if states is not None:
+                kwargs['layer_out'] = states[lid]
             if unit_ratios and reference_points.shape[-1] == 2:
                 reference_points_input = reference_points[:, :, None].expand(
                     -1, -1, valid_ratios.shape[1], -1)
@@ -245,11 +283,17 @@ class DeformableDetrTransformerDecoderMulFrames(TransformerLayerSequence):
             if branches is not None:
                 assert reference_points.shape[-1] == 2
                 reference_points = _frame_branches(branches, lid, output, 0,       # MT:861-866
-                                                   update_ref=reference_points)
+                                                   update_ref=reference_points,
+                                                   out=refs[lid] if refs is not None else None)
             output = output.permute(1, 0, 2)
-            if self.return_intermediate:
+            if states is not None:
+                output = _into_level(states, lid, value_seq_first=output)
+                reference_points = _into_level(refs, lid, value=reference_points)
+            elif self.return_intermediate:
                 intermediate.append(output)
                 intermediate_reference_points.append(reference_points)
+        if states is not None:
+            return states.transpose(1, 2), refs
         if self.return_intermediate:
             return torch.stack(intermediate), torch.stack(intermediate_reference_points)
         return output, reference_points

@@ -4,10 +4,31 @@ import torch
 
 
 @torch.no_grad()
-def init_random_weights(model, seed=0):
-    """Reference-equivalent ``init_weights`` under a fixed seed, then re-randomise the
-    sampling-offset / attention-logit Linears: their default init is
-    all-zero weights (OT:1631-1642), which makes every query sample the same points."""
+def init_random_weights(model, seed=0, reference_sigma_init=True):
+    """Reference-equivalent ``init_weights`` under a fixed seed, then what a random-weight model needs to be a
+    MEANINGFUL test input (every change below is to the recipe, not to the model):
+
+    * the sampling-offset / attention-logit Linears are re-randomised: their default init is all-zero weights
+      (OT:1631-1642), which makes every query sample the same points;
+    * ``cls_branches`` weights N(0, 0.1): spread proposal / query scores (near-tie top-k selections otherwise);
+    * the last layer of the pose-decoder ``kpt_branches`` N(0, 0.05) weights, N(0, 0.3) bias (the reference zeroes
+      it, HEAD init_weights): poses with real extents (tens of pixels) instead of 15 key points on one spot, so
+      that OKS-NMS compares poses and suppresses some of them;
+    * ``transformer.enc_output.bias = -0.1 x (the proposal class branch's weight row)``: the two-stage proposals give
+      every INVALID token (level borders, padding: ~5 % of the tokens, ``gen_encoder_output_proposals``
+      OT:21204-21214) a zero memory row, i.e. the SAME class logit cls(LayerNorm(enc_output.bias)) for all of them.
+      A random-weight encoder gives the valid tokens a large common component, so whether that constant lands
+      inside the top 300 is a coin toss per weight draw and canvas -- on the 750 x 1333 PoseTrack canvas it did:
+      all 300 proposals were invalid tokens with reference point sigmoid(inf) = (1, 1), every pose collapsed into
+      the bottom-right corner and OKS-NMS kept ONE (round 6; round 5 had met the same symptom and blamed the sigma
+      init).  LayerNorm scales the bias of an empty row to unit variance (its elements, ~0.01, are well above
+      sqrt(eps) = 3e-3), so a bias that is a small negative multiple of the class weight puts the empty rows' logit
+      ~ |w| sqrt(256) = 25 below the class bias (never selected) and moves the valid tokens
+      (|enc_output(memory)| ~ 1 per element) by a percent.  A trained model scores empty rows low by itself;
+    * reference_sigma_init (default since round 6): `Linear_with_norm`'s constructor-time xavier_uniform(gain 0.01)
+      on the last layer of the sigma / RLE branches (HEAD:1611), which `init_weights` never redoes and the seeded
+      reset below would otherwise replace by the default Linear init (advisor finding, rounds 4 and 5);
+    * BatchNorm running statistics as a trained net has them, ``bn3.weight = 0.3`` (the reference zero-inits it)."""
     torch.manual_seed(seed)
     # PyTorch draws Linear / Conv / Embedding defaults from the global generator at CONSTRUCTION time,
     # and init_weights leaves many of them (every bias of the Linears, the attention in-projections) as
@@ -18,15 +39,10 @@ def init_random_weights(model, seed=0):
         if callable(reset) and not list(mod.children()) or isinstance(mod, torch.nn.MultiheadAttention):
             if callable(reset):
                 reset()
-    # NOT re-applied on purpose: heads.Linear_with_norm's constructor-time xavier_uniform(gain = 0.01) on the last
-    # layer of the sigma / RLE branches (HEAD:1611; `init_weights` never redoes it, so the reset above leaves the
-    # default Linear init there -- advisor finding, round 4).  Tried in round 5 (`constructor_init()` after the
-    # reset): every sigma then sits at ~0.5, the twenty best poses of a random-weight clip become near copies of
-    # each other and OKS-NMS keeps ONE (bench parity: oracle_poses 1) -- the full-size parity tests need >= 5
-    # surviving poses to mean anything.  The recipe of rounds 1-4 stays; what it costs: the RLE rescale
-    # kpt p^5 / (p^5 + 1e-10) is ill-conditioned for some poses (p^5 ~ 1e-10), so rounding-level differences
-    # between two batch compositions show as up to ~0.4 px in FINAL key points while the decoder states agree to
-    # 1e-4 (tests compare across batch compositions on the decoder states, against the oracle on one composition).
+    if reference_sigma_init:
+        for mod in model.modules():
+            if hasattr(mod, 'constructor_init') and mod.__class__.__name__ == 'Linear_with_norm':
+                mod.constructor_init()
     for m in (model.backbone, model.neck, model.bbox_head):
         if m is not None:
             m.init_weights()
@@ -37,8 +53,17 @@ def init_random_weights(model, seed=0):
             p.copy_(torch.randn(p.shape, generator=g) * std)
         elif 'cls_branches' in name and name.endswith('weight'):
             p.copy_(torch.randn(p.shape, generator=g) * 0.1)  # spread the proposal scores
+        elif 'kpt_branches' in name and 'refine' not in name and name.endswith('.6.weight'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        elif 'kpt_branches' in name and 'refine' not in name and name.endswith('.6.bias'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
         elif ('kpt_branches' in name) and name.endswith('.6.weight'):
             p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+    head = model.bbox_head
+    tr = getattr(head, 'transformer', None)
+    if tr is not None and hasattr(tr, 'enc_output') and hasattr(head, 'cls_branches'):
+        w_cls = head.cls_branches[tr.decoder.num_layers].weight        # the encoder-proposal class branch
+        tr.enc_output.bias.copy_(-0.1 * w_cls[0])
     # BN running stats as a trained net would have (non-trivial but well conditioned)
     for name, b in model.named_buffers():
         if name.endswith('running_var'):

@@ -418,3 +418,38 @@ def test_integration_binding_compiles():
     # the snippet quoted in INTEGRATION.md is this file's text
     doc = open(os.path.join(root, 'INTEGRATION.md')).read()
     assert 'integration/ms_deform_attn_pave.cpp' in doc
+
+
+def test_launch_census_classifies_aten_operators():
+    """pavenet_amd.census.LaunchCensus (what `forward_device(strict=True)`, bench.py's `fallback_ops_per_step` and the
+    GPU suite's zero-fallback tests count): library compute operators (GEMM, convolution, normalisation, attention,
+    pooling, top-k) are FALLBACKS, other kernels-launching operators are counted beside them, views and allocations
+    are not counted at all, slow-path notes reach the running census only -- checked here on host tensors
+    (device_types=('cpu',)), the classification does not depend on the device."""
+    import torch
+    import torch.nn.functional as F
+    from pavenet_amd.census import FallbackError, LaunchCensus, note_slow_path
+    lin, x = torch.nn.Linear(8, 8), torch.randn(2, 4, 8)
+    note_slow_path('outside any census: dropped')
+    with torch.no_grad(), LaunchCensus(device_types=('cpu',)) as c:
+        y = lin(x).relu() + 1
+        y.view(8, 8).transpose(0, 1).unsqueeze(0)[:, :2].expand(3, -1, -1)      # views: nothing launched
+        torch.empty(4, 4).new_empty(2)                                         # allocations
+        torch.stack([y, y])
+        F.layer_norm(y, (8,))
+        F.conv2d(torch.randn(1, 3, 8, 8), torch.randn(4, 3, 3, 3))
+        F.scaled_dot_product_attention(x, x, x)
+        y.topk(2)
+        note_slow_path('generic kernel')
+    assert c.fallback_ops['native_layer_norm'] == 1 and c.fallback_ops['convolution'] == 1
+    assert c.fallback_ops['topk'] == 1
+    assert any(k in c.fallback_ops for k in ('addmm', 'mm', 'bmm', 'linear'))
+    assert set(c.aten_launches) >= {'relu', 'add', 'stack'}
+    assert not any(k in c.aten_launches or k in c.fallback_ops for k in ('view', 'transpose', 'expand', 'empty'))
+    assert dict(c.slow_paths) == {'generic kernel': 1}
+    with pytest.raises(FallbackError):
+        c.raise_on_fallback('test')
+    with torch.no_grad(), LaunchCensus(device_types=('cuda',)) as none:      # host tensors are not the census's
+        lin(x)
+    assert not none.fallback_ops and not none.aten_launches
+    none.raise_on_fallback('test')

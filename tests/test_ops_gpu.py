@@ -778,6 +778,42 @@ def test_stem_conv7x7_split_vs_torch_fp64(N, H, W):
         assert torch.equal(new, old)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 37, 53), (1, 21, 131), (2, 33, 389), (1, 75, 1333), (1, 18, 202)])
+def test_stem_repitched_odd_width_equals_window_load_kernel(N, H, W):
+    """Widths off the 4-pixel grid (the reference's PoseTrack test canvas is 750 x 1333,
+    configs/_base_/datasets/posetrack17_video_keypoint.py:68-81 with size_divisor = 1): the image rows re-laid at a
+    16-byte aligned pitch with zero pad columns (pave_repitch_rows_f32) through the LDS-window stem kernel
+    (row_pitch of pave_conv7x7s2_nchw_split_f32) -- bit-identical to the per-lane window-load kernel on the dense
+    image (same products in the same order), within fp32 rounding of torch's fp64 convolution, and a NaN in a pad
+    column would show (the pad must be zeros, not stale memory: the buffer is poisoned first)."""
+    from pavenet_amd.ops import conv7x7s2_nchw_split, repitch_rows, split_stem7x7_weight
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    wp = split_stem7x7_weight(w.cuda())
+    xd = x.cuda()
+    pitch = (W + 3) // 4 * 4
+    poison = torch.full((N, 3, H, pitch), float('nan'), device='cuda')    # the allocator hands this block back
+    del poison
+    xp = repitch_rows(xd)
+    assert tuple(xp.shape) == (N, 3, H, pitch) and xp.data_ptr() % 16 == 0
+    assert torch.equal(xp[..., :W], xd) and bool((xp[..., W:] == 0).all())
+    got = conv7x7s2_nchw_split(xp, wp, b.cuda(), relu=True, valid_w=W)
+    old = conv7x7s2_nchw_split(xd, wp, b.cuda(), relu=True)            # dense odd width: the window-load kernel
+    assert tuple(got.shape) == tuple(old.shape) == (N, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    assert torch.equal(got, old)
+    exp = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 3))
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=2e-5)
+    # fp16 operands: only the LDS-window kernel exists, so an odd width needs the re-laid rows
+    wh = split_stem7x7_weight(w.cuda(), 16)
+    goth = conv7x7s2_nchw_split(xp, wh, b.cuda(), relu=True, valid_w=W)
+    exph = torch.relu(torch.nn.functional.conv2d(x.half().double(), w.half().double(), b.double(), 2, 3))
+    np.testing.assert_allclose(goth.cpu().numpy(), exph.numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        conv7x7s2_nchw_split(xp, wp, None, valid_w=pitch + 1)
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 13, 17, 256, 512, 2), (1, 20, 9, 64, 128, 2),
                                                    (3, 8, 8, 128, 256, 1)])
 def test_conv1x1_strided_split_vs_torch_fp64(N, H, W, Cin, Cout, stride):
@@ -2211,12 +2247,22 @@ def test_small_row_gemm_form_equals_tile_kernels_bit_for_bit(seed):
         a, w, b = rnd(M, G * K), rnd(G * gn, K, scale=0.05), rnd(G * gn)
         wp = ops.split_weight_bf16x3(w, pad=True)
         run = lambda: ops.gemm_bf16x3_grouped(a, wp, b, gn, relu=relu)        # noqa: E731
-    small = run().clone()
+    with native.diag_build(19):          # the one-wave small-row form (the shipped selection until round 6)
+        small = run().clone()
     with native.diag_build(8):
         tile = run().clone()
     torch.cuda.synchronize()
     assert torch.isfinite(small).all()
     assert torch.equal(small, tile), (kind, M, K, float((small - tile).abs().max()))
+    # the shipped selection (round 6): the K axis split over the four waves of a block, partial tiles added in a
+    # fixed order -- the same fp32 terms in another association: equal to rounding, and bit-identical run to run
+    ksplit = run().clone()
+    again = run().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(ksplit, again), 'the K-split small-row form is not deterministic'
+    scale = float(tile.abs().max()) + 1e-6
+    assert float((ksplit - tile).abs().max()) <= 4e-6 * scale * max(1.0, (K / 256) ** 0.5), \
+        (kind, M, K, float((ksplit - tile).abs().max()), scale)
 
 
 @pytest.mark.parametrize('M,K', [(1200, 256), (1200, 1024), (37, 64), (300, 512)])
