@@ -70,37 +70,19 @@ class PETRTransformer(VideoPoseTransformerMulFrames):
     def forward(self, mlvl_feats, mlvl_masks, query_embed, mlvl_pos_embeds, kpt_branches=None,
                 cls_branches=None, has_padding=True, **kwargs):
         assert self.as_two_stage or query_embed is not None
-        dev = mlvl_feats[0].device
-        geom = self.geometry([f.shape[-2:] for f in mlvl_feats], dev)
-        feat_flatten, mask_flatten, lvl_pos_embed_flatten = [], [], []
-        for lvl, (feat, mask, pos_embed) in enumerate(zip(mlvl_feats, mlvl_masks, mlvl_pos_embeds)):
-            feat_flatten.append(feat.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
-            pos_embed = pos_embed.flatten(2).transpose(1, 2)
-            lvl_pos_embed_flatten.append(pos_embed + self.level_embeds[lvl].view(1, 1, -1))
-        feat_flatten = torch.cat(feat_flatten, 1)
-        bs = feat_flatten.shape[0]
-        mask_flatten = torch.cat(mask_flatten, 1)
-        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
-        if lvl_pos_embed_flatten.shape[0] != bs:
-            lvl_pos_embed_flatten = lvl_pos_embed_flatten.expand(bs, -1, -1)
-            valid_ratios = valid_ratios.expand(bs, -1, -1)
+        # flatten + encoder: the video transformer's frame encoder (every image is a one-frame clip) -- the same
+        # launches, and its per-shape caches (flattened masks / positional table, valid ratios, reference grid), so a
+        # warm step rebuilds none of them (round 6: the merged projection's epilogue table used to miss its cache
+        # every step here, six vendor GEMMs per forward)
+        memory, mask_flatten, valid_ratios, geom = self.encode_frames(mlvl_feats, mlvl_masks, mlvl_pos_embeds,
+                                                                      has_padding)
+        bs = memory.shape[0]
+        if mask_flatten.shape[0] != bs:
             mask_flatten = mask_flatten.expand(bs, -1)
+        if valid_ratios.shape[0] != bs:
+            valid_ratios = valid_ratios.expand(bs, -1, -1)
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
-        reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
         attn_mask = mask_flatten if has_padding else None
-        extra = dict(inplace_residual=True)
-        if self.enc_lds_tile and feat_flatten.is_cuda and geom.tile_levels() is not None:
-            extra['tile_levels'] = geom.tile_levels()
-        elif self.xcd_unit_order and feat_flatten.is_cuda:
-            extra['unit_order'] = geom.unit_order(bs, dev)
-        memory = self.encoder(
-            query=seq_first_view(feat_flatten), key=None, value=None,
-            query_pos=seq_first_view(lvl_pos_embed_flatten), query_key_padding_mask=attn_mask,
-            spatial_shapes=spatial_shapes, reference_points=reference_points,
-            level_start_index=level_start_index, valid_ratios=valid_ratios, **extra)
-        memory = batch_first(memory)
         c = memory.shape[-1]
         hm_proto = None  # training only (OT:4551)
         if self.as_two_stage:

@@ -493,7 +493,9 @@ class VideoPoseTransformerMulFrames(Transformer):
             self._geom[key] = _LevelGeometry(hw_list, device)
         return self._geom[key]
 
-    def gen_encoder_output_proposals(self, memory, memory_padding_mask, geom):
+    def gen_encoder_output_proposals(self, memory, memory_padding_mask, geom, mask_key=None):
+        """mask_key: identity of a PADDED batch's (cached) mask set -- the proposal grid, its validity and the rows to
+        blank are functions of the masks alone, built once per mask set instead of ~60 tensor launches per step."""
         N, S, C = memory.shape
         dev = memory.device
         cached = None
@@ -507,6 +509,14 @@ class VideoPoseTransformerMulFrames(Transformer):
                 output_memory = memory.masked_fill(~valid, float(0))
                 output_memory = linear_norm(output_memory, self.enc_output, self.enc_output_norm)
                 return output_memory, output_proposals
+        if memory_padding_mask is not None and mask_key is not None and memory.is_cuda \
+                and not torch.is_grad_enabled() and self.fused_proposal_stage:
+            hit = geom.unpadded.get(('proposals_padded', N))
+            if hit is not None and hit[0] == mask_key:
+                _, output_proposals, keep = hit
+                filled = self._output_memory_filled(memory, keep, geom, tag=('padded', N), key_extra=mask_key)
+                if filled is not None:
+                    return filled, output_proposals
         proposals = []
         _cur = 0
         for lvl, (H, W) in enumerate(geom.hw):
@@ -539,6 +549,14 @@ class VideoPoseTransformerMulFrames(Transformer):
             filled = self._output_memory_filled(memory, valid, geom) if self.fused_proposal_stage else None
             if filled is not None:
                 return filled, output_proposals
+        if memory_padding_mask is not None and mask_key is not None and memory.is_cuda \
+                and not torch.is_grad_enabled() and self.fused_proposal_stage:
+            # rows that stay: valid proposal AND not padding (OT:21204-21214 blanks the memory rows of both)
+            keep = valid & ~memory_padding_mask.unsqueeze(-1)
+            geom.unpadded[('proposals_padded', N)] = (mask_key, output_proposals, keep)
+            filled = self._output_memory_filled(memory, keep, geom, tag=('padded', N), key_extra=mask_key)
+            if filled is not None:
+                return filled, output_proposals
         output_memory = memory
         if memory_padding_mask is not None:
             output_memory = output_memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
@@ -558,7 +576,7 @@ class VideoPoseTransformerMulFrames(Transformer):
             self.__dict__['_pave_' + name] = hit
         return hit[1]
 
-    def _output_memory_filled(self, memory, valid, geom):
+    def _output_memory_filled(self, memory, valid, geom, tag=None, key_extra=None):
         """enc_output_norm(enc_output(memory.masked_fill(~valid, 0))) (OT:21206-21214) without the masked copy
         of the memory: Linear + LayerNorm per clip straight from the (strided) centre-frame rows, then the rows of
         the invalid proposals -- the level borders, ~5 % of the tokens -- overwritten with the value a zero row
@@ -571,13 +589,15 @@ class VideoPoseTransformerMulFrames(Transformer):
             return None
         from . import ops
         from .bricks import get_gemm_mode
+        # (key_extra: the mask set of a padded batch -- `valid` then also excludes its padded tokens)
         key = SourceKey([lin.weight, lin.bias, norm.weight, norm.bias], extra=get_gemm_mode())
-        const = geom.unpadded.get(('proposal_fill', N))
-        if const is None or const[0] != key:
+        slot = ('proposal_fill', N) if tag is None else ('proposal_fill',) + tuple(tag)
+        const = geom.unpadded.get(slot)
+        if const is None or const[0] != key or (key_extra is not None and const[3] != key_extra):
             zrows = linear_norm(memory.new_zeros((max(S, 1), C)), lin, norm)   # (the same launch form as a clip)
             rows = (~valid.reshape(N * S)).nonzero().flatten().to(torch.int32)
-            const = (key, zrows[0].clone(), rows)
-            geom.unpadded[('proposal_fill', N)] = const
+            const = (key, zrows[0].clone(), rows, key_extra)
+            geom.unpadded[slot] = const
         out = torch.empty((N, S, norm.normalized_shape[0]), dtype=torch.float32, device=memory.device)
         for b in range(N):
             linear_norm(memory[b], lin, norm, out=out[b])
@@ -662,12 +682,21 @@ class VideoPoseTransformerMulFrames(Transformer):
         if const is not None:       # no padding: valid ratios are exactly 1, the grid is constant
             valid_ratios, reference_points = const
         else:
-            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
-            if valid_ratios.shape[0] != nfr:
-                valid_ratios = valid_ratios.expand(nfr, -1, -1)
-            reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
-            if not has_padding and feat_flatten.is_cuda and not torch.is_grad_enabled():
-                geom.unpadded[('refs', nfr)] = (valid_ratios.contiguous(), reference_points)
+            pkey = SourceKey(list(mlvl_masks), extra=nfr)
+            phit = geom.unpadded.get(('refs_padded', nfr)) if (feat_flatten.is_cuda
+                                                               and not torch.is_grad_enabled()) else None
+            if phit is not None and phit[0] == pkey:    # (a padded batch's masks are cached per batch shape)
+                valid_ratios, reference_points = phit[1], phit[2]
+            else:
+                valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
+                if valid_ratios.shape[0] != nfr:
+                    valid_ratios = valid_ratios.expand(nfr, -1, -1)
+                reference_points = self.get_reference_points(geom.hw, valid_ratios, device=dev)
+                if feat_flatten.is_cuda and not torch.is_grad_enabled():
+                    if has_padding:
+                        geom.unpadded[('refs_padded', nfr)] = (pkey, valid_ratios, reference_points)
+                    else:
+                        geom.unpadded[('refs', nfr)] = (valid_ratios.contiguous(), reference_points)
         attn_mask = mask_flatten if has_padding else None
         if attn_mask is not None and attn_mask.shape[0] != feat_flatten.shape[0]:
             attn_mask = attn_mask.expand(feat_flatten.shape[0], -1)
@@ -726,8 +755,10 @@ class VideoPoseTransformerMulFrames(Transformer):
         now_frame_mask_flatten = mask_flatten[ctr] if mask_flatten.shape[0] == bs else mask_flatten
         now_frame_valid_ratios = valid_ratios[ctr]  # equal for every frame of a clip
         if self.as_two_stage:
+            mask_key = SourceKey((mask_flatten,), extra=(ctr.start, ctr.step, now_frame_memory.shape[0])) \
+                if (has_padding and frame_shard is None) else None
             output_memory, output_proposals = self.gen_encoder_output_proposals(
-                now_frame_memory, now_frame_mask_flatten if has_padding else None, geom)
+                now_frame_memory, now_frame_mask_flatten if has_padding else None, geom, mask_key=mask_key)
             enc_outputs_class = mlp_rows(cls_branches[self.decoder.num_layers], output_memory)
             topk = self.two_stage_num_proposals
             logits = enc_outputs_class[..., 0]
@@ -839,13 +870,19 @@ class VideoPoseTransformerMulFrames(Transformer):
         spatial_shapes, level_start_index = geom.spatial_shapes, geom.level_start_index
         const = geom.unpadded.get(('refine', mlvl_masks[0].shape[0])) \
             if (not has_padding and memory.is_cuda) else None
+        pkey = SourceKey(list(mlvl_masks)) if (has_padding and memory.is_cuda and not torch.is_grad_enabled()) else None
+        phit = geom.unpadded.get(('refine_padded', mlvl_masks[0].shape[0])) if pkey is not None else None
         if const is not None:            # no padding: all-False masks, valid ratios exactly 1
             mask_flatten, valid_ratios = const
+        elif phit is not None and phit[0] == pkey:     # (a padded batch's masks are cached per batch shape)
+            mask_flatten, valid_ratios = phit[1], phit[2]
         else:
             mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
             if not has_padding and memory.is_cuda and not torch.is_grad_enabled():
                 geom.unpadded[('refine', mlvl_masks[0].shape[0])] = (mask_flatten, valid_ratios)
+            elif pkey is not None:
+                geom.unpadded[('refine_padded', mlvl_masks[0].shape[0])] = (pkey, mask_flatten, valid_ratios)
         B = memory.shape[1]
         if valid_ratios.shape[0] != B * Tl:
             valid_ratios = valid_ratios.expand(B * Tl, -1, -1)
@@ -861,11 +898,23 @@ class VideoPoseTransformerMulFrames(Transformer):
         reference_points = reference_points_pose.reshape(-1, reference_points_pose.size(1) // 2, 2)
         mask_bt = mask_flatten.reshape(-1, Tl, mask_flatten.size(-1))         # [B, T_loc, S]
         if has_padding:
-            vr = valid_ratios.reshape(-1, Tl, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
-            if frame_shard is not None:
-                # every frame of a clip has the same valid ratios: rebuild the [N, T, L, 2] table
-                vr = vr[:, :1].expand(-1, T, -1, -1)
-            vr_rows = vr.flatten(0, 1)
+            vkey = SourceKey((valid_ratios, img_inds), extra=(Tl, T, frame_shard is not None)) if pkey is not None else None
+            vhit = self.__dict__.get('_pave_vr_rows')
+            if vkey is not None and vhit is not None and vhit[0] == vkey:
+                vr_rows = vhit[1]          # (the gather by the head's cached clip-of-pose index, once per mask set)
+            else:
+                vr = valid_ratios.reshape(-1, Tl, valid_ratios.size(-2), valid_ratios.size(-1))[img_inds]
+                if frame_shard is not None:
+                    # every frame of a clip has the same valid ratios: rebuild the [N, T, L, 2] table
+                    vr = vr[:, :1].expand(-1, T, -1, -1)
+                # FRAME-major rows, as the reference points they scale ([T * N, K, 2]: `[pre..., now..., next...]`,
+                # HEAD:610).  The reference flattens this table pose-major (`flatten(0, 1)`, OT:21511) -- the same
+                # thing only while every pose belongs to ONE clip (it asserts batch size 1); in a batch of clips
+                # with different valid sizes that order would hand a pose another clip's ratios (found in round 6:
+                # poses of a padded two-clip batch were sampled at 750/800 of their y coordinate)
+                vr_rows = vr.transpose(0, 1).flatten(0, 1)
+                if vkey is not None:
+                    self.__dict__['_pave_vr_rows'] = (vkey, vr_rows)
         else:   # every valid ratio is exactly 1: a broadcast row, no gather / copy per step
             vr_rows = valid_ratios[:1].expand(img_inds.shape[0] * T, -1, -1)
         dec_kwargs = {}

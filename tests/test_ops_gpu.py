@@ -1419,7 +1419,14 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
             outs[v] = run().clone()
     outs[0] = run().clone()     # the shipped library's own selection
     torch.cuda.synchronize()
+    # (round 6: few-tile launches with K >= 512 take the K-split small-row form in the shipped selection -- the
+    # same fp32 terms added in another association: equal to rounding there, bit-identical everywhere else)
+    ksplit = K >= 512 and not nsplit and ((M + 31) // 32) * ((N + 31) // 32) <= 4096
     for v in (8, 7, 0):
+        if v == 0 and ksplit:
+            scale = float(outs[9].abs().max()) + 1e-6
+            assert float((outs[0] - outs[9]).abs().max()) <= 8e-6 * scale, (seed, M, K, N)
+            continue
         assert torch.equal(outs[v], outs[9]), (seed, M, K, N, v, float((outs[v] - outs[9]).abs().max()))
     assert torch.isfinite(outs[0]).all()
 
@@ -2283,7 +2290,7 @@ def test_small_row_linear_layernorm_vs_fp64(M, K):
     assert torch.equal(inplace, got)
     with native.diag_build(13):
         one = gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)
-    np.testing.assert_allclose(got.cpu().numpy(), one.cpu().numpy(), rtol=0, atol=4e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), one.cpu().numpy(), rtol=0, atol=1e-5 if K >= 512 else 4e-6)
     x = a.double() @ w.double().t() + b.double() + r.double()
     exp = torch.nn.functional.layer_norm(x, (256,), ga.double(), be.double(), 1e-5)
     np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
