@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 &&
 }
 // 3x3 form on a map that arrives as pre-split bf16 planes ([pixel][3][Cin], IO bit 2): no VALU split in the loop
 template <int TN, bool HT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2))) void gemm_qp_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_qp_kernel(
     const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
     const float* residual, float* out, const int M, const int K, const int N, const int relu, const QConv g,
     const QOut os) {
@@ -1463,6 +1463,23 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
   return PAVE_OK;
 }
 
+// fp32 rows [rows, C] -> the three bf16 planes of every row, [rows][3][C]: split8's terms (truncation, truncation,
+// rounded remainder), 8 values per lane
+__global__ __launch_bounds__(256) void split_rows_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ pl,
+                                                                const long long n8, const int c8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const long long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(x + i * 8);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    u32x4 o[3];
+    split8(lo, hi, o);
+    uint16_t* dst = pl + (r * 3) * (long long)(c8 * 8) + c;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + (long long)p * c8 * 8) = o[p];
+  }
+}
+
 template <int TN, bool HT>
 int launch_qp(const uint16_t* a, const uint16_t* w, const float* bias, const float* residual, float* out,
               long long M, int K, int N, int relu, hipStream_t st, const QConv g, const QOut os) {
@@ -1745,8 +1762,10 @@ int launch_sk(const float* a, const uint16_t* w, const float* bias, const float*
 // (1 200 x 256 x 2 688: 22 | 15 | 15), at K = 1 024 it is what the launch waits for (300 .. 1 200 x 1024 x 256:
 // < 15 | 24 | 34).
 constexpr long long kSkTiles = 4096;     // 32 x 32 tiles (= blocks) up to which the K-split small-row form is taken
+constexpr long long kSkTiles256 = 512;   // ... and at K = 256 .. 511 (4 - 7 slabs per wave): only where the blocks fit one round
 inline bool small_rows_ksplit_form(long long M, int N, int K) {
-  return K >= 512 && ((M + 31) / 32) * (((long long)N + 31) / 32) <= kSkTiles;
+  const long long tiles = ((M + 31) / 32) * (((long long)N + 31) / 32);
+  return (K >= 512 && tiles <= kSkTiles) || (K >= 256 && tiles <= kSkTiles256);
 }
 
 // Which launches take the small-row form: fewer than 64 tiles of 128 x 128 (and < 8 192 rows).  tools/
@@ -1978,6 +1997,18 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3 bf16 planes or 1 fp16 plane");
   return gemm_q_dispatch<3>(a, a_bias, w_planes, bias, residual, residual_rows, out, out2, n_split, M, K, N, relu,
                             kind, H, W, Cin, Ho, Wo, stride, stream, a2, n_real, ksplit, ks_slabs);
+}
+
+int pave_internal_split_rows_planes(const float* x, void* planes, long long rows, int C, void* stream) {
+  if (rows <= 0 || C <= 0 || C % 8 != 0) return pave_internal_fail(PAVE_E_ARG, "split_rows_bf16x3: C %% 8 == 0");
+  const long long n8 = rows * (C / 8);
+  long long nb = (n8 + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(split_rows_planes_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, static_cast<uint16_t*>(planes), n8, C / 8);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
 }
 
 // 3x3 / pad 1 convolution of a map given as pre-split bf16 planes [N, H, W, 3, Cin] (stride 1 | 2), 3-plane weights
