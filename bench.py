@@ -731,13 +731,17 @@ def main():
         TAIL_ON[0] = True
     # un-timed passes behind the timed regions, on every rank (the steps hold the job's collectives):
     # (a) the ATen-operator census of one forward, (b) the class's in-kernel clock on the diagnostic build
+    # (neither pass may leave the ranks of a multi-rank job with different collective counts if it fails on one of
+    # them: the census runs where the forward holds no collective -- every mode but the frame-sharded one --, the
+    # clock pass, whose steps include the result all-gather, at N = 1 only)
     census = None
-    try:
-        census = census_of_step(model, img, metas, **(dict(frame_shard=shard) if shard is not None else {}))
-    except Exception as e:
-        census = dict(census_error=f'{type(e).__name__}: {e}'[:200])
+    if shard is None:
+        try:
+            census = census_of_step(model, img, metas)
+        except Exception as e:
+            census = dict(census_error=f'{type(e).__name__}: {e}'[:200])
     clock = None
-    if args.gemm != 'native' and graphed is None and tail_graph is None and not args.no_events:
+    if dist is None and args.gemm != 'native' and graphed is None and tail_graph is None and not args.no_events:
         clock = class_clock_pass(lambda: step())
     timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl, _ in events]
     shaped_ev = [(tag, s.elapsed_time(e) * 1e-3, fl, sh) for tag, s, e, fl, sh in events]

@@ -504,23 +504,6 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
                            int stride, int relu, int nplanes, void* stream);
 
 /*
- * The same convolution on a map that arrives ALREADY SPLIT into its three bf16 planes (ABI 19):
- *   x_planes [N, H, W, 3, Cin] bf16 -- pave_split_rows_bf16x3_f32 of the fp32 map [N H W, Cin]: per pixel the
- *   truncation, truncation and rounded-remainder terms of its Cin values (x == p0 + p1 + p2 exactly), i.e. what the
- *   fp32-input form computes on the VALU for every (pixel, tap) of its operand fetch -- nine times per pixel.  The
- *   A stage then holds operand-ready planes and the loop has no vector arithmetic; same six products in the same
- *   order per accumulator: bit-identical to pave_conv3x3_split_f32(nplanes = 3) on the fp32 map.
- *   Cin %% 16 == 0, Cout %% 4 == 0, the plane map below 4 GiB; weight planes as for pave_conv3x3_split_f32.
- * For the 48- / 96-channel 3x3 branches of HRNet-w48 (hrnet.py:183-260), whose 64- / 96-column tiles spend as
- * many issue cycles on the operand split as on the MFMAs it feeds.
- * pave_split_rows_bf16x3_f32: x [rows, C] fp32 -> planes [rows, 3, C] bf16 (C %% 8 == 0), one pass.
- */
-int pave_conv3x3_planes_f32(const void* x_planes, const void* w_planes, const float* bias,
-                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
-                            int stride, int relu, void* stream);
-int pave_split_rows_bf16x3_f32(const float* x, void* planes, long long rows, int C, void* stream);
-
-/*
  * The same convolution (3 planes) with the K axis cut into parts -- for maps with FEW output pixels
  * and many input channels, where the 128-row tiles alone leave most of the chip idle (the
  * ChannelMapper's extra level: 3x3 / stride 2, 2048 -> 256 on the C5 map,

@@ -236,13 +236,13 @@ struct ClockStamp {
 // IO (fp16 mode, plain rows): bit 0 = the A rows are fp16 in memory (a tensor that is only ever a GEMM operand --
 // the FFN hidden -- kept as what the MFMA consumes: half the bytes, no conversion, the same values), bit 1 = the
 // output is stored as fp16 (bias + ReLU in fp32 first).
-// IO bit 2 (3 planes, 3x3 form KIND 1): the A operand arrives ALREADY SPLIT -- the map is [pixel][3 planes][Cin]
-// bf16 (pave_split_rows_bf16x3_f32: the same truncation / truncation / rounded-remainder terms split8 makes), its
-// stage holds the three planes of the 128 rows in the W planes' layout (12 DMA instructions of 16-byte half
-// rows, slot permutation h ^ ((r >> 3) & 1)), and the fragment read IS the MFMA operand: no VALU split in the
-// loop.  A 3x3 convolution re-splits every input pixel nine times (once per tap) at 36 vector instructions per
-// 8 values; at N = 64 (HRNet-w48's 48-channel branch) that split is as many issue cycles as the MFMAs it feeds.
-// Same products in the same order: bit-identical to the fp32-input form.
+// (A form whose A operand arrives ALREADY SPLIT -- the map as [pixel][3 planes][Cin] bf16 written by the producer,
+// its stage holding operand-ready planes in the W planes' layout, no vector arithmetic in the loop -- was built for
+// the 3x3 form in round 6, bit-identical, and measured 16 - 30 % SLOWER than splitting at operand fetch (HRNet-w48's
+// 48 -> 48 at 28 x 200 x 336: 645 -> 749 us, 96 -> 96: 438 -> 530, 64 -> 64: 820 -> 1 071): 12 instead of 8 A DMA
+// instructions per slab, 54 KB of LDS (two blocks per CU instead of three at 64-column tiles).  What bounds these
+// launches is the A-side data movement, not the VALU split.  Removed; commit 1c032d8 has it, docs/HISTORY.md the
+// numbers.)
 template <int TN, int WN, int KIND, bool ABIAS, bool LNORM, bool WIDE = false, int EPI = 0, int RM = 1, int PL = 3,
           bool HT = false, int IO = 0>
 __device__ __forceinline__ void gemm_q_body(
@@ -255,12 +255,10 @@ __device__ __forceinline__ void gemm_q_body(
   constexpr int NWAVE = 4 * WN;
   constexpr int BN = WN * TN * 32;           // block width
   constexpr int BM = QBM * RM;               // rows per block
-  constexpr bool AH = (IO & 1) != 0, OH = (IO & 2) != 0, AP = (IO & 4) != 0;
+  constexpr bool AH = (IO & 1) != 0, OH = (IO & 2) != 0;
   static_assert(!AH || (PL == 1 && KIND == 0 && !ABIAS && RM == 1), "fp16 A rows: fp16 operand mode, plain rows");
   static_assert(!OH || (PL == 1 && !LNORM && EPI == 0 && !HT && RM == 1), "fp16 output: plain epilogue");
-  static_assert(!AP || (PL == 3 && KIND == 1 && !ABIAS && RM == 1 && WN == 1 && !WIDE && !LNORM),
-                "pre-split A planes: 3 planes, buffer-addressed 3x3 form, narrow tiles");
-  constexpr int A_STAGE = AP ? BM * 32 * PL : (AH ? BM * 32 : BM * 64);   // raw fp32: BM rows x 64 B (fp16 rows: 32 B; planes: PL x 32 B)
+  constexpr int A_STAGE = AH ? BM * 32 : BM * 64;   // raw fp32: BM rows x 64 B (fp16 rows: 32 B)
   static_assert(RM == 1 || (RM == 2 && WN == 1 && !WIDE && !LNORM && EPI == 0), "two row tiles per wave: narrow form");
   static_assert(PL == 3 || PL == 1, "operand planes: 3 (bf16 split) or 1 (fp16)");
   constexpr int W_STAGE = PL * BN * 32;      // PL planes x BN rows x 32 B
@@ -316,7 +314,7 @@ __device__ __forceinline__ void gemm_q_body(
     a_rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ab >> 32) & 0xffff);
     // bytes of the whole map (the launcher takes this form below 4 GiB only)
     a_rsrc.z = __builtin_amdgcn_readfirstlane(
-        (int)((unsigned)(M / (g.Ho * g.Wo)) * (unsigned)g.H * (unsigned)g.W * (unsigned)g.Cin * (AP ? 6u : 4u)));
+        (int)((unsigned)(M / (g.Ho * g.Wo)) * (unsigned)g.H * (unsigned)g.W * (unsigned)g.Cin * 4u));
     a_rsrc.w = 0x00020000;
   }
   unsigned w_voff[QMAX - QA];
@@ -331,10 +329,9 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int d = wave + NWAVE * q;
-      // (fp16 rows: an instruction covers 32 rows x two 16-byte halves, half h of row r at slot h ^ ((r >> 3) & 1);
-      //  pre-split planes: instruction d = plane d / (BM / 32), 32 rows, the same two halves)
-      const int r = AP ? (d % (BM / 32)) * 32 + (lane >> 1) : (AH ? d * 32 + (lane >> 1) : d * 16 + (lane >> 2));
-      const int c = (AH || AP) ? (lane & 1) ^ ((r >> 3) & 1) : (lane & 3) ^ ((r >> 2) & 3);
+      // (fp16 rows: an instruction covers 32 rows x two 16-byte halves, half h of row r at slot h ^ ((r >> 3) & 1))
+      const int r = AH ? d * 32 + (lane >> 1) : d * 16 + (lane >> 2);
+      const int c = AH ? (lane & 1) ^ ((r >> 3) & 1) : (lane & 3) ^ ((r >> 2) & 3);
       long long gm = (long long)m0 + r;
       if (gm >= M) gm = M - 1;   // rows past M: stand-in data, never stored
       if (KIND == 0 && AH) {
@@ -354,9 +351,6 @@ __device__ __forceinline__ void gemm_q_body(
         } else if (KIND == 1) {
           const int iy0 = oy * g.stride - 1, ix0 = ox * g.stride - 1;
           // byte offset of tap (0, 0), chunk c (mod 2^32: may lie before the map for a padded tap)
-          if constexpr (AP)   // [pixel][plane][Cin] bf16: plane d / (BM / 32), half c (8 values)
-            a_voff[q] = (unsigned)((((((long long)n * g.H + iy0) * g.W + ix0) * PL + d / (BM / 32)) * g.Cin + c * 8) * 2);
-          else
           a_voff[q] = (unsigned)(((((long long)n * g.H + iy0) * g.W + ix0) * g.Cin + c * 4) * 4);
           unsigned mk = 0;
 #pragma unroll
@@ -401,8 +395,7 @@ __device__ __forceinline__ void gemm_q_body(
         const int tap = g.rcp ? (int)__umulhi((unsigned)slab, g.rcp) : slab;
         const int c0 = (slab - tap * (g.Cin >> 4)) * 16;
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // (tap < 16)
-        const unsigned toff = AP ? (unsigned)(((ky * g.W + kx) * g.Cin * PL + c0) * 2)
-                                 : (unsigned)(((ky * g.W + kx) * g.Cin + c0) * 4);
+        const unsigned toff = (unsigned)(((ky * g.W + kx) * g.Cin + c0) * 4);
         // (tap >= 9: the zero slab that pads K = 9 Cin to a multiple of 32 -- no mask bit)
         const bool ok = (a_mask[q] >> tap) & 1u;
         dma16_buf(ok ? a_voff[q] + toff : 0xffffff00u, a_rsrc, dst);   // (beyond any map < 4 GiB - 64 KiB)
@@ -437,7 +430,6 @@ __device__ __forceinline__ void gemm_q_body(
   const int a_rd0 = AH ? (wm * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16)
                        : (wm * 32 * RM + lr) * 64 + (((2 * kh) ^ sw) * 16);   // (+ 2 KiB per further row tile)
   const int a_rd1 = a_rd0 ^ 16;
-  const int a_rdp = (wm * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);   // AP: plane p at + p * BM * 32
   const int w_rd = A_STAGE + (wn * TN * 32 + lr) * 32 + ((kh ^ ((lr >> 3) & 1)) * 16);
 
   f32x16 acc[RM * TN];     // [row tile][column tile]
@@ -446,14 +438,8 @@ __device__ __forceinline__ void gemm_q_body(
   u32x4 wf[2][PL][TQ];     // W fragments: [set][plane][column tile (of the quarter, WIDE)]
   const float* const ab_lds = reinterpret_cast<const float*>(smem + ABOFF);
 
-  u32x4 rawp[PL];          // AP: the lane's operand pieces of the next slab, one per plane
   auto read_raw = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE;
-    if constexpr (AP) {
-#pragma unroll
-      for (int p = 0; p < PL; ++p) rawp[p] = *reinterpret_cast<const u32x4*>(st + a_rdp + p * (BM * 32));
-      return;
-    }
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
       raw[rt][0] = *reinterpret_cast<const f32x4*>(st + a_rd0 + rt * 2048);
@@ -521,11 +507,6 @@ __device__ __forceinline__ void gemm_q_body(
     }
   };
   auto split_raw = [&](const int slab, const int set) {
-    if constexpr (AP) {      // the planes ARE the operands
-#pragma unroll
-      for (int p = 0; p < PL; ++p) apl[set][0][p] = rawp[p];
-      return;
-    }
 #pragma unroll
    for (int rt = 0; rt < RM; ++rt) {
     f32x4 lo = raw[rt][0], hi = raw[rt][1];
@@ -1086,17 +1067,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TN == 2 &&
                                                                os, QLn{nullptr, nullptr, 0.f}, A2);
   PAVE_CLOCK_END();
 }
-// 3x3 form on a map that arrives as pre-split bf16 planes ([pixel][3][Cin], IO bit 2): no VALU split in the loop
-template <int TN, bool HT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_qp_kernel(
-    const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
-    const float* residual, float* out, const int M, const int K, const int N, const int relu, const QConv g,
-    const QOut os) {
-  PAVE_CLOCK_BEGIN(0);
-  gemm_q_body<TN, 1, 1, false, false, false, 0, 1, 3, HT, 4>(reinterpret_cast<const float*>(Ap), Wp, bias, residual, out,
-                                                             M, K, N, relu, nullptr, g, os, QLn{nullptr, nullptr, 0.f});
-  PAVE_CLOCK_END();
-}
 // the wide form: 128 x 256 block on 4 waves, 32 x 256 per wave, ring of 2
 template <int KIND, int PL = 3, int IO = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_w_kernel(
@@ -1463,47 +1433,6 @@ int launch_q(const float* a, const uint16_t* w, const float* bias, const float* 
   return PAVE_OK;
 }
 
-// fp32 rows [rows, C] -> the three bf16 planes of every row, [rows][3][C]: split8's terms (truncation, truncation,
-// rounded remainder), 8 values per lane
-__global__ __launch_bounds__(256) void split_rows_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ pl,
-                                                                const long long n8, const int c8) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-    const long long r = i / c8;
-    const int c = (int)(i - r * c8) * 8;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(x + i * 8);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-    u32x4 o[3];
-    split8(lo, hi, o);
-    uint16_t* dst = pl + (r * 3) * (long long)(c8 * 8) + c;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + (long long)p * c8 * 8) = o[p];
-  }
-}
-
-template <int TN, bool HT>
-int launch_qp(const uint16_t* a, const uint16_t* w, const float* bias, const float* residual, float* out,
-              long long M, int K, int N, int relu, hipStream_t st, const QConv g, const QOut os) {
-  constexpr int BN = TN * 32;
-  constexpr int STAGE = QBM * 32 * 3 + 3 * BN * 32;
-  constexpr int EPIB = 4 * 32 * QCST * 4;
-  constexpr int smem = QNS * STAGE > EPIB ? QNS * STAGE : EPIB;
-  const long long gx = ((M + QBM - 1) / QBM) * (N / BN);
-  if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_qp: grid too large");
-  auto kern = gemm_qp_kernel<TN, HT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess)
-      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_qp: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, st, a, w, bias, residual, out, (int)M, K, N, relu,
-                     g, os);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  return PAVE_OK;
-}
-
 // split-K second pass: out = act(sum over the parts IN ORDER + bias + residual), float4 per lane
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float* __restrict__ ws, const int parts, const long long total4, const int n4,
@@ -1762,7 +1691,7 @@ int launch_sk(const float* a, const uint16_t* w, const float* bias, const float*
 // (1 200 x 256 x 2 688: 22 | 15 | 15), at K = 1 024 it is what the launch waits for (300 .. 1 200 x 1024 x 256:
 // < 15 | 24 | 34).
 constexpr long long kSkTiles = 4096;     // 32 x 32 tiles (= blocks) up to which the K-split small-row form is taken
-constexpr long long kSkTiles256 = 512;   // ... and at K = 256 .. 511 (4 - 7 slabs per wave): only where the blocks fit one round
+constexpr long long kSkTiles256 = 1280;   // ... and at K = 256 .. 511 (4 - 7 slabs per wave): only where the blocks fit one round
 inline bool small_rows_ksplit_form(long long M, int N, int K) {
   const long long tiles = ((M + 31) / 32) * (((long long)N + 31) / 32);
   return (K >= 512 && tiles <= kSkTiles) || (K >= 256 && tiles <= kSkTiles256);
@@ -1794,14 +1723,22 @@ int launch_w(const float* a, const uint16_t* w, const float* bias, const float* 
   const long long gx = ((M + QBM - 1) / QBM) * (N / 256);
   if (gx >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "gemm_w: grid too large");
   auto kern = gemm_w_kernel<KIND, PL>;
+  // (diag variant 20, tools/coresidency_probe.py: 40 KiB more dynamic LDS than the kernel uses, so that ONE block
+  // fits a CU instead of two -- what a GEMM that leaves room for a co-resident sampler block would look like)
+#ifdef PAVE_DIAG
+  constexpr int kPad = 40 * 1024;
+#else
+  constexpr int kPad = 0;
+#endif
+  const int smem = w_smem<PL>() + (pave_internal_diag_variant() == 20 ? kPad : 0);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, w_smem<PL>()) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, w_smem<PL>() + kPad) != hipSuccess)
       return pave_internal_fail(PAVE_E_LAUNCH, "gemm_w: cannot raise dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), w_smem<PL>(), st, a, w, bias,
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ksplit), dim3(256), smem, st, a, w, bias,
                      residual, out, (int)M, K, N, relu, g, os, a2);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
@@ -1997,42 +1934,6 @@ int pave_internal_gemm_q(const float* a, const float* a_bias, const void* w_plan
   if (planes != 3) return pave_internal_fail(PAVE_E_ARG, "gemm_q: 3 bf16 planes or 1 fp16 plane");
   return gemm_q_dispatch<3>(a, a_bias, w_planes, bias, residual, residual_rows, out, out2, n_split, M, K, N, relu,
                             kind, H, W, Cin, Ho, Wo, stride, stream, a2, n_real, ksplit, ks_slabs);
-}
-
-int pave_internal_split_rows_planes(const float* x, void* planes, long long rows, int C, void* stream) {
-  if (rows <= 0 || C <= 0 || C % 8 != 0) return pave_internal_fail(PAVE_E_ARG, "split_rows_bf16x3: C %% 8 == 0");
-  const long long n8 = rows * (C / 8);
-  long long nb = (n8 + 255) / 256;
-  if (nb > 256 * 32) nb = 256 * 32;
-  hipLaunchKernelGGL(split_rows_planes_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     x, static_cast<uint16_t*>(planes), n8, C / 8);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  return PAVE_OK;
-}
-
-// 3x3 / pad 1 convolution of a map given as pre-split bf16 planes [N, H, W, 3, Cin] (stride 1 | 2), 3-plane weights
-// zero-padded to Np % 64 == 0 output rows, n_real real outputs; the narrow forms only (64 / 96 / 128-column tiles)
-int pave_internal_conv3x3_planes(const void* x_planes, const void* w_planes, const float* bias, const float* residual,
-                                 float* out, long long M, int K, int Np, int n_real, int relu, int H, int W, int Cin,
-                                 int Ho, int Wo, int stride, void* stream) {
-  const QConv g{H, W, Cin, Ho, Wo, stride,
-                Cin > 16 ? (unsigned)(((1ull << 32) + (Cin >> 4) - 1) / (unsigned)(Cin >> 4)) : 0u};
-  if (K % 32 != 0 || K < 64 || Cin % 16 != 0 || n_real <= 0 || n_real > Np || n_real % 4 != 0)
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_planes: K %% 32 == 0, Cin %% 16 == 0, n_real %% 4 == 0");
-  if ((M / ((long long)Ho * Wo)) * H * W * Cin * 6 >= (1ll << 32) - 65536)
-    return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv3x3_planes: the plane map must stay below 4 GiB");
-  const QOut os{nullptr, 0, 0, n_real, 0};
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const uint16_t* a = static_cast<const uint16_t*>(x_planes);
-  const uint16_t* w = static_cast<const uint16_t*>(w_planes);
-  if (Np == 64 && n_real > 32 && n_real <= 48)
-    return launch_qp<2, true>(a, w, bias, residual, out, M, K, Np, relu, st, g, os);
-  if (Np == 64) return launch_qp<2, false>(a, w, bias, residual, out, M, K, Np, relu, st, g, os);
-  if (Np == 128 && n_real <= 96 && n_real > 64)
-    return launch_qp<3, false>(a, w, bias, residual, out, M, K, Np, relu, st, g, os);
-  if (Np % 128 == 0) return launch_qp<4, false>(a, w, bias, residual, out, M, K, Np, relu, st, g, os);
-  return pave_internal_fail(PAVE_E_UNSUPPORTED, "conv3x3_planes: 64- or 128-row weight planes");
 }
 
 // merged encoder projection with the sampler's softmax / location arithmetic in the epilogue

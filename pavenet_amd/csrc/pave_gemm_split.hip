@@ -863,26 +863,6 @@ int pave_conv3x3_split_f32(const float* x, const void* w_planes, const float* bi
 #undef PAVE_CV
 }
 
-int pave_conv3x3_planes_f32(const void* x_planes, const void* w_planes, const float* bias,
-                            const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
-                            int stride, int relu, void* stream) {
-  if (!x_planes || !w_planes || !y) return pave_internal_fail(PAVE_E_ARG, "conv3x3_planes: null pointer");
-  if (N <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || (relu != 0 && relu != 1))
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_planes: bad sizes (stride 1 or 2; relu 0 | 1)");
-  if (Cin <= 0 || Cout <= 0 || Cin % 16 != 0 || Cout % 4 != 0)
-    return pave_internal_fail(PAVE_E_ARG, "conv3x3_planes: Cin %% 16 == 0 and Cout %% 4 == 0 required");
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const long long M = (long long)N * Ho * Wo;
-  if (M >= (1ll << 31)) return pave_internal_fail(PAVE_E_ARG, "conv3x3_planes: tensor too large");
-  return pave_internal_conv3x3_planes(x_planes, w_planes, bias, residual, y, M, (9 * Cin + 31) / 32 * 32,
-                                      (Cout + 63) / 64 * 64, Cout, relu, H, W, Cin, Ho, Wo, stride, stream);
-}
-
-int pave_split_rows_bf16x3_f32(const float* x, void* planes, long long rows, int C, void* stream) {
-  if (!x || !planes) return pave_internal_fail(PAVE_E_ARG, "split_rows_bf16x3: null pointer");
-  return pave_internal_split_rows_planes(x, planes, rows, C, stream);
-}
-
 long long pave_conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) ||
       Cin % 16 != 0 || Cout % 4 != 0 || g_diag_variant == 9)

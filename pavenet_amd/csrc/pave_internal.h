@@ -31,10 +31,6 @@ static inline int pave_internal_diag_variant() { return 0; }
 int pave_internal_gemm_f16act(const void* a, int a_f16, const void* w_plane, const float* bias, const float* residual,
                               const float* gamma, const float* beta, float eps, void* out, int out_f16, long long M,
                               int K, int N, int relu, void* stream);
-int pave_internal_split_rows_planes(const float* x, void* planes, long long rows, int C, void* stream);
-int pave_internal_conv3x3_planes(const void* x_planes, const void* w_planes, const float* bias, const float* residual,
-                                 float* out, long long M, int K, int Np, int n_real, int relu, int H, int W, int Cin,
-                                 int Ho, int Wo, int stride, void* stream);
 int pave_internal_stem7x7_q(const float* x, const void* w_stem, const float* bias, float* y, int N,
                             int H, int W, int pitch, int relu, void* stream, int planes = 3);
 #endif /* PAVE_INTERNAL_H_ */

@@ -52,8 +52,6 @@ SIGNATURES = {
     'pave_conv1x1_strided_split_f32': [_vp] * 4 + [_c_int] * 8 + [_vp],
     'pave_split_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_conv3x3_split_f32': [_vp] * 5 + [_c_int] * 8 + [_vp],
-    'pave_conv3x3_planes_f32': [_vp] * 5 + [_c_int] * 7 + [_vp],
-    'pave_split_rows_bf16x3_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _vp],
     'pave_bottleneck_chain_f32': [_vp] * 8 + [_c_int, _vp, _vp, _vp, _vp] + [_c_int] * 5 + [_vp],
     'pave_conv3x3_splitk_f32': [_vp] * 5 + [_c_int] * 7 + [_vp, ctypes.c_longlong, _c_int, _vp],
     'pave_gemm_bf16x3_encproj_f32': [_vp, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp,

@@ -1402,50 +1402,3 @@ def conv3x3_split(x, w_planes, bias=None, stride=1, relu=False, fp16=False, resi
             y.data_ptr(), N, H, W, Cin, Cout, int(stride), int(bool(relu)), npl, _stream_ptr())
     native.check(st, 'conv3x3_split')
     return y.permute(0, 3, 1, 2)
-
-
-def split_rows_bf16x3(x):
-    """x [..., C] fp32 (dense; C % 8 == 0) -> int16 [..., 3, C]: every row's three bf16 planes (truncation,
-    truncation, rounded remainder: x == p0 + p1 + p2 exactly) -- the A operand of conv3x3_planes
-    (pave_split_rows_bf16x3_f32)."""
-    lib = native.load()
-    _dev(x, 'x', torch.float32)
-    C = x.shape[-1]
-    _require(C % 8 == 0, 'split_rows_bf16x3: C % 8 == 0')
-    out = torch.empty(tuple(x.shape[:-1]) + (3, C), dtype=torch.int16, device=x.device)
-    with torch.cuda.device(x.device):
-        st = lib.pave_split_rows_bf16x3_f32(x.data_ptr(), out.data_ptr(), x.numel() // C, C, _stream_ptr())
-    native.check(st, 'split_rows_bf16x3')
-    return out
-
-
-def conv3x3_planes(x_planes, w_planes, bias=None, stride=1, relu=False, residual=None, cout=None):
-    """conv3x3_split on a map that arrives as its three bf16 planes: x_planes [N, H, W, 3, Cin] int16
-    (split_rows_bf16x3 of the NHWC map) -> [N, Cout, Ho, Wo] channels_last, bit-identical to the fp32-input form.
-    No VALU operand split in the loop (pave_conv3x3_planes_f32; the 48- / 96-channel 3x3 branches of HRNet-w48)."""
-    lib = native.load()
-    _dev(x_planes, 'x_planes', torch.int16)
-    _require(x_planes.dim() == 5 and x_planes.shape[3] == 3, 'conv3x3_planes: x_planes [N, H, W, 3, Cin]')
-    npl = _planes(w_planes, only=(3,))
-    N, H, W, _, Cin = x_planes.shape
-    _require(w_planes.shape[0] * 16 == (9 * Cin + 31) // 32 * 32,
-             'conv3x3_planes: w_planes [roundup(9 Cin, 32) / 16, 3, Cout, 16] (split_conv3x3_weight)')
-    Cout = int(cout) if cout is not None else w_planes.shape[2]
-    _require((Cout + 63) // 64 * 64 == w_planes.shape[2], 'conv3x3_planes: cout does not match the planes')
-    if bias is not None:
-        _dev(bias, 'bias', torch.float32)
-        _require(bias.numel() == Cout, 'conv3x3_planes: bias [Cout]')
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    if residual is not None:
-        _require(residual.is_cuda and residual.dtype == torch.float32 and tuple(residual.shape) == (N, Cout, Ho, Wo)
-                 and residual.is_contiguous(memory_format=torch.channels_last),
-                 'conv3x3_planes: residual [N, Cout, Ho, Wo] channels_last')
-    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x_planes.device)
-    with torch.cuda.device(x_planes.device), _Timed('conv3x3_split', 2 * N * Ho * Wo * Cout * 9 * Cin,
-                                                    (N * Ho * Wo, 9 * Cin, Cout, f'3x3 s{stride}', 'planes')):
-        st = lib.pave_conv3x3_planes_f32(
-            x_planes.data_ptr(), w_planes.data_ptr(), bias.data_ptr() if bias is not None else None,
-            residual.data_ptr() if residual is not None else None, y.data_ptr(), N, H, W, Cin, Cout, int(stride),
-            int(bool(relu)), _stream_ptr())
-    native.check(st, 'conv3x3_planes')
-    return y.permute(0, 3, 1, 2)
