@@ -270,7 +270,7 @@ def clip0_image(args, frames):
     return torch.randn(1, frames, 3, args.height, args.width, generator=g)
 
 
-def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
+def cpu_baseline_and_parity(model, args, frames, clip0, free_result, free_selection=None):
     """The oracle (CPU restatement of the reference's path with the torch-CPU sampler the
     reference's own CPU fallback uses) on clip 0: one small warm-up, then `cpu_baseline_clips`
     timed runs.  Its output is the parity reference for clip 0 of the timed batch."""
@@ -313,6 +313,10 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
     gk = gk.cpu()
     keep_equal = tuple(gk.shape) == tuple(ek.shape)
     max_px = float((gk[..., :2] - ek[..., :2]).abs().max()) if keep_equal else None
+    free_sel_equal = None
+    if free_selection is not None:
+        free_sel_equal = bool(torch.equal(free_selection[0].cpu().view(-1), taps['topk_idx'].view(-1))
+                              and torch.equal(free_selection[1].cpu().view(-1), taps['score_topk_idx'].view(-1)))
     # free run: how many of the oracle's kept poses the un-forced timed batch reproduced (within
     # 0.05 px); under random weights the two top-k selections sit on near-ties, so this is
     # reported, not asserted
@@ -323,7 +327,13 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result):
             matched += 1
     parity = dict(max_px=None if max_px is None else round(max_px, 5), keep_equal=bool(keep_equal),
                   oracle_poses=int(ek.shape[0]), free_run_poses_matched=matched,
-                  note='clip 0 vs the CPU oracle; max_px with the oracle\'s top-k selections pinned')
+                  free_run_selection_is_the_oracles=free_sel_equal,
+                  note='clip 0 vs the CPU oracle; max_px with the oracle\'s top-k selections pinned.  The free '
+                       '(un-pinned) timed run reproduces the oracle\'s poses only where it makes the oracle\'s '
+                       'selections: the 300 proposals are a sorted list and query i adds its own embedding to '
+                       'proposal i, so two logits ~1e-6 apart that swap places give two queries other inputs '
+                       '(tests/test_model_gpu.py::_full_size_vs_oracle re-runs the oracle with the device\'s '
+                       'selections forced in that case)')
     return base, parity
 
 
@@ -734,6 +744,11 @@ def main():
     # (neither pass may leave the ranks of a multi-rank job with different collective counts if it fails on one of
     # them: the census runs where the forward holds no collective -- every mode but the frame-sharded one --, the
     # clock pass, whose steps include the result all-gather, at N = 1 only)
+    free_selection = None
+    if rank == 0 and shard is None and hasattr(model.bbox_head.transformer, 'last_topk_proposals'):
+        with torch.no_grad():      # (the un-pinned selections of clip 0, as the timed steps made them)
+            r_ = model.forward_device(img, metas)
+        free_selection = (model.bbox_head.transformer.last_topk_proposals[0].clone(), r_['score_index'][0].clone())
     census = None
     if shard is None:
         try:
@@ -917,7 +932,7 @@ def main():
             kept = last[0, -N:] > 0.5
             free_kpts = last[0, N * 5:N * 5 + N * K * 3].view(N, K, 3)[kept]
             line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(model, args, T, clip0,
-                                                                           free_kpts)
+                                                                           free_kpts, free_selection)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -794,7 +794,7 @@ def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=
     """bench.py's batch of a BASELINE configuration at 800 x 1344 (bench weights, headline GEMM mode
     'bf16x3', shipped GEMM selections): clip 0 against ONE run of the CPU oracle -- key points within
     1e-3 px with the oracle's two top-k selections pinned, equal OKS-NMS keep sets, and the FREE run
-    (nothing pinned) reproducing every pose the oracle kept.  gemm='fp16' (BASELINE configs[4]'s fp16 MFMA
+    (nothing pinned) making a valid selection and reproducing every pose the oracle keeps under it.  gemm='fp16' (BASELINE configs[4]'s fp16 MFMA
     projections, BASELINE.md section 4: <= 0.5 px): the pinned comparison at tol_px and equal keep sets."""
     import bench
     from pavenet_amd import bricks, tuning
@@ -840,8 +840,12 @@ def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=
     try:
         with torch.no_grad():
             # (strict: the forward raises if a torch / vendor compute operator ran on a device tensor)
-            free = m.bbox_head.results_to_list(m.forward_device(img, metas, strict=True))[0][2].cpu()
+            free_res = m.forward_device(img, metas, strict=True)
+            free = m.bbox_head.results_to_list(free_res)[0][2].cpu()
             assert not m.last_census.slow_paths, m.last_census.slow_paths
+            free_sel = (m.bbox_head.transformer.last_topk_proposals[0].cpu().clone(),
+                        free_res['score_index'][0].cpu().clone(),
+                        m.bbox_head.transformer.last_enc_cls[0, :, 0].cpu().clone())
             res = m.forward_device(img[:1], metas[:1],
                                    force_topk_proposals=taps['topk_idx'].cuda(),
                                    force_score_topk=taps['score_topk_idx'].view(1, -1).cuda())
@@ -897,10 +901,29 @@ def _full_size_vs_oracle(T, B, backbone='r50', seed=1234, gemm='bf16x3', tol_px=
             _close(gb_.cpu().numpy()[:, :4], cb.numpy()[:, :4], rtol=0, atol=1e-3)
             _close(gk_.cpu().numpy()[..., 2], ck.numpy()[..., 2], rtol=1e-4, atol=1e-5)
         return
-    # the un-pinned batch run found every oracle pose (its own top-k, its own NMS)
-    assert free.shape[0] == ek.shape[0], (free.shape, ek.shape)
-    for pose in ek[..., :2]:
-        assert float((free[..., :2] - pose).abs().amax(dim=(1, 2)).min()) <= 1e-3
+    # the un-pinned batch run (its own top-k selections, its own NMS).  The proposal top-k is a SORTED list of 300 of
+    # ~22 000 logits and query i adds its own embedding to proposal i (OT:21400-21403), so two logits a few 1e-6
+    # apart that swap places between the CPU oracle and the device give two queries other inputs: a free run can
+    # only be expected to reproduce the oracle's poses where it makes the oracle's selections.  Hence: the free
+    # selection must be a valid top-k of OUR logits up to near-ties; if it IS the oracle's, every oracle pose is
+    # reproduced within 1e-3 px; if it differs on near-ties, the oracle is run once more with the device's own
+    # selections forced and must then give the device's poses (<= 1e-3 px, same keep set).
+    free_prop, free_score, free_logits = free_sel
+    _assert_same_selection(free_logits, taps['topk_idx'], 1e-4, 'proposals (free run)')
+    same = torch.equal(free_prop, taps['topk_idx'].view(-1)) and torch.equal(free_score, taps['score_topk_idx'].view(-1))
+    ek_free = ek
+    if not same:
+        old = R.SAMPLER
+        R.SAMPLER = 'torch'
+        try:
+            with torch.no_grad():
+                t2 = {'force_topk_idx': free_prop.view(1, -1), 'force_score_topk_idx': free_score.view(-1)}
+                _, _, ek_free = R.videopose_simple_test(sd, cfg, clip0, img_shape=shapes[0], taps=t2)
+        finally:
+            R.SAMPLER = old
+    assert free.shape[0] == ek_free.shape[0], (free.shape, ek_free.shape, same)
+    for pose in ek_free[..., :2]:
+        assert float((free[..., :2] - pose).abs().amax(dim=(1, 2)).min()) <= 1e-3, same
 
 
 def test_bench_batch_full_size_t7_b4_vs_oracle():
