@@ -562,7 +562,10 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // 15 / 16 = two row tiles per wave (256-row blocks) for the 64- / 96-column
                          // tile forms and the ResNet layer1 chain: never / wherever the form exists,
                          // 17 = no half-tail form (33 .. 48 output columns of a 3x3 as zero-padded 32x32x16
-                         // products instead of 16x16x32 products over slab pairs)
+                         // products instead of 16x16x32 products over slab pairs),
+                         // 19 = the small-row selection of rounds 4 - 5 (no K-split small-row form: the forms the
+                         // bit-equality tests compare), 20 = the wide GEMM capped at one block per CU (40 KiB of
+                         // unused dynamic LDS; tools/coresidency_probe.py)
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {

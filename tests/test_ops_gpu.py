@@ -1800,10 +1800,11 @@ def test_fp16_operand_mode_on_every_fused_form(form):
         w2p, b2 = ops.split_conv3x3_weight(rnd(64, 64, 3, 3, sc=0.05).cuda(), F16), rnd(64, sc=0.1).cuda()
         w3p, b3 = ops.split_weight_bf16x3(rnd(256, 64, sc=0.08).cuda(), F16), rnd(256, sc=0.1).cuda()
         w1p, b1 = ops.split_weight_bf16x3(rnd(64, 256, sc=0.05).cuda(), F16), rnd(64, sc=0.1).cuda()
-        c2 = ops.conv3x3_split(c1, w2p, b2, relu=True)
-        exp_out = ops.gemm_bf16x3(c2.permute(0, 2, 3, 1).reshape(-1, 64), w3p, b3,
-                                  xin.permute(0, 2, 3, 1).reshape(-1, 256), relu=True)
-        exp_c1n = ops.gemm_bf16x3(exp_out, w1p, b1, relu=True)
+        with native.diag_build(19):    # (the separate launches on the tile kernels: at these few rows the shipped
+            c2 = ops.conv3x3_split(c1, w2p, b2, relu=True)     # selection takes the K-split small-row form)
+            exp_out = ops.gemm_bf16x3(c2.permute(0, 2, 3, 1).reshape(-1, 64), w3p, b3,
+                                      xin.permute(0, 2, 3, 1).reshape(-1, 256), relu=True)
+            exp_c1n = ops.gemm_bf16x3(exp_out, w1p, b1, relu=True)
         for v in (15, 16):      # 128- and 256-row tiles of the chain launch
             with native.diag_build(v):
                 out, c1n = ops.bottleneck_chain(c1, w2p, b2, w3p, b3, residual=xin, w1n_planes=w1p, b1n=b1)
@@ -1844,7 +1845,9 @@ def test_fp16_activations_between_two_launches_change_no_value(M):
     h32 = ops.gemm_fp16_act(xd, p1, b1.cuda(), relu=True)                      # fp32 in, fp32 out
     h16 = ops.gemm_fp16_act(xd, p1, b1.cuda(), relu=True, out_half=True)       # fp32 in, fp16 out
     assert h16.dtype == torch.float16 and torch.equal(h16, h32.half())
-    assert torch.equal(h32, ops.gemm_bf16x3(xd, p1, b1.cuda(), relu=True))     # = the ordinary fp16-mode launch
+    from pavenet_amd import native
+    with native.diag_build(19):     # (tile kernels: the shipped selection splits K over a block's waves at these rows)
+        assert torch.equal(h32, ops.gemm_bf16x3(xd, p1, b1.cuda(), relu=True))     # = the ordinary fp16-mode launch
     ln = (ga.cuda(), be.cuda(), 1e-5)
     o32 = ops.gemm_fp16_act(h32, p2, b2.cuda(), residual=idt.cuda(), ln=ln)
     o16 = ops.gemm_fp16_act(h16, p2, b2.cuda(), residual=idt.cuda(), ln=ln)
