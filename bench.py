@@ -92,6 +92,10 @@ def parse():
                     help='steps in flight: P > 1 runs consecutive steps (independent batches) on P HIP '
                          'streams, so the launch-bound decoder / post-processing tail of step i overlaps '
                          'the backbone of step i + 1; results are still copied to the host per step')
+    ap.add_argument('--no-extra-passes', action='store_true',
+                    help='skip the un-timed passes behind the timed region (ATen census, free-selection forward, '
+                         'in-kernel clock pass on the diagnostic build): profiling runs, whose traces should hold the '
+                         'timed steps only')
     ap.add_argument('--no-events', action='store_true',
                     help='do not bracket the tagged kernels with HIP events (A/B of the measurement overhead)')
     ap.add_argument('--gemm-select', choices=('tuned', 'default', 'tune'), default='tuned',
@@ -206,10 +210,21 @@ def algorithmic_bytes_gemm_launch(tag, shape):
     return a + M * N * 4 + res
 
 
-def algorithmic_bytes_encoder_launch(n_frames):
+def tokens_per_frame(height, width):
+    """S of the 4-level pyramid the R-50 / ChannelMapper stack makes of a height x width frame: strides 8, 16, 32,
+    64, every halving rounded up (22 323 at 800 x 1344, 20 906 at 750 x 1333)."""
+    h, w = (height + 7) // 8, (width + 7) // 8
+    s = 0
+    for _ in range(4):
+        s += h * w
+        h, w = (h + 1) // 2, (w + 1) // 2
+    return s
+
+
+def algorithmic_bytes_encoder_launch(n_frames, height=800, width=1344):
     """4 B x [value S*256 + offsets/logits S*8*16*3 + out S*256] per frame-layer
     = 80.0 MB at S = 22 323; one launch covers all frames of the batch."""
-    return 4 * n_frames * S_TOKENS * (256 + 8 * 16 * 3 + 256)
+    return 4 * n_frames * tokens_per_frame(height, width) * (256 + 8 * 16 * 3 + 256)
 
 
 def census_of_step(model, img, metas, **kw):
@@ -745,18 +760,20 @@ def main():
     # them: the census runs where the forward holds no collective -- every mode but the frame-sharded one --, the
     # clock pass, whose steps include the result all-gather, at N = 1 only)
     free_selection = None
-    if rank == 0 and shard is None and hasattr(model.bbox_head.transformer, 'last_topk_proposals'):
+    if rank == 0 and shard is None and not args.no_extra_passes \
+            and hasattr(model.bbox_head.transformer, 'last_topk_proposals'):
         with torch.no_grad():      # (the un-pinned selections of clip 0, as the timed steps made them)
             r_ = model.forward_device(img, metas)
         free_selection = (model.bbox_head.transformer.last_topk_proposals[0].clone(), r_['score_index'][0].clone())
     census = None
-    if shard is None:
+    if shard is None and not args.no_extra_passes:
         try:
             census = census_of_step(model, img, metas)
         except Exception as e:
             census = dict(census_error=f'{type(e).__name__}: {e}'[:200])
     clock = None
-    if dist is None and args.gemm != 'native' and graphed is None and tail_graph is None and not args.no_events:
+    if dist is None and args.gemm != 'native' and graphed is None and tail_graph is None and not args.no_events \
+            and not args.no_extra_passes:
         clock = class_clock_pass(lambda: step())
     timed_ev = [(tag, s.elapsed_time(e) * 1e-3, fl) for tag, s, e, fl, _ in events]
     shaped_ev = [(tag, s.elapsed_time(e) * 1e-3, fl, sh) for tag, s, e, fl, sh in events]
@@ -841,7 +858,7 @@ def main():
         roofline = dict(skipped='graph replay: kernels are not launched through the timed wrappers')
     elif enc:
         avg = sum(t for _, t in enc) / len(enc)
-        alg = algorithmic_bytes_encoder_launch(n_frames)
+        alg = algorithmic_bytes_encoder_launch(n_frames, args.height, args.width)
         achieved = alg / avg / 1e9
         tile = enc[0][0] == 'enc_tile'
         roofline = dict(bound='hbm',

@@ -14,6 +14,7 @@ bash tools/pmc_enc_tile.sh ${P}_pmc_enc > gpurun_out/${P}_pmc_enc_tile.txt 2>&1 
 bash tools/pmc_bench_enc.sh ${P}_enc_traffic > gpurun_out/${P}_enc_traffic.log 2>&1 && echo "enc traffic ok"
 python3 tools/gemm_census.py 3 > gpurun_out/${P}_gemm_shapes.txt 2>&1 && echo "census ok"
 SEQ_MIN_US=0 bash tools/profile_bench.sh ${P}_t3b1 --frames 3 --clips 1 --steps 6 && echo "configs[1] trace ok"
+SEQ_MIN_US=0 bash tools/profile_bench.sh ${P}_t3b1_750x1333 --frames 3 --clips 1 --steps 6 --height 750 --width 1333 && echo "PoseTrack canvas trace ok"
 SEQ_MIN_US=40 bash tools/profile_bench.sh ${P}_swin_l_t3 --backbone swin_l --frames 3 --clips 1 && echo "swin trace ok"
 python3 tools/gemm_census.py 3 0 3 1 r50 > gpurun_out/${P}_gemm_shapes_t3b1.txt 2>&1 && echo "census t3 ok"
 python3 tools/gemm_census.py 3 0 15 1 r50 fp16 > gpurun_out/${P}_gemm_shapes_t15_fp16.txt 2>&1 && echo "census t15 fp16 ok"

@@ -9,7 +9,7 @@ mkdir -p $R/gpurun_out/$OUT
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side --no-secondary > $R/gpurun_out/$OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side --no-secondary --no-extra-passes > $R/gpurun_out/$OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json, hashlib

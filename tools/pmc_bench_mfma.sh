@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$OUT
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_]*MFMA[A-Z_0-9]*" | sort -u > $R/gpurun_out/$OUT/mfma_counters_available.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv \
-  -d $R/gpurun_out/$OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side --no-secondary "$@" > $R/gpurun_out/$OUT/p1.log 2>&1
+  -d $R/gpurun_out/$OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-native-side --no-secondary --no-extra-passes "$@" > $R/gpurun_out/$OUT/p1.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 rows = []

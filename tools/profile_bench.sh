@@ -6,7 +6,7 @@ NAME=$1; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$NAME
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-native-side --no-secondary "$@" > $R/gpurun_out/${NAME}_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-native-side --no-secondary --no-extra-passes "$@" > $R/gpurun_out/${NAME}_run.log 2>&1
 T=$(find /tmp/prof_$NAME -name '*kernel_trace.csv' | head -1)
 S=$(find /tmp/prof_$NAME -name '*kernel_stats.csv' | head -1)
 python3 $R/tools/trace_stats.py $T 5 > $R/gpurun_out/${NAME}_steady.txt
