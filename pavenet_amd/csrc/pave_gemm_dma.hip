@@ -1692,9 +1692,13 @@ int launch_sk(const float* a, const uint16_t* w, const float* bias, const float*
 // < 15 | 24 | 34).
 constexpr long long kSkTiles = 4096;     // 32 x 32 tiles (= blocks) up to which the K-split small-row form is taken
 constexpr long long kSkTiles256 = 1280;   // ... and at K = 256 .. 511 (4 - 7 slabs per wave): only where the blocks fit one round
+// ... and only up to 2 048 rows: a block re-reads its A rows once per 32 output columns, which a few hundred
+// query rows do from L2 for free and a 3 150-pixel layer4 map of a one-clip batch does not (3 150 x 2048 x 512 took
+// 93 us on this form in the step's trace, 45 on the tile kernels).
+constexpr long long kSkRows = 2048;
 inline bool small_rows_ksplit_form(long long M, int N, int K) {
   const long long tiles = ((M + 31) / 32) * (((long long)N + 31) / 32);
-  return (K >= 512 && tiles <= kSkTiles) || (K >= 256 && tiles <= kSkTiles256);
+  return M <= kSkRows && ((K >= 512 && tiles <= kSkTiles) || (K >= 256 && tiles <= kSkTiles256));
 }
 
 // Which launches take the small-row form: fewer than 64 tiles of 128 x 128 (and < 8 192 rows).  tools/

@@ -676,6 +676,30 @@ def split_weight_bf16x3(weight, planes=3, pad=False):
     return pl.view(pl.shape[0], N, K // 16, 16).permute(2, 0, 1, 3).contiguous()
 
 
+BLOCK_SLOTS = 512         # resident GEMM blocks of the chip: 256 CUs x 2 blocks of the wide / LayerNorm forms
+ROUND_SPLIT = True        # A/B switch of round_split_rows (tools/ab_switch.py)
+
+
+def round_split_rows(M, tiles_per_row_tile):
+    """Block-slot quantisation: a launch whose tile count lands just above a multiple of the chip's 512 block slots
+    runs a whole extra round for a handful of tiles (3 x 22 323 rows = 524 row tiles: every LayerNorm-epilogue launch
+    of a one-clip T = 3 step ran a second round of 12 tiles -- 227 us where one round takes 110).  Returns the row
+    count M1 of the FULL rounds when the last round would be less than an eighth full and its rows (at most 2 048)
+    fit the small-row forms -- the caller launches rows [0, M1) and [M1, M) separately (GEMM rows are independent:
+    the same values up to the summation order of the form each part takes) -- else None."""
+    if not ROUND_SPLIT:
+        return None
+    rt = (M + 127) // 128
+    per_round = BLOCK_SLOTS // max(1, tiles_per_row_tile)      # row tiles per round
+    if per_round < 1 or rt <= per_round:
+        return None
+    r = rt % per_round
+    if r == 0 or r * tiles_per_row_tile > BLOCK_SLOTS // 8:
+        return None
+    M1 = (rt - r) * 128
+    return M1 if 0 < M - M1 <= 2048 else None
+
+
 _ACT_CODE = {'gelu': 2, 'sigmoid': 3}     # pave_gemm_bf16x3_f32's `relu` argument beyond 0 / 1
 SPLITK_ROWS = True     # plain row GEMMs with a split-K plan take pave_gemm_bf16x3_splitk_f32 (tools: A/B switch)
 
@@ -717,6 +741,14 @@ def gemm_bf16x3(a, w_planes, bias=None, residual=None, relu=False, out=None, a_b
     else:
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3: out [M,N]')
+    if N % 256 == 0 and npl in _Q_PLANES and a_bias is None and N == w_planes.shape[2]:
+        M1 = round_split_rows(M, N // 256)          # (the wide form's tiles: N / 256 per row tile)
+        if M1 is not None:
+            gemm_bf16x3(a[:M1], w_planes, bias, residual[:M1] if residual is not None else None, relu=relu,
+                        out=out[:M1], fp16=fp16)
+            gemm_bf16x3(a[M1:], w_planes, bias, residual[M1:] if residual is not None else None, relu=relu,
+                        out=out[M1:], fp16=fp16)
+            return out
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     # few row tiles and a long K (a one-clip batch's layer4 1x1 reductions, the neck's C5 lateral): the split-K
     # form, as for the 3x3 convolutions (workspace from torch's stream-aware caching allocator)
@@ -1013,6 +1045,13 @@ def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):
     else:
         _dev(out, 'out', torch.float32)
         _require(tuple(out.shape) == (M, N), 'gemm_bf16x3_ln: out [M,N]')
+    M1 = round_split_rows(M, 1)
+    if M1 is not None:      # (the last, nearly empty round of block slots as a launch of the small-row form)
+        gemm_bf16x3_ln(a[:M1], w_planes, bias, residual[:M1] if residual is not None else None, gamma, beta, eps,
+                       out=out[:M1])
+        gemm_bf16x3_ln(a[M1:], w_planes, bias, residual[M1:] if residual is not None else None, gamma, beta, eps,
+                       out=out[M1:])
+        return out
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3_ln', M), 2 * M * K * N, (M, K, N, 'ln', 'res' if residual is not None else '')):
         st = lib.pave_gemm_bf16x3_ln_f32(a.data_ptr(), w_planes.data_ptr(), ptr(bias), ptr(residual),
@@ -1069,7 +1108,7 @@ def gemm_fp16_act(a, w_plane, bias=None, relu=False, out_half=False, residual=No
 
 
 def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_split=0, relu=False,
-                   a_bias=None, fp16=False):
+                   a_bias=None, fp16=False, _out=None):
     """gemm_bf16x3 with a row-periodic residual table (`residual` [residual_rows, N], row m adds
     residual[m % residual_rows]) and / or the output cut at column `n_split` into two dense
     matrices -> out [M, n_split], out2 [M, N - n_split] (n_split = 0: one output, out2 = None)."""
@@ -1095,8 +1134,21 @@ def gemm_bf16x3_ex(a, w_planes, bias=None, residual=None, residual_rows=0, n_spl
     n_split = int(n_split)
     _require(n_split == 0 or (0 < n_split < N and n_split % 128 == 0),
              'gemm_bf16x3_ex: 0 < n_split < N, n_split % 128 == 0')
-    out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
-    out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
+    if N % 256 == 0 and npl in _Q_PLANES and a_bias is None and rr == 0 and (n_split == 0 or n_split % 256 == 0) \
+            and _out is None:
+        M1 = round_split_rows(M, N // 256)      # (a nearly empty last round of block slots: see round_split_rows)
+        if M1 is not None:
+            out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
+            out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
+            for r0, r1 in ((0, M1), (M1, M)):
+                gemm_bf16x3_ex(a[r0:r1], w_planes, bias, residual[r0:r1] if residual is not None else None, 0, n_split,
+                               relu, None, fp16, _out=(out[r0:r1], out2[r0:r1] if out2 is not None else None))
+            return out, out2
+    if _out is not None:
+        out, out2 = _out
+    else:
+        out = torch.empty((M, n_split or N), dtype=torch.float32, device=a.device)
+        out2 = torch.empty((M, N - n_split), dtype=torch.float32, device=a.device) if n_split else None
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(a.device), _Timed(_gemm_tag('gemm_bf16x3', M), 2 * M * K * N, (M, K, N, 'ex', f'rows{rr}', f'split{n_split}')):
         st = lib.pave_gemm_bf16x3_ex_f32(a.data_ptr(), ptr(a_bias), w_planes.data_ptr(), ptr(bias),

@@ -1425,7 +1425,7 @@ def test_gemm_forms_random_shapes_bit_identical(seed):
     # (round 6: few-tile launches with K >= 512 take the K-split small-row form in the shipped selection -- the
     # same fp32 terms added in another association: equal to rounding there, bit-identical everywhere else)
     t32 = ((M + 31) // 32) * ((N + 31) // 32)
-    ksplit = not nsplit and ((K >= 512 and t32 <= 4096) or (K >= 256 and t32 <= 1280))
+    ksplit = not nsplit and M <= 2048 and ((K >= 512 and t32 <= 4096) or (K >= 256 and t32 <= 1280))
     for v in (8, 7, 0):
         if v == 0 and ksplit:
             scale = float(outs[9].abs().max()) + 1e-6
@@ -2323,3 +2323,45 @@ def test_neck_1x1_level_with_96_channels_runs_the_split_gemm():
     assert y is not None, 'the K = 96 level fell back to the library'
     exp = torch.nn.functional.conv2d(x.double(), conv.weight.double())
     np.testing.assert_allclose(y.detach().cpu().numpy(), exp.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_round_split_of_a_nearly_empty_last_block_round():
+    """ops.round_split_rows: 3 x 22 323 rows (a one-clip T = 3 step) are 524 row tiles for the chip's 512 block slots,
+    so every wide / LayerNorm-epilogue launch of the encoder ran a second round for 12 tiles.  The rows of the full
+    rounds and the remainder (1 433 rows, small-row forms) are launched separately: same values as the one-launch
+    form up to the summation order of the form each part takes; the rule itself on a few sizes."""
+    from pavenet_amd import ops
+    assert ops.round_split_rows(3 * 22323, 1) == 512 * 128          # LayerNorm form: one tile per row tile
+    assert ops.round_split_rows(3 * 22323, 4) == 512 * 128          # FFN1 (N = 1024): 4 tiles per row tile, 128 per round
+    assert ops.round_split_rows(28 * 22323, 1) is None              # 4 884 tiles: the last round is half full
+    assert ops.round_split_rows(3 * 20906, 1) is None               # the 750 x 1333 canvas: 490 tiles, one round
+    assert ops.round_split_rows(512 * 128, 1) is None and ops.round_split_rows(300, 1) is None
+    M = 3 * 22323
+    g = torch.Generator(device='cuda').manual_seed(5)
+    a = torch.randn(M, 256, device='cuda', generator=g)
+    w1 = torch.randn(1024, 256, device='cuda', generator=g) / 16
+    b1 = torch.randn(1024, device='cuda', generator=g)
+    wp1 = ops.split_weight_bf16x3(w1)
+    w2 = torch.randn(256, 1024, device='cuda', generator=g) / 32
+    wp2 = ops.split_weight_bf16x3(w2)
+    b2, ga, be = (torch.randn(256, device='cuda', generator=g) for _ in range(3))
+    res = torch.randn(M, 256, device='cuda', generator=g)
+    try:
+        ops.ROUND_SPLIT = False
+        h_one = ops.gemm_bf16x3(a, wp1, b1, relu=True)
+        o_one = ops.gemm_bf16x3_ln(h_one, wp2, b2, res, ga, be, 1e-5)
+    finally:
+        ops.ROUND_SPLIT = True
+    h_two = ops.gemm_bf16x3(a, wp1, b1, relu=True)
+    o_two = ops.gemm_bf16x3_ln(h_one, wp2, b2, res, ga, be, 1e-5)
+    inplace = res.clone()
+    assert ops.gemm_bf16x3_ln(h_one, wp2, b2, inplace, ga, be, 1e-5, out=inplace).data_ptr() == inplace.data_ptr()
+    torch.cuda.synchronize()
+    M1 = 512 * 128
+    assert torch.equal(h_two[:M1], h_one[:M1]) and torch.equal(o_two[:M1], o_one[:M1])     # the full rounds: same launch form
+    np.testing.assert_allclose(h_two[M1:].cpu().numpy(), h_one[M1:].cpu().numpy(), rtol=0, atol=4e-6 * float(h_one.abs().max()))
+    np.testing.assert_allclose(o_two[M1:].cpu().numpy(), o_one[M1:].cpu().numpy(), rtol=0, atol=2e-5)
+    assert torch.equal(inplace, o_two)
+    exp = torch.nn.functional.layer_norm(h_one[M1:].double() @ w2.double().t() + b2.double() + res[M1:].double(), (256,),
+                                         ga.double(), be.double(), 1e-5)
+    np.testing.assert_allclose(o_two[M1:].cpu().numpy(), exp.cpu().numpy(), rtol=2e-5, atol=2e-5)
