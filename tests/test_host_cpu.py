@@ -453,3 +453,30 @@ def test_launch_census_classifies_aten_operators():
         lin(x)
     assert not none.fallback_ops and not none.aten_launches
     none.raise_on_fallback('test')
+
+
+def test_round_split_rule_and_token_count():
+    """Host rules of round 6: ops.round_split_rows (rows of the full rounds of the chip's 512 block slots when the
+    last round would be nearly empty and its rows fit the small-row forms) and bench.tokens_per_frame (S of the
+    4-level pyramid of a canvas: the byte count of the encoder roofline)."""
+    import importlib.util
+    from pavenet_amd import ops
+    assert ops.round_split_rows(3 * 22323, 1) == 65536 and ops.round_split_rows(3 * 22323, 4) == 65536
+    assert ops.round_split_rows(3 * 22323, 2) == 65536                      # value-projection pairs: N = 512
+    assert ops.round_split_rows(28 * 22323, 1) is None                      # last round half full
+    assert ops.round_split_rows(15 * 22323, 1) is None                      # 57 tiles = 7 296 rows: beyond the small-row forms
+    assert ops.round_split_rows(3 * 20906, 1) is None                       # 490 tiles: one round
+    assert ops.round_split_rows(65536, 1) is None and ops.round_split_rows(65537, 1) == 65536
+    old = ops.ROUND_SPLIT
+    try:
+        ops.ROUND_SPLIT = False
+        assert ops.round_split_rows(3 * 22323, 1) is None
+    finally:
+        ops.ROUND_SPLIT = old
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.tokens_per_frame(800, 1344) == 22323 == bench.S_TOKENS
+    assert bench.tokens_per_frame(750, 1333) == 94 * 167 + 47 * 84 + 24 * 42 + 12 * 21 == 20906
+    assert bench.algorithmic_bytes_encoder_launch(1) == 4 * 22323 * 896
