@@ -55,6 +55,12 @@ const char* pave_last_error(void);
  *   out            [bs, Lq, M*D]  (fully overwritten; need not be zeroed)
  * im2col_step only reproduces the reference's divisibility check
  * (ms_deform_attn_cuda.cu:242-245): min(bs, step) must divide bs.
+ * Two kernels behind it: D %% 4 == 0 fp32 takes msda_fwd_vec_kernel (G lanes x 4 channels per (query, head),
+ * float4 corner loads); every other case -- fp64, D not a multiple of 4 (the reference's gradcheck list has 30, 71
+ * and 1025) -- takes msda_fwd_scalar_kernel, the COMPATIBILITY FALLBACK of this entry point: one thread per output
+ * element, i.e. the reference kernel's own work decomposition (ms_deform_attn_cuda_kernel.cuh:200-254), kept for
+ * coverage of the drop-in signature and not a CDNA4 design.  The PAVE-Net forward path never calls either: it runs
+ * on the fused launches below (pave_enc_deform_attn_tile_f32, pave_deform_attn_*_fused_f32).
  */
 int pave_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start, const float* sampling_loc,
