@@ -1690,129 +1690,11 @@ int launch_sk(const float* a, const uint16_t* w, const float* bias, const float*
 // K-split | one-wave form | tile kernels): at K = 256 a wave's whole walk is 16 slabs and the split only adds blocks
 // (1 200 x 256 x 2 688: 22 | 15 | 15), at K = 1 024 it is what the launch waits for (300 .. 1 200 x 1024 x 256:
 // < 15 | 24 | 34).
-// ---------------------------------------------------------------------------
-// Linear + bias + identity + LayerNorm at few rows in ONE launch (round 6): the decoders' out_proj / FFN2 behind
-// their post-norm (bricks/transformer.py:1316-1353) were the K-split GEMM above plus a LayerNorm pass -- two
-// dependent launches, 15 times per step on the latency-bound tail.  A block owns 32 WHOLE rows of the 256-column
-// output: 16 waves = 8 column tiles x 2 halves of the K axis, each walking its half with the small-row form's
-// loads; the partial tiles land in LDS as [half][row][column] (64 KiB), and after one barrier wave w finishes rows
-// 2 w and 2 w + 1: x = (p0 + p1) + bias + identity in that fixed order, two-pass mean / centred variance over the
-// row by wave reduction (a lane holds 4 consecutive columns), gamma / beta, one coalesced 1-KiB store per row.
-// Deterministic; equal to the other LayerNorm forms to rounding (the K halves and the row statistics are summed in
-// another order).
-// ---------------------------------------------------------------------------
-template <int PF, int PL = 3>
-__global__ __launch_bounds__(1024) void gemm_skln_kernel(
-    const float* __restrict__ A, const uint16_t* __restrict__ Wp, const float* __restrict__ bias,
-    const float* residual, float* out, const int M, const int K, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float eps) {
-  constexpr int N = 256;
-  extern __shared__ __attribute__((aligned(16))) float part[];      // [2][32][256]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ct = wave & 7, half = wave >> 3;
-  const int lr = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * 32, n0 = ct * 32;
-  const int nslabs = K >> 4;
-  const int per = (nslabs + 1) >> 1;
-  const int sb = half * per, se = min(nslabs, sb + per);
-  const int arow = min(m0 + lr, M - 1);                // rows past M: stand-in data, never stored
-  const float* ap = A + (long long)arow * K + kh * 8;
-  const uint16_t* wp = Wp + ((long long)(n0 + lr) * 16 + kh * 8);
-  const long long w_plane = (long long)N * 16, w_slab = PL * w_plane;   // in 16-bit elements
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32x4 raw[PF][2];
-  u32x4 wf[PF][PL];
-  auto load = [&](const int slab, const int set) {
-    raw[set][0] = *reinterpret_cast<const f32x4*>(ap + slab * 16);
-    raw[set][1] = *reinterpret_cast<const f32x4*>(ap + slab * 16 + 4);
-#pragma unroll
-    for (int p = 0; p < PL; ++p)
-      wf[set][p] = *reinterpret_cast<const u32x4*>(wp + slab * w_slab + p * w_plane);
-  };
-#pragma unroll
-  for (int u = 0; u < PF; ++u)
-    if (sb + u < se) load(sb + u, u);
-  for (int s = sb; s < se; s += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      if (s + u < se) {
-        u32x4 apl[PL];
-        if constexpr (PL == 1) {
-          apl[0] = u32x4{pack_rne_f16(raw[u][0].x, raw[u][0].y), pack_rne_f16(raw[u][0].z, raw[u][0].w),
-                         pack_rne_f16(raw[u][1].x, raw[u][1].y), pack_rne_f16(raw[u][1].z, raw[u][1].w)};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, apl[0]),
-                                                       __builtin_bit_cast(f16x8, wf[u][0]), acc, 0, 0, 0);
-        } else {
-          split8(raw[u][0], raw[u][1], apl);
-#pragma unroll
-          for (int o = 2; o >= 0; --o)
-#pragma unroll
-            for (int pa = 0; pa <= o; ++pa)
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, apl[pa]),
-                                                            __builtin_bit_cast(bf16x8, wf[u][o - pa]), acc, 0, 0, 0);
-        }
-        if (s + u + PF < se) load(s + u + PF, u);
-      }
-    }
-  }
-  // partial tile -> LDS [half][row][column]: register r = row (r & 3) + 8 (r >> 2) + 4 kh, column n0 + lr
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    part[(half * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N + n0 + lr] = acc[r];
-  __syncthreads();
-  // wave w: rows 2 w, 2 w + 1; a lane holds columns 4 lane .. 4 lane + 3
-  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * lane);
-  const float4 e4 = *reinterpret_cast<const float4*>(beta + 4 * lane);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lrow = 2 * wave + i;
-    const int row = m0 + lrow;
-    if (row >= M) continue;                                // (wave-uniform)
-    const float4 p0 = *reinterpret_cast<const float4*>(part + lrow * N + 4 * lane);
-    const float4 p1 = *reinterpret_cast<const float4*>(part + (32 + lrow) * N + 4 * lane);
-    float4 x = make_float4((p0.x + p1.x) + b4.x, (p0.y + p1.y) + b4.y, (p0.z + p1.z) + b4.z, (p0.w + p1.w) + b4.w);
-    if (residual) {
-      const float4 r4 = *reinterpret_cast<const float4*>(residual + (long long)row * N + 4 * lane);
-      x.x += r4.x, x.y += r4.y, x.z += r4.z, x.w += r4.w;
-    }
-    float sum = (x.x + x.y) + (x.z + x.w);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float mean = sum * (1.f / N);
-    const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
-    float sq = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float rstd = rsqrtf(sq * (1.f / N) + eps);
-    const float4 y = make_float4(fmaf(dx * rstd, g4.x, e4.x), fmaf(dy * rstd, g4.y, e4.y), fmaf(dz * rstd, g4.z, e4.z),
-                                 fmaf(dw * rstd, g4.w, e4.w));
-    *reinterpret_cast<float4*>(out + (long long)row * N + 4 * lane) = y;
-  }
-}
-
-template <int PL = 3>
-int launch_skln(const float* a, const uint16_t* w, const float* bias, const float* residual, float* out,
-                long long M, int K, const float* gamma, const float* beta, float eps, hipStream_t st) {
-  constexpr int smem = 2 * 32 * 256 * 4;
-  auto kern = gemm_skln_kernel<4, PL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess)
-      return pave_internal_fail(PAVE_E_LAUNCH, "gemm_skln: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((M + 31) / 32)), dim3(1024), smem, st, a, w, bias, residual, out, (int)M, K,
-                     gamma, beta, eps);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return pave_internal_fail(PAVE_E_LAUNCH, hipGetErrorString(e));
-  return PAVE_OK;
-}
-
+// (Linear + identity + LayerNorm at few rows as ONE launch -- a 1 024-thread block owning 32 whole rows, 8 column
+// tiles x 2 K halves, LayerNorm from LDS -- was built in round 6 and measured SLOWER than the K-split GEMM + LayerNorm
+// pass it was meant to replace: 300 x 256 x 256 13.8 against 7.6 us, 300 x 1024 x 256 41.8 against 11.4, 1 200 x 1024 x 256
+// 41.9 against 19.2 (tools/small_gemm_ksplit_ab.py at commit 188af1e: M / 32 blocks are 10 - 38 blocks for 256 CUs
+// and a wave walks half of K alone).  Removed; the two-launch form stays.)
 constexpr long long kSkTiles = 4096;     // 32 x 32 tiles (= blocks) up to which the K-split small-row form is taken
 constexpr long long kSkTiles256 = 1280;   // ... and at K = 256 .. 511 (4 - 7 slabs per wave): only where the blocks fit one round
 // ... and only up to 2 048 rows: a block re-reads its A rows once per 32 output columns, which a few hundred
@@ -2111,16 +1993,10 @@ static int gemm_q_ln_go(const float* a, const void* w_planes, const float* bias,
                         int K, int N, void* stream) {
   if (K % 32 != 0 || K < 64 || N != 256)
     return pave_internal_fail(PAVE_E_UNSUPPORTED, "gemm_q_ln: K %% 32 == 0, K >= 64 and N == 256 required");
-  if (small_rows_form(M, N) && (pave_internal_diag_variant() == 0 || pave_internal_diag_variant() == 19 ||
-                                pave_internal_diag_variant() == 21)) {
+  if (small_rows_form(M, N) && (pave_internal_diag_variant() == 0 || pave_internal_diag_variant() == 19)) {
     // few rows: the small-row GEMM (bias + identity in its epilogue), then LayerNorm in place -- two
     // launches of a few microseconds instead of 10 row tiles walking K behind barriers
-    // up to 2 048 rows, K >= 256: Linear + identity + LayerNorm as ONE launch (gemm_skln_kernel; diag variant 21: the
-    // two-launch form below, for A/B)
-    if (M <= kSkRows && K >= 256 && pave_internal_diag_variant() == 0)
-      return launch_skln<PL>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, gamma, beta, eps,
-                             reinterpret_cast<hipStream_t>(stream));
-    const int st1 = (small_rows_ksplit_form(M, N, K) && (pave_internal_diag_variant() == 0 || pave_internal_diag_variant() == 21))
+    const int st1 = (small_rows_ksplit_form(M, N, K) && pave_internal_diag_variant() == 0)
         ? launch_sk<PL>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K, 0, 0, N,
                         reinterpret_cast<hipStream_t>(stream))
         : launch_s<1, 4, PL>(a, static_cast<const uint16_t*>(w_planes), bias, residual, out, M, K, N, 0, K,

@@ -565,8 +565,7 @@ constexpr int g_diag_variant = 0;   // the shipped library has no kernel-form gl
                          // products instead of 16x16x32 products over slab pairs),
                          // 19 = the small-row selection of rounds 4 - 5 (no K-split small-row form: the forms the
                          // bit-equality tests compare), 20 = the wide GEMM capped at one block per CU (40 KiB of
-                         // unused dynamic LDS; tools/coresidency_probe.py), 21 = few-row Linear + LayerNorm as the
-                         // K-split GEMM + a LayerNorm pass (two launches) instead of gemm_skln_kernel
+                         // unused dynamic LDS; tools/coresidency_probe.py)
 
 // Shapes that take the 128 x 256, 8-wave tile (measured per shape, tools/bench_gemm_shapes.py)
 bool use_w8(long long M, int K, int N) {

@@ -63,23 +63,3 @@ for M, K, N, what in SHAPES:
     print(f'{M:5d} x {K:4d} x {N:5d}  {what:34s} K-split {res[0]:6.1f} us   one-wave / tile rule of round 5 {res[19]:6.1f} us'
           f'   tile kernels {res[8]:6.1f} us   (K-split vs tile: {err:.1e} relative)', flush=True)
 
-print()
-print('Linear + identity + LayerNorm at few rows: ONE launch (gemm_skln_kernel, shipped) | K-split GEMM + LayerNorm pass '
-      '(diag variant 21) | the 8-wave tile kernel (13)')
-for M, K, what in ((300, 256, 'out_proj + LN, one clip'), (300, 1024, 'FFN2 + LN, one clip'),
-                   (1200, 256, 'out_proj + LN, 4 clips'), (1200, 1024, 'FFN2 + LN, 4 clips'),
-                   (1433, 1024, 'the round-split remainder of a one-clip T = 3 encoder layer'),
-                   (1800, 256, 'out_proj + LN, 6 clips')):
-    a = torch.randn(M, K, device='cuda')
-    wp = ops.split_weight_bf16x3(torch.randn(256, K, device='cuda') / K ** 0.5)
-    b, ga, be = (torch.randn(256, device='cuda') for _ in range(3))
-    r = torch.randn(M, 256, device='cuda')
-    fn = lambda: ops.gemm_bf16x3_ln(a, wp, b, r, ga, be, 1e-5)   # noqa: E731
-    res, outs = {}, {}
-    for v in (0, 21, 13):
-        with native.diag_build(v):
-            res[v] = timed(fn)
-            outs[v] = fn().clone()
-    err = float((outs[0] - outs[13]).abs().max())
-    print(f'{M:5d} x {K:4d} x 256  {what:58s} {res[0]:6.1f} us | {res[21]:6.1f} us | {res[13]:6.1f} us   '
-          f'(one launch vs 8-wave: max |d| {err:.1e})', flush=True)
