@@ -2,7 +2,10 @@
 third_party/mmdetection/mmdet/models/backbones/resnet.py (Bottleneck :99-305, ResNet :308-672,
 forward :632-654).  Same ctor kwargs (the ones the PAVE-Net configs use) and state-dict keys.
 
-Dense convolutions are true contractions and go to MIOpen (MFMA) through PyTorch-ROCm.
+Dense convolutions are true contractions: in the default GEMM mode every one of them (7x7 stem, 1x1, 3x3, the
+strided downsample, the 64-channel stage as one chained launch per Bottleneck) is a split-operand MFMA launch of this
+package (ops.conv7x7s2_nchw_split / gemm_bf16x3 / conv3x3_split / conv1x1_strided_split / bottleneck_chain); MIOpen /
+hipBLASLt through PyTorch-ROCm serve the `'native'` mode, CPU tensors and autograd.
 Inference-time: frozen BatchNorm is folded into the preceding convolution (cached; the
 reference offers the same transformation as ``--fuse-conv-bn``, tools/test.py:227-228), and
 the whole trunk runs channels-last.

@@ -2,9 +2,12 @@
 state-dict keys (restated from third_party/mmcv/mmcv/cnn/bricks/transformer.py and
 third_party/mmdetection/mmdet/models/utils/{transformer,positional_encoding}.py).
 
-Dense ops (Linear / LayerNorm / nn.MultiheadAttention) run through PyTorch-ROCm (rocBLAS /
-hipBLASLt MFMA GEMMs); everything is inference-mode: dropout layers exist only as
-identities so that configs with ``dropout=0.1`` build unchanged.
+On the device, under ``no_grad`` and in the default GEMM mode (`set_gemm_mode('bf16x3')`) every dense op here --
+Linear, Linear + identity + LayerNorm, the FFN pair, the decoders' self-attention -- is a launch of this package's
+kernels (`ops.gemm_bf16x3*`, `ops.mha_core`); the torch expressions beside them serve CPU tensors, autograd and the
+`'native'` (vendor fp32-MFMA) mode.  Which side a forward took is measurable: `census.LaunchCensus`,
+`forward_device(strict=True)`.  Everything is inference-mode: dropout layers exist only as identities so that
+configs with ``dropout=0.1`` build unchanged.
 
 Layout note: sequence-first tensors ``[n, bs, C]`` handed between modules are kept as
 *views* of batch-first contiguous storage wherever possible (``seq_first_view``), so the
