@@ -340,9 +340,25 @@ def cpu_baseline_and_parity(model, args, frames, clip0, free_result, free_select
     for pose in ek[..., :2]:
         if fk.numel() and float((fk[..., :2] - pose).abs().amax(dim=(1, 2)).min()) < 5e-2:
             matched += 1
+    free_forced = None
+    if free_sel_equal is False:
+        # the free run made other (near-tie) selections than the oracle: one more oracle clip with the DEVICE's
+        # selections forced -- the free timed batch must then be reproduced pose for pose
+        R.SAMPLER = 'torch'
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            t2 = {'force_topk_idx': free_selection[0].cpu().view(1, -1),
+                  'force_score_topk_idx': free_selection[1].cpu().view(-1)}
+            _, _, ek2 = R.videopose_simple_test(sd, cfg, clip0, taps=t2)
+        torch.set_num_threads(default_threads)
+        same_n = tuple(ek2.shape) == tuple(fk.shape)
+        free_forced = dict(keep_equal=bool(same_n), oracle_poses=int(ek2.shape[0]),
+                           max_px=round(float((fk[..., :2] - ek2[..., :2]).abs().max()), 5) if same_n else None,
+                           note='the oracle re-run with the free timed batch\'s own two selections forced, against '
+                                'clip 0 of that batch')
     parity = dict(max_px=None if max_px is None else round(max_px, 5), keep_equal=bool(keep_equal),
                   oracle_poses=int(ek.shape[0]), free_run_poses_matched=matched,
-                  free_run_selection_is_the_oracles=free_sel_equal,
+                  free_run_selection_is_the_oracles=free_sel_equal, free_run_vs_oracle_with_its_selections=free_forced,
                   note='clip 0 vs the CPU oracle; max_px with the oracle\'s top-k selections pinned.  The free '
                        '(un-pinned) timed run reproduces the oracle\'s poses only where it makes the oracle\'s '
                        'selections: the 300 proposals are a sorted list and query i adds its own embedding to '
