@@ -190,11 +190,38 @@ struct ClockStamp {
     }
   }
 };
-#define PAVE_CLOCK_BEGIN(kind) const ClockStamp pave_cs(kind)
+// Phase stagger probe (tools/stagger_probe.py): the two workgroups that share a CU start a launch together and,
+// tiles taking equal time, stay in step -- main loops (matrix pipe) together, epilogues (HBM) together.  With
+// g_diag_stagger = n > 0 the first-round workgroups (blockIdx.x < 512) that sit in an ODD slot of their CU sleep
+// n x 8 128 shader clocks before they start, so that the pair runs out of phase.  Slot = bit 0 of the wave id on the
+// SIMD (mode 0), of the CU's thread-group id (mode 1), or of blockIdx.x (mode 2: a control -- neighbours in
+// blockIdx.x sit on different XCDs); g_diag_stagger = mode * 1000 + n.  g_diag_hwid[b] = HW_ID of wave 0 of block b.
+__device__ int g_diag_stagger = 0;
+__device__ unsigned g_diag_hwid[1024];
+__device__ __forceinline__ void diag_stagger() {
+  const int v = g_diag_stagger;
+  if (v <= 0 || blockIdx.y != 0 || blockIdx.x >= 1024) return;
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  if (threadIdx.x == 0) g_diag_hwid[blockIdx.x] = hw;
+  if (blockIdx.x >= 512) return;
+  const int mode = v / 1000, n = v % 1000;
+  const unsigned bit = mode == 0 ? hw & 1u : (mode == 1 ? (hw >> 16) & 1u : blockIdx.x & 1u);
+  if (bit)
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#define PAVE_CLOCK_BEGIN(kind) diag_stagger(); const ClockStamp pave_cs(kind)
 #define PAVE_CLOCK_END() pave_cs.end()
+// timing-only traffic probes (tools/ffn_traffic_probe.py; the results are WRONG on purpose): g_diag_stagger = -1: the
+// epilogue's stores are dropped (out-of-range buffer offsets); -2: every row tile of a plain-row launch reads the A
+// rows of tile 0 (they stay in L2); -3: both
+#define PAVE_PROBE_DROP_STORES() (g_diag_stagger == -1 || g_diag_stagger == -3)
+#define PAVE_PROBE_CACHED_A() (g_diag_stagger == -2 || g_diag_stagger == -3)
 #else
 #define PAVE_CLOCK_BEGIN(kind)
 #define PAVE_CLOCK_END()
+#define PAVE_PROBE_DROP_STORES() false
+#define PAVE_PROBE_CACHED_A() false
 #endif
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
@@ -370,7 +397,7 @@ __device__ __forceinline__ void gemm_q_body(
       a_base = reinterpret_cast<const unsigned char*>(A) +
                ((long long)m0 * (g.H > 0 ? g.H : K) + (g.W > 0 ? (long long)(n0 / g.W) * K : 0)) * 2;
     else if (KIND == 0)
-      a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * (g.H > 0 ? g.H : K) +
+      a_base = reinterpret_cast<const unsigned char*>(A + (long long)(PAVE_PROBE_CACHED_A() ? 0 : m0) * (g.H > 0 ? g.H : K) +
                                                       (g.W > 0 ? (long long)(n0 / g.W) * K : 0));
     if (KIND == 4) {
       a_base = reinterpret_cast<const unsigned char*>(A + (long long)m0 * g.Cin);
@@ -775,7 +802,7 @@ __device__ __forceinline__ void gemm_q_body(
 #pragma unroll
     for (int ps = 0; ps < NPR; ++ps) {
       const int lrow = wm * 32 * RM + ps * 8 + erow + late;
-      oro[ps] = lrow < orows ? (unsigned)(lrow * ldo * OB + ec4 * 4 * OB) : kOut;
+      oro[ps] = (lrow < orows && !PAVE_PROBE_DROP_STORES()) ? (unsigned)(lrow * ldo * OB + ec4 * 4 * OB) : kOut;
     }
     constexpr bool LNW = LNORM && WIDE;   // LayerNorm computed on the accumulator layout (below)
     if constexpr (LNW) {
@@ -2176,6 +2203,16 @@ static int bottleneck_chain_go(const float* c1, const void* w2_planes, const flo
 extern "C" int pave_diag_clock_reset(void) {
   unsigned long long z[16] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(g_clock_acc), z, sizeof(z)) == hipSuccess ? PAVE_OK : PAVE_E_LAUNCH;
+}
+extern "C" int pave_diag_set_stagger(int v) {
+  if (hipDeviceSynchronize() != hipSuccess) return PAVE_E_LAUNCH;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_stagger), &v, sizeof(v)) == hipSuccess ? PAVE_OK : PAVE_E_LAUNCH;
+}
+extern "C" int pave_diag_hwid_read(unsigned* out1024) {
+  if (!out1024) return PAVE_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return PAVE_E_LAUNCH;
+  return hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_diag_hwid), 1024 * sizeof(unsigned)) == hipSuccess
+             ? PAVE_OK : PAVE_E_LAUNCH;
 }
 extern "C" int pave_diag_clock_read(unsigned long long* out16) {
   if (!out16) return PAVE_E_ARG;
