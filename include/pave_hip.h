@@ -40,7 +40,7 @@ extern "C" {
 #define PAVE_E_UNSUPPORTED (-4) /* valid arguments, but not a shape this entry point's kernel covers */
 
 /* ABI version; bumped on any signature change (pavenet_amd/native.py checks it at load). */
-#define PAVE_ABI_VERSION 19
+#define PAVE_ABI_VERSION 20
 int pave_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* pave_last_error(void);
@@ -454,6 +454,25 @@ int pave_ref_update_f32(const float* tmp, const float* ref, float* out, long lon
 int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y,
                             long long y_batch_stride, int N, int HW, int C, int G, float eps,
                             double* partial, int nchunks, float* ab, void* stream);
+
+/*
+ * The same GroupNorm over up to four maps of one N, C and G at once -- the levels of the neck
+ * (necks/channel_mapper.py:90-100: one ConvModule per level, each with its own GroupNorm(32)) -- as THREE launches
+ * instead of three per level; per level the values are those of pave_groupnorm_nhwc_f32 with the same nchunks,
+ * bit for bit.  Scratch: partial [N * G * 2 * sum(nchunks)] doubles, ab [nlev * N * 2 * C] floats.
+ */
+typedef struct pave_gn_level {
+  const float* x;              /* [N, HW, C] dense */
+  const float* gamma;          /* [C] */
+  const float* beta;           /* [C] */
+  float* y;                    /* row n at y + n * y_batch_stride */
+  long long y_batch_stride;    /* floats, >= HW * C */
+  int HW;
+  int nchunks;                 /* row chunks of the statistics pass */
+  float eps;
+} pave_gn_level;
+int pave_groupnorm_levels_nhwc_f32(const pave_gn_level* levels, int nlev, int N, int C, int G, double* partial,
+                                   float* ab, void* stream);
 
 /*
  * out[M, N] = act([a | a2] @ W^T + bias + residual): two row matrices a [M, K1] and a2 [M, K - K1]

@@ -1510,6 +1510,119 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(
   }
 }
 
+// The same three passes over up to four maps at once (the neck's levels share N, C and G and differ in their
+// HW): one launch per pass instead of one per pass and level -- the small levels' launches are latency, not
+// work.  Every block finds its level from the cumulative block counts and then runs the single-level body on
+// it (same chunks, same summation order: the values are those of pave_groupnorm_nhwc_f32 bit for bit).
+struct GnLevels {
+  const float* x[4]; const float* gamma[4]; const float* beta[4]; float* y[4];
+  long long y_batch_stride[4];
+  long long partial_off[4];   // doubles
+  int HW[4], nchunks[4];
+  int chunk_end[4];           // cumulative chunk counts (stats grid)
+  int apply_end[4];           // cumulative block counts (apply grid)
+  float eps[4];
+  int nlev;
+};
+__global__ __launch_bounds__(256) void groupnorm_levels_stats_kernel(const GnLevels p, double* __restrict__ partial,
+                                                                    const int C, const int G) {
+  __shared__ double sh[256][2];
+  int l = 0;
+  while (l + 1 < p.nlev && (int)blockIdx.x >= p.chunk_end[l]) ++l;
+  const int chunk = (int)blockIdx.x - (l ? p.chunk_end[l - 1] : 0);
+  const int HW = p.HW[l], nchunks = p.nchunks[l];
+  const int tpr = C >> 2;
+  const int rpp = 256 / tpr;
+  const int c4 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
+  const int n = blockIdx.y;
+  const int rows_per_chunk = (HW + nchunks - 1) / nchunks;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(HW, rbeg + rows_per_chunk);
+  const float* xb = p.x[l] + (long long)n * HW * C + c4 * 4;
+  double s = 0.0, q = 0.0;
+  if (r0 < rpp)
+    for (int r = rbeg + r0; r < rend; r += rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (long long)r * C);
+      s += (double)((v.x + v.y) + (v.z + v.w));
+      q += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    }
+  sh[threadIdx.x][0] = (r0 < rpp) ? s : 0.0;
+  sh[threadIdx.x][1] = (r0 < rpp) ? q : 0.0;
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int tpg = (C / G) >> 2;
+    double ts = 0.0, tq = 0.0;
+    for (int r = 0; r < rpp; ++r)
+      for (int j = 0; j < tpg; ++j) {
+        const int t = r * tpr + threadIdx.x * tpg + j;
+        ts += sh[t][0];
+        tq += sh[t][1];
+      }
+    double* o = partial + p.partial_off[l] + (((long long)n * nchunks + chunk) * G + threadIdx.x) * 2;
+    o[0] = ts;
+    o[1] = tq;
+  }
+}
+// grid (N, levels): ab [level][N][2][C]
+__global__ __launch_bounds__(256) void groupnorm_levels_finalize_kernel(const GnLevels p,
+                                                                       const double* __restrict__ partial,
+                                                                       float* __restrict__ ab, const int N,
+                                                                       const int C, const int G) {
+  __shared__ float mean_s[256], rstd_s[256];
+  const int n = blockIdx.x, l = blockIdx.y;
+  const int HW = p.HW[l], nchunks = p.nchunks[l];
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double ts = 0.0, tq = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const double* o = partial + p.partial_off[l] + (((long long)n * nchunks + ch) * G + g) * 2;
+      ts += o[0];
+      tq += o[1];
+    }
+    const double cnt = (double)HW * (double)(C / G);
+    const double mean = ts / cnt;
+    double var = tq / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    mean_s[g] = (float)mean;
+    rstd_s[g] = (float)(1.0 / sqrt(var + (double)p.eps[l]));
+  }
+  __syncthreads();
+  float* abl = ab + (long long)l * N * 2 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / (C / G);
+    const float a = rstd_s[g] * p.gamma[l][c];
+    abl[((long long)n * 2) * C + c] = a;
+    abl[((long long)n * 2 + 1) * C + c] = p.beta[l][c] - mean_s[g] * a;
+  }
+}
+__global__ __launch_bounds__(256) void groupnorm_levels_apply_kernel(const GnLevels p, const float* __restrict__ ab,
+                                                                    const int N, const int C) {
+  int l = 0;
+  while (l + 1 < p.nlev && (int)blockIdx.x >= p.apply_end[l]) ++l;
+  const int b0 = l ? p.apply_end[l - 1] : 0;
+  const long long blk = (long long)blockIdx.x - b0, nblk = p.apply_end[l] - b0;
+  const int HW = p.HW[l];
+  const int tpr = C >> 2;
+  const long long total = (long long)N * HW * tpr;
+  const float* x = p.x[l];
+  float* y = p.y[l];
+  const float* abl = ab + (long long)l * N * 2 * C;
+  for (long long i = blk * 256 + threadIdx.x; i < total; i += nblk * 256) {
+    const int c4 = (int)(i % tpr);
+    const long long row = i / tpr;
+    const int n = (int)(row / HW);
+    const long long r = row - (long long)n * HW;
+    const float4 v = *reinterpret_cast<const float4*>(x + row * C + c4 * 4);
+    const float4 a = *reinterpret_cast<const float4*>(abl + ((long long)n * 2) * C + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(abl + ((long long)n * 2 + 1) * C + c4 * 4);
+    float4 o;
+    o.x = fmaf(v.x, a.x, b.x);
+    o.y = fmaf(v.y, a.y, b.y);
+    o.z = fmaf(v.z, a.z, b.z);
+    o.w = fmaf(v.w, a.w, b.w);
+    *reinterpret_cast<float4*>(y + (long long)n * p.y_batch_stride[l] + r * C + c4 * 4) = o;
+  }
+}
+
 // out = sigmoid(tmp + inverse_sigmoid(ref)): the reference-point update after every decoder layer
 // (OT:6733-6735, MT:865-866 with mmdet's inverse_sigmoid, eps = 1e-5) -- seven elementwise
 // launches of the PyTorch formulation in one; same operation order in fp32.
@@ -1961,6 +2074,48 @@ int pave_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* bet
   const long long nb = std::min<long long>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ab, y,
                      y_batch_stride, N, HW, C);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
+  return PAVE_OK;
+}
+
+int pave_groupnorm_levels_nhwc_f32(const pave_gn_level* levels, int nlev, int N, int C, int G, double* partial,
+                                   float* ab, void* stream) {
+  if (!levels || !partial || !ab) return fail(PAVE_E_ARG, "groupnorm_levels: null pointer");
+  if (nlev <= 0 || nlev > 4) return fail(PAVE_E_ARG, "groupnorm_levels: 1 .. 4 levels per call");
+  if (N <= 0 || N > 65535 || C <= 0 || G <= 0)
+    return fail(PAVE_E_ARG, "groupnorm_levels: sizes must be positive (N <= 65535)");
+  if (C % 4 != 0 || C > 1024 || C % G != 0 || (C / G) % 4 != 0 || G > 256 || 256 % (C / 4) != 0)
+    return fail(PAVE_E_UNSUPPORTED,
+                "groupnorm_levels: C %% 4 == 0, (C / G) %% 4 == 0, C / 4 divides 256, G <= 256");
+  GnLevels p{};
+  p.nlev = nlev;
+  long long off = 0, chunks = 0, blocks = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const pave_gn_level& v = levels[l];
+    if (!v.x || !v.gamma || !v.beta || !v.y) return fail(PAVE_E_ARG, "groupnorm_levels: null pointer in a level");
+    if (v.HW <= 0 || v.nchunks <= 0 || v.nchunks > 65535)
+      return fail(PAVE_E_ARG, "groupnorm_levels: HW and nchunks must be positive (nchunks <= 65535)");
+    if (v.y_batch_stride < (long long)v.HW * C)
+      return fail(PAVE_E_ARG, "groupnorm_levels: y_batch_stride smaller than one image");
+    p.x[l] = v.x, p.gamma[l] = v.gamma, p.beta[l] = v.beta, p.y[l] = v.y;
+    p.y_batch_stride[l] = v.y_batch_stride;
+    p.HW[l] = v.HW, p.nchunks[l] = v.nchunks, p.eps[l] = v.eps;
+    p.partial_off[l] = off;
+    off += (long long)N * v.nchunks * G * 2;
+    chunks += v.nchunks;
+    p.chunk_end[l] = (int)chunks;
+    const long long total = (long long)N * v.HW * (C / 4);
+    blocks += std::min<long long>((total + 255) / 256, 256 * 32);   // (per level what the one-level entry launches)
+    p.apply_end[l] = (int)blocks;
+  }
+  if (chunks > 65535 * 4ll || blocks >= (1ll << 31)) return fail(PAVE_E_ARG, "groupnorm_levels: grid too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(groupnorm_levels_stats_kernel, dim3((unsigned)chunks, (unsigned)N), dim3(256), 0, st, p, partial,
+                     C, G);
+  hipLaunchKernelGGL(groupnorm_levels_finalize_kernel, dim3((unsigned)N, (unsigned)nlev), dim3(256), 0, st, p, partial,
+                     ab, N, C, G);
+  hipLaunchKernelGGL(groupnorm_levels_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, ab, N, C);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;

@@ -46,6 +46,7 @@ SIGNATURES = {
     'pave_gemm_bf16x3_ln_f32': [_vp] * 6 + [ctypes.c_float, _vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _vp],
     'pave_groupnorm_nhwc_f32': [_vp] * 4 + [ctypes.c_longlong] + [_c_int] * 4 + [ctypes.c_float, _vp,
                                 _c_int, _vp, _vp],
+    'pave_groupnorm_levels_nhwc_f32': [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp],
     'pave_ref_update_f32': [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_float, _vp],
     'pave_conv7x7s2_nchw_split_f32': [_vp] * 4 + [_c_int] * 7 + [_vp],
     'pave_repitch_rows_f32': [_vp, _vp, ctypes.c_longlong, _c_int, _c_int, _vp],
@@ -74,8 +75,17 @@ SIGNATURES = {
 EXPORTED = tuple(SIGNATURES) + ('pave_abi_version', 'pave_last_error', 'pave_conv3x3_splitk_workspace_bytes',
                                 'pave_gemm_splitk_workspace_bytes')
 
+
+
+class GnLevel(ctypes.Structure):
+    """`pave_gn_level` of include/pave_hip.h (one map of pave_groupnorm_levels_nhwc_f32)."""
+    _fields_ = [('x', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('y_batch_stride', ctypes.c_longlong), ('HW', ctypes.c_int), ('nchunks', ctypes.c_int),
+                ('eps', ctypes.c_float)]
+
+
 _lib = None
-ABI_VERSION = 19  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
+ABI_VERSION = 20  # == PAVE_ABI_VERSION of include/pave_hip.h this file's SIGNATURES were written for
 
 
 class NativeLibraryError(RuntimeError):

@@ -105,15 +105,30 @@ class ChannelMapper(BaseModule):
         S = sum(y.shape[2] * y.shape[3] for y in ys)
         buf = torch.empty((n, S, C), dtype=torch.float32, device=ys[0].device)
         outs, st = [], 0
-        for m, y in zip(mods, ys):
-            gn = getattr(m, m.norm_name)
+        gns = [getattr(m, m.norm_name) for m in mods]
+        G = gns[0].num_groups
+        # (the kernel's own shape conditions, pave_groupnorm_nhwc_f32: anything else -> torch below)
+        hip_ok = [C % 4 == 0 and C <= 1024 and C % gn.num_groups == 0 and (C // gn.num_groups) % 4 == 0
+                  and gn.num_groups <= 256 and 256 % (C // 4) == 0 and gn.affine for gn in gns]
+        if all(hip_ok) and all(gn.num_groups == G for gn in gns):
+            # every level in the same three launches (statistics, scale / shift, apply)
+            from . import ops
+            levels = []
+            for gn, y in zip(gns, ys):
+                h, w = y.shape[2:]
+                rows = y.permute(0, 2, 3, 1).reshape(n, h * w, C)      # view of the NHWC storage
+                dst = buf[:, st:st + h * w]
+                levels.append((rows, gn.weight, gn.bias, gn.eps, dst))
+                outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))
+                st += h * w
+            ops.groupnorm_levels_into(levels, G)
+            return tuple(outs)
+        for m, y, gn, ok in zip(mods, ys, gns, hip_ok):
             G = gn.num_groups
             h, w = y.shape[2:]
             rows = y.permute(0, 2, 3, 1).reshape(n, h * w, C)          # view of the NHWC storage
             dst = buf[:, st:st + h * w]
-            # (the kernel's own shape conditions, pave_groupnorm_nhwc_f32: anything else -> torch below)
-            if C % 4 == 0 and C <= 1024 and C % G == 0 and (C // G) % 4 == 0 and G <= 256 \
-                    and 256 % (C // 4) == 0 and gn.affine:
+            if ok:
                 from . import ops
                 ops.groupnorm_nhwc_into(rows, gn.weight, gn.bias, G, gn.eps, dst)   # HIP, 3 launches
                 outs.append(dst.view(n, h, w, C).permute(0, 3, 1, 2))

@@ -15,6 +15,8 @@ PyTorch is used here only for device memory and the current HIP stream.  There
 is no CPU path: a non-device tensor raises, exactly as the reference's
 ``AT_ASSERTM(value.is_cuda())`` does (ms_deform_attn_cuda.cu:221-230).
 """
+import ctypes
+
 import torch
 
 from . import native
@@ -1018,6 +1020,42 @@ def groupnorm_nhwc_into(x_rows, gamma, beta, num_groups, eps, dst):
                                          ab.data_ptr(), _stream_ptr())
     native.check(st, 'groupnorm_nhwc_into')
     return dst
+
+
+def groupnorm_levels_into(levels, num_groups):
+    """GroupNorm of several NHWC maps of one N and C at once -- the neck's levels -- as three launches in all
+    (statistics, scale / shift, apply) instead of three per level; per level the values of `groupnorm_nhwc_into`,
+    bit for bit.  levels: [(x_rows [N, HW_l, C], gamma, beta, eps, dst [N, HW_l, C])]."""
+    lib = native.load()
+    _require(len(levels) >= 1, 'groupnorm_levels_into: at least one level')
+    N, _, C = levels[0][0].shape
+    dev = levels[0][0].device
+    for i0 in range(0, len(levels), 4):       # (the entry takes up to four maps per call)
+        part = levels[i0:i0 + 4]
+        arr = (native.GnLevel * len(part))()
+        total_chunks = 0
+        for j, (x_rows, gamma, beta, eps, dst) in enumerate(part):
+            _dev(x_rows, 'x', torch.float32)
+            _dev(gamma, 'gamma', torch.float32)
+            _dev(beta, 'beta', torch.float32)
+            _require(x_rows.dim() == 3 and x_rows.shape[0] == N and x_rows.shape[2] == C and x_rows.device == dev,
+                     'groupnorm_levels_into: every x [N, HW_l, C] on one device')
+            HW = x_rows.shape[1]
+            _require(gamma.numel() == C and beta.numel() == C, 'groupnorm_levels_into: gamma / beta [C]')
+            _require(dst.is_cuda and dst.dtype == torch.float32 and tuple(dst.shape) == (N, HW, C)
+                     and dst.stride(2) == 1 and dst.stride(1) == C and (N == 1 or dst.stride(0) >= HW * C),
+                     'groupnorm_levels_into: dst [N, HW, C] with dense rows')
+            nchunks = max(1, min(128, (HW + 63) // 64))       # (as groupnorm_nhwc_into)
+            arr[j] = native.GnLevel(x_rows.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dst.data_ptr(),
+                                    dst.stride(0) if N > 1 else HW * C, HW, nchunks, float(eps))
+            total_chunks += nchunks
+        partial = torch.empty((N * total_chunks * num_groups * 2,), dtype=torch.float64, device=dev)
+        ab = torch.empty((len(part), N, 2, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _Timed('groupnorm'):
+            st = lib.pave_groupnorm_levels_nhwc_f32(ctypes.cast(arr, ctypes.c_void_p), len(part), N, C,
+                                                    int(num_groups), partial.data_ptr(), ab.data_ptr(), _stream_ptr())
+        native.check(st, 'groupnorm_levels_into')
+    return [lv[4] for lv in levels]
 
 
 def gemm_bf16x3_ln(a, w_planes, bias, residual, gamma, beta, eps, out=None):

@@ -866,6 +866,33 @@ def test_groupnorm_nhwc_into_vs_torch_fp64(N, HW, C, G):
     assert torch.equal(buf, buf2)
 
 
+@pytest.mark.parametrize('N,hws,C,G', [(3, (1000, 260, 63, 20), 256, 32), (1, (7,), 64, 8),
+                                       (2, (4100, 35, 9000, 1, 130, 17), 128, 32)])
+def test_groupnorm_levels_equal_the_one_level_entry(N, hws, C, G):
+    """pave_groupnorm_levels_nhwc_f32 (every level of the neck in the same three launches; more than four maps
+    go in calls of four) against pave_groupnorm_nhwc_f32 level by level: bit-equal, written into slices of ONE
+    token buffer whose other rows stay untouched; and against fp64 torch."""
+    from pavenet_amd.ops import groupnorm_levels_into, groupnorm_nhwc_into
+    g = torch.Generator().manual_seed(sum(hws) + C)
+    S = sum(hws) + 11
+    buf = torch.full((N, S, C), 7.0).cuda()
+    ref = torch.full((N, S, C), 7.0).cuda()
+    levels, st = [], 4
+    for i, HW in enumerate(hws):
+        x = (torch.randn(N, HW, C, generator=g) * (1 + i) + 0.5 * i).cuda()
+        gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+        eps = 1e-5 * (1 + i)
+        levels.append((x, gam, bet, eps, buf[:, st:st + HW]))
+        groupnorm_nhwc_into(x, gam, bet, G, eps, ref[:, st:st + HW])
+        exp = torch.nn.functional.group_norm(x.double().permute(0, 2, 1), G, gam.double(), bet.double(),
+                                             eps).permute(0, 2, 1)
+        np.testing.assert_allclose(ref[:, st:st + HW].cpu().numpy(), exp.cpu().numpy(), rtol=1e-5, atol=2e-5)
+        st += HW
+    groupnorm_levels_into(levels, G)
+    assert torch.equal(buf, ref)
+    assert float(buf[:, :4].min()) == 7.0 and float(buf[:, st:].max()) == 7.0
+
+
 @pytest.mark.parametrize('N,H,W,C', [(2, 16, 24, 64), (1, 15, 9, 64), (3, 7, 8, 32)])
 def test_bias_relu_maxpool_vs_torch(N, H, W, C):
     """Stem tail: maxpool3x3/s2/p1(relu(x + b)) in one pass == torch's two ops (bit-exact)."""
