@@ -215,13 +215,17 @@ __device__ __forceinline__ void diag_stagger() {
 // timing-only traffic probes (tools/ffn_traffic_probe.py; the results are WRONG on purpose): g_diag_stagger = -1: the
 // epilogue's stores are dropped (out-of-range buffer offsets); -2: every row tile of a plain-row launch reads the A
 // rows of tile 0 (they stay in L2); -3: both
-#define PAVE_PROBE_DROP_STORES() (g_diag_stagger == -1 || g_diag_stagger == -3)
+#define PAVE_PROBE_DROP_STORES() (g_diag_stagger == -1 || g_diag_stagger == -3 || g_diag_stagger == -5)
 #define PAVE_PROBE_CACHED_A() (g_diag_stagger == -2 || g_diag_stagger == -3)
+// -4: the layer1 chain without its workgroup fences / barriers between the bodies (a body then reads rows its
+// neighbours may not have written yet: wrong values, same instruction stream otherwise); -5: -4 and -1
+#define PAVE_PROBE_NO_CHAIN_SYNC() (g_diag_stagger == -4 || g_diag_stagger == -5)
 #else
 #define PAVE_CLOCK_BEGIN(kind)
 #define PAVE_CLOCK_END()
 #define PAVE_PROBE_DROP_STORES() false
 #define PAVE_PROBE_CACHED_A() false
+#define PAVE_PROBE_NO_CHAIN_SYNC() false
 #endif
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
@@ -1184,6 +1188,7 @@ __device__ __forceinline__ void chain_sync() {
   // reached L2 (write-through L1, vmcnt(0)) and the CU's own L1 stays coherent with its stores,
   // so workgroup scope is enough.  (Agent scope writes back / invalidates the whole L2 of the
   // XCD per tile: measured 3x slower.)
+  if (PAVE_PROBE_NO_CHAIN_SYNC()) return;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
