@@ -1646,6 +1646,24 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // the epilogue's operands -- bias of the lane's column, identity of its four output elements -- are fetched NOW,
+  // beside the first slabs (an element is read by the thread that writes it: in-place residuals stay correct);
+  // behind the LDS exchange they were one more dependent memory round trip of a 7 - 10 us launch
+  const int col = n0 + lr;
+  const bool colok = col < n_real;
+  const float bj = (bias && colok) ? bias[col] : 0.f;
+  float rv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (residual && colok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * wave + i;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row < M) {
+        const int rr = res_rows > 0 ? (int)((unsigned)row % (unsigned)res_rows) : row;
+        rv[i] = residual[(long long)rr * n_real + col];
+      }
+    }
+  }
   f32x4 raw[PF][2];
   u32x4 wf[PF][PL];
   auto load = [&](const int slab, const int set) {
@@ -1685,9 +1703,6 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
   __syncthreads();
-  const int col = n0 + lr;
-  const bool colok = col < n_real;
-  const float bj = (bias && colok) ? bias[col] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 4 * wave + i;
@@ -1695,10 +1710,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(
     float v = ((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane];
     if (row < M && colok) {
       v += bj;
-      if (residual) {
-        const int rr = res_rows > 0 ? (int)((unsigned)row % (unsigned)res_rows) : row;
-        v += residual[(long long)rr * n_real + col];
-      }
+      if (residual) v += rv[i];
       if (relu == 1) v = fmaxf(v, 0.f);
       else if (relu == 2) v = gelu_erf(v);
       else if (relu == 3) v = sigmoid_f(v);

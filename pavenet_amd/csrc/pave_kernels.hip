@@ -482,14 +482,25 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
                                                       const double* __restrict__ sigmas,
                                                       const double thresh, int* __restrict__ keep,
                                                       int* __restrict__ order_out, const int N,
-                                                      const int K) {
+                                                      const int K, const int staged) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* order = reinterpret_cast<int*>(smem);           // [N]
+  double* var_s = reinterpret_cast<double*>(smem);     // [K] when `staged`: (2 sigma_k)^2
+  int* order = reinterpret_cast<int*>(smem + (staged ? K * sizeof(double) : 0));   // [N]
   int* dead = order + N;                               // [N]
   float* area = reinterpret_cast<float*>(dead + N);    // [N]
+  float* kxy = area + N;                               // [N][K][2] when `staged`
   const int b = blockIdx.x;
   const float* kp = kpts + (long long)b * N * K * 3;
   const float* sc = scores + (long long)b * N;
+  // the clip's key points once into LDS (the launcher stages them while they fit): the suppression sweep below is
+  // N dependent steps, each of which otherwise waits for its poses' coordinates from L2
+  if (staged) {
+    for (int t = threadIdx.x; t < N * K; t += blockDim.x) {
+      kxy[2 * t] = kp[3 * t];
+      kxy[2 * t + 1] = kp[3 * t + 1];
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) var_s[k] = (sigmas[k] * 2.0) * (sigmas[k] * 2.0);
+  }
   for (int j = threadIdx.x; j < N; j += blockDim.x) {
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
     for (int k = 0; k < K; ++k) {
@@ -523,10 +534,16 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
         const double denom = (double)((area[i] + area[j]) / 2.f) + 2.220446049250313e-16;
         double acc = 0.0;
         for (int k = 0; k < K; ++k) {
-          const float dx = kp[(j * K + k) * 3] - kp[(i * K + k) * 3];
-          const float dy = kp[(j * K + k) * 3 + 1] - kp[(i * K + k) * 3 + 1];
+          float dx, dy;
+          if (staged) {
+            dx = kxy[(j * K + k) * 2] - kxy[(i * K + k) * 2];
+            dy = kxy[(j * K + k) * 2 + 1] - kxy[(i * K + k) * 2 + 1];
+          } else {
+            dx = kp[(j * K + k) * 3] - kp[(i * K + k) * 3];
+            dy = kp[(j * K + k) * 3 + 1] - kp[(i * K + k) * 3 + 1];
+          }
           const float d2 = dx * dx + dy * dy;
-          const double var = (sigmas[k] * 2.0) * (sigmas[k] * 2.0);
+          const double var = staged ? var_s[k] : (sigmas[k] * 2.0) * (sigmas[k] * 2.0);
           const double e = (double)d2 / var / denom / 2.0;
           acc += exp(-e);
         }
@@ -1839,9 +1856,12 @@ int pave_oks_nms_f32(const float* kpts, const float* scores, const double* sigma
   if (n_clips <= 0 || N <= 0 || K <= 0) return fail(PAVE_E_ARG, "oks_nms: sizes must be positive");
   if (N > 4096) return fail(PAVE_E_ARG, "oks_nms: at most 4096 poses per clip");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t shmem = (size_t)N * (2 * sizeof(int) + sizeof(float));
+  size_t shmem = (size_t)N * (2 * sizeof(int) + sizeof(float));
+  const size_t stage = (size_t)N * K * 2 * sizeof(float) + (size_t)K * sizeof(double);
+  const int staged = shmem + stage <= 48 * 1024;   // (100 poses x 15 key points: 12 KB)
+  if (staged) shmem += stage;
   hipLaunchKernelGGL(oks_nms_kernel, dim3(n_clips), dim3(256), shmem, st, kpts, scores, sigmas,
-                     thresh, keep, order, N, K);
+                     thresh, keep, order, N, K, staged);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PAVE_E_LAUNCH, hipGetErrorString(e));
   return PAVE_OK;
