@@ -26,6 +26,29 @@ def test_capi_exports_every_declared_symbol():
     assert lib.pave_abi_version() == int(m.group(1)) == native.ABI_VERSION
 
 
+def test_ctypes_struct_layout_equals_the_header(tmp_path):
+    """`native.GnLevel` is passed to pave_groupnorm_levels_nhwc_f32 as an array of the header's `pave_gn_level`: a
+    field that drifts apart corrupts device pointers silently.  The header is compiled (gcc, as C) into a program
+    that prints sizeof / offsetof of every field; ctypes must agree."""
+    import shutil
+    import subprocess
+    from pavenet_amd import native
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f for f, _ in native.GnLevel._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pave_hip.h"\nint main(void) {\n'
+                   '  printf("%zu", sizeof(pave_gn_level));\n'
+                   + ''.join(f'  printf(" %zu", offsetof(pave_gn_level, {f}));\n' for f in fields)
+                   + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(native.GnLevel)
+    assert got[1:] == [getattr(native.GnLevel, f).offset for f in fields]
+
+
 def test_shipped_library_has_no_diagnostic_switches():
     """The kernel-form override and the timing-only ablations live in the -DPAVE_DIAG build only:
     the shipped library exports exactly the C ABI of the header, the diag build adds pave_diag_*."""
