@@ -220,12 +220,15 @@ __device__ __forceinline__ void diag_stagger() {
 // -4: the layer1 chain without its workgroup fences / barriers between the bodies (a body then reads rows its
 // neighbours may not have written yet: wrong values, same instruction stream otherwise); -5: -4 and -1
 #define PAVE_PROBE_NO_CHAIN_SYNC() (g_diag_stagger == -4 || g_diag_stagger == -5)
+// -6: the epilogue's 16-byte stores carry the non-temporal hint (aux bit 1 = nt on gfx942 / gfx950): same values
+#define PAVE_PROBE_NT_STORES() (g_diag_stagger == -6)
 #else
 #define PAVE_CLOCK_BEGIN(kind)
 #define PAVE_CLOCK_END()
 #define PAVE_PROBE_DROP_STORES() false
 #define PAVE_PROBE_CACHED_A() false
 #define PAVE_PROBE_NO_CHAIN_SYNC() false
+#define PAVE_PROBE_NT_STORES() false
 #endif
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
@@ -916,6 +919,9 @@ __device__ __forceinline__ void gemm_q_body(
             float4 v = *reinterpret_cast<const float4*>(Cs + (ps * 8 + erow) * QCST + ec4 * 4);
             v.x = fmaf(v.x, g4.x, be4.x), v.y = fmaf(v.y, g4.y, be4.y);
             v.z = fmaf(v.z, g4.z, be4.z), v.w = fmaf(v.w, g4.w, be4.w);
+            if (PAVE_PROBE_NT_STORES())
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, oro[ps] + j * 128, 0, 2);
+            else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, oro[ps] + j * 128, 0, 0);
           }
         } else {
@@ -972,7 +978,10 @@ __device__ __forceinline__ void gemm_q_body(
               typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
               const u32x2s hv = {pack_rne_f16(v[ps].x, v[ps].y), pack_rne_f16(v[ps].z, v[ps].w)};
               __builtin_amdgcn_raw_buffer_store_b64(hv, ors, (colok ? oro[rt * NPS + ps] : kOut) + j * 64, 0, 0);
-            } else
+            } else if (PAVE_PROBE_NT_STORES())
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ps]), ors,
+                                                   (colok ? oro[rt * NPS + ps] : kOut) + j * 128, 0, 2);
+            else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ps]), ors,
                                                    (colok ? oro[rt * NPS + ps] : kOut) + j * 128, 0, 0);
           }

@@ -59,7 +59,7 @@ def main():
         launches[0][1]()
     torch.cuda.synchronize()
     print(f'# {n} frames, S = {S} rows; us per launch')
-    print(f'# {"launch":44s} {"shipped":>9s} {"no stores":>10s} {"A in L2":>9s} {"both":>9s} {"1 blk/CU":>9s}')
+    print(f'# {"launch":44s} {"shipped":>9s} {"no stores":>10s} {"A in L2":>9s} {"both":>9s} {"1 blk/CU":>9s} {"nt stores":>10s}')
     for label, fn in launches:
         row = []
         for v in (0, -1, -2, -3):
@@ -69,6 +69,10 @@ def main():
         native.use_diag_build(20)
         row.append(timed(fn))
         native.use_diag_build(0)
+        lib.pave_diag_set_stagger(-6)      # (stores with the non-temporal hint: same values)
+        row.append(timed(fn))
+        lib.pave_diag_set_stagger(0)
+        row.append(timed(fn))              # (shipped again: the drift of the box over the row)
         print(f'  {label:44s} ' + ' '.join(f'{t:9.1f}' for t in row))
     # the same arithmetic on all-zero operands (the matrix pipe's data-dependent power)
     x.zero_()
