@@ -222,6 +222,8 @@ __device__ __forceinline__ void diag_stagger() {
 #define PAVE_PROBE_NO_CHAIN_SYNC() (g_diag_stagger == -4 || g_diag_stagger == -5)
 // -6: the epilogue's 16-byte stores carry the non-temporal hint (aux bit 1 = nt on gfx942 / gfx950): same values
 #define PAVE_PROBE_NT_STORES() (g_diag_stagger == -6)
+// -7: the A operand's three planes are the raw fp32 bits (no vector arithmetic for the split; wrong values)
+#define PAVE_PROBE_FREE_SPLIT() (g_diag_stagger == -7)
 #else
 #define PAVE_CLOCK_BEGIN(kind)
 #define PAVE_CLOCK_END()
@@ -229,6 +231,7 @@ __device__ __forceinline__ void diag_stagger() {
 #define PAVE_PROBE_CACHED_A() false
 #define PAVE_PROBE_NO_CHAIN_SYNC() false
 #define PAVE_PROBE_NT_STORES() false
+#define PAVE_PROBE_FREE_SPLIT() false
 #endif
 
 // KIND: 0 = plain rows A [M, K] (row stride g.H floats if g.H > 0; GROUPED when g.W > 0: the N axis
@@ -556,6 +559,11 @@ __device__ __forceinline__ void gemm_q_body(
     if constexpr (AH) {      // the lane's 8 halves ARE the operand
       apl[set][rt][0] = __builtin_bit_cast(u32x4, lo);
     } else if constexpr (PL == 3) {
+      if (PAVE_PROBE_FREE_SPLIT()) {
+        apl[set][rt][0] = __builtin_bit_cast(u32x4, lo);
+        apl[set][rt][1] = __builtin_bit_cast(u32x4, hi);
+        apl[set][rt][2] = __builtin_bit_cast(u32x4, lo);
+      } else
       split8(lo, hi, apl[set][rt]);
     } else {
       apl[set][rt][0] = u32x4{pack_rne_f16(lo.x, lo.y), pack_rne_f16(lo.z, lo.w), pack_rne_f16(hi.x, hi.y),

@@ -4,7 +4,7 @@ launches compute WRONG results on purpose.)
 `pave_bottleneck_chain_f32` runs three GEMM bodies per row tile (3x3 | conv3 + identity | next conv1); between
 them the tile's rows go through global memory behind a workgroup fence + barrier, and each body starts with an
 empty DMA ring.  Probes: the same launches (a) without the fences / barriers between the bodies (`g_diag_stagger`
-= -4), (b) with every store dropped (-1: no HBM writes; the bodies read whatever the buffers held), (c) both (-5);
+= -4), (b) with every store dropped (-1: no HBM writes; the bodies read whatever the buffers held), (c) both (-5), (d) with the A operand's three planes taken as the raw fp32 bits (-7: no vector arithmetic for the split);
 and the three bodies as separate launches for scale.
 
     python tools/chain_probe.py [frames=28]
@@ -59,10 +59,10 @@ def main():
         cases[1][1]()
     torch.cuda.synchronize()
     print(f'# {F} frames of {H} x {W}: {M} pixels; us per launch')
-    print(f'# {"launch":72s} {"shipped":>9s} {"no syncs":>9s} {"no stores":>10s} {"neither":>9s}')
+    print(f'# {"launch":72s} {"shipped":>9s} {"no syncs":>9s} {"no stores":>10s} {"neither":>9s} {"free split":>10s}')
     for label, fn in cases:
         row = []
-        for v in (0, -4, -1, -5):
+        for v in (0, -4, -1, -5, -7):
             lib.pave_diag_set_stagger(v)
             row.append(timed(fn))
         lib.pave_diag_set_stagger(0)
@@ -73,7 +73,10 @@ def main():
     a256 = rnd(M, 256).relu_()
     idr = rnd(M, 256)
     o256 = torch.empty(M, 256, device=dev)
+    a1024 = rnd(F * 50 * 84, 1024).relu_()
+    w1024 = mk(256, 1024)
     parts = [
+        ('(for scale) layer3 conv1 1024 -> 256 + ReLU, 256-column tiles', lambda: ops.gemm_bf16x3(a1024, w1024, b256, relu=True)),
         ('3x3 64 -> 64 + ReLU', lambda: ops.conv3x3_split(c1, w2, b64, relu=True, cout=64)),
         ('conv3 64 -> 256 + identity + ReLU', lambda: ops.gemm_bf16x3(a64, w3, b256, idr, relu=True, out=o256)),
         ('conv1 256 -> 64 + ReLU', lambda: ops.gemm_bf16x3(a256, w1n, b64, relu=True)),
@@ -81,13 +84,14 @@ def main():
     tot = [0.0, 0.0]
     for label, fn in parts:
         row = []
-        for v in (0, -1):
+        for v in (0, -1, -7):
             lib.pave_diag_set_stagger(v)
             row.append(timed(fn))
         lib.pave_diag_set_stagger(0)
-        tot[0] += row[0]
-        tot[1] += row[1]
-        print(f'  {label:72s} {row[0]:9.1f} {"":>9s} {row[1]:10.1f}')
+        if not label.startswith('(for scale)'):
+            tot[0] += row[0]
+            tot[1] += row[1]
+        print(f'  {label:72s} {row[0]:9.1f} {"":>9s} {row[1]:10.1f} {"":>9s} {row[2]:10.1f}')
     print(f'  {"sum of the three bodies as separate launches":72s} {tot[0]:9.1f} {"":>9s} {tot[1]:10.1f}')
     del c2
 
